@@ -1,0 +1,594 @@
+/*
+ * sqy_oracle.c -- CPU restatement of the sqeazy hot path.  TEST INFRASTRUCTURE ONLY (see
+ * sqy_oracle.h): nothing under sqeazy_amd/ may include, link or call this file.
+ *
+ * Compile WITHOUT -ffast-math (the reference's release flags use it, which makes its float
+ * paths compiler dependent; the declared parity target is IEEE evaluation in statement order).
+ *
+ * Paths cited are relative to /root/reference/src/cpp/src.
+ */
+#include "sqy_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* bitswap1                                                                                    */
+/* ------------------------------------------------------------------------------------------ */
+
+/* encoders/bitplane_reorder_scalar.hpp:27-74 (scalar_bitplane_reorder_encode<1>) with the tail
+ * rule of encoders/bitswap_scheme_impl.hpp:97-103: W = bits per element, L = len - len % W,
+ * S = L / W.  Bit b of element i lands in word (W-1-b)*S + i/W at bit W-1-(i%W).
+ * Elements [L,len) are copied unchanged. */
+void sqo_bitswap1_encode_u16(const uint16_t* in, uint16_t* out, size_t len)
+{
+    const unsigned W = 16;
+    const size_t L = len - (len % W);
+    const size_t S = L / W;
+    for (size_t i = L; i < len; ++i) out[i] = in[i];
+    memset(out, 0, L * sizeof(uint16_t));
+    for (size_t i = 0; i < L; ++i) {
+        const uint16_t v = in[i];
+        const unsigned obit = (W - 1) - (unsigned)(i % W);
+        for (unsigned b = 0; b < W; ++b) {
+            const size_t oidx = (size_t)(W - 1 - b) * S + i / W;
+            out[oidx] = (uint16_t)(out[oidx] | (((v >> b) & 1u) << obit));
+        }
+    }
+}
+
+void sqo_bitswap1_encode_u8(const uint8_t* in, uint8_t* out, size_t len)
+{
+    const unsigned W = 8;
+    const size_t L = len - (len % W);
+    const size_t S = L / W;
+    for (size_t i = L; i < len; ++i) out[i] = in[i];
+    memset(out, 0, L);
+    for (size_t i = 0; i < L; ++i) {
+        const uint8_t v = in[i];
+        const unsigned obit = (W - 1) - (unsigned)(i % W);
+        for (unsigned b = 0; b < W; ++b) {
+            const size_t oidx = (size_t)(W - 1 - b) * S + i / W;
+            out[oidx] = (uint8_t)(out[oidx] | (((v >> b) & 1u) << obit));
+        }
+    }
+}
+
+/* encoders/sse_utils.hpp:1365-1433 (simd_segment_broadcast) + :1150-1217
+ * (simd_collect_single_bitplane_impl): one full pass over the input per bit-plane, planes
+ * distributed over <= 16 threads, 8 elements gathered per step through a sign-bit mask
+ * (the reference shifts the wanted bit to the msb and uses movemask; the scalar loop below
+ * collects the same 8 bits).  Output identical to sqo_bitswap1_encode_u16. */
+void sqo_bitswap1_encode_u16_planes(const uint16_t* in, uint16_t* out, size_t len, int nthreads)
+{
+    const unsigned W = 16;
+    const size_t L = len - (len % W);
+    const size_t S = L / W;
+    for (size_t i = L; i < len; ++i) out[i] = in[i];
+    if (nthreads > (int)W) nthreads = (int)W;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+    for (int seg = 0; seg < (int)W; ++seg) {
+        const unsigned b = W - 1 - (unsigned)seg; /* plane 0 of the output is the msb */
+        uint16_t* dst = out + (size_t)seg * S;
+        for (size_t w = 0; w < S; ++w) {
+            const uint16_t* p = in + w * W;
+            unsigned acc = 0;
+            for (unsigned j = 0; j < W; ++j) acc = (acc << 1) | ((p[j] >> b) & 1u);
+            dst[w] = (uint16_t)acc;
+        }
+    }
+}
+
+/* encoders/bitplane_reorder_scalar.hpp:81-116 + bitswap_scheme_impl.hpp:147-165 */
+void sqo_bitswap1_decode_u16(const uint16_t* in, uint16_t* out, size_t len)
+{
+    const unsigned W = 16;
+    const size_t L = len - (len % W);
+    const size_t S = L / W;
+    for (size_t i = L; i < len; ++i) out[i] = in[i];
+    for (size_t i = 0; i < L; ++i) {
+        unsigned v = 0;
+        const unsigned ibit = (W - 1) - (unsigned)(i % W);
+        for (unsigned b = 0; b < W; ++b) {
+            const size_t iidx = (size_t)(W - 1 - b) * S + i / W;
+            v |= ((in[iidx] >> ibit) & 1u) << b;
+        }
+        out[i] = (uint16_t)v;
+    }
+}
+
+void sqo_bitswap1_decode_u8(const uint8_t* in, uint8_t* out, size_t len)
+{
+    const unsigned W = 8;
+    const size_t L = len - (len % W);
+    const size_t S = L / W;
+    for (size_t i = L; i < len; ++i) out[i] = in[i];
+    for (size_t i = 0; i < L; ++i) {
+        unsigned v = 0;
+        const unsigned ibit = (W - 1) - (unsigned)(i % W);
+        for (unsigned b = 0; b < W; ++b) {
+            const size_t iidx = (size_t)(W - 1 - b) * S + i / W;
+            v |= ((in[iidx] >> ibit) & 1u) << b;
+        }
+        out[i] = (uint8_t)v;
+    }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* diff3x3x1                                                                                   */
+/* ------------------------------------------------------------------------------------------ */
+
+/* neighborhood_utils.hpp:160-240 for last_plane_neighborhood<3> (offsets begin {-1,-1,-1},
+ * end {2,2,0} on axes {x,y,z}).  halo::world is indexed world[2]=w(x), world[1]=h(y),
+ * world[0]=d(z), but non_halo_end(dim) indexes world[dim] with dim 0 meaning "x" -- so the x
+ * extent comes out of the DEPTH and the z extent out of the WIDTH (reference quirk, kept):
+ *   non_halo_begin(*) = 1
+ *   non_halo_end(0) = world[0]-1 = Z-1      -> halo_size_x = Z-2       (diff_scheme_impl.hpp:97)
+ *   non_halo_end(1) = world[1]-1 = Y-1
+ *   non_halo_end(2) = world[2]   = X        (z loop runs to X, clipped by offset < length)
+ * compute_offsets_in_x: num_offsets_required = (X-1)*(Y-2); when that is <= 1 there is a single
+ * offset (=1) and halo_size_x = length - 1 (diff_scheme_impl.hpp:98-101). */
+size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, size_t* halo_size_x)
+{
+    const size_t Z = shape[0], Y = shape[1], X = shape[2];
+    const size_t length = Z * Y * X;
+    /* compute_offsets_in_x: int non_halo_length; if(non_halo_length != (int)world.at(i)) num *= ... */
+    long num = 1;
+    if (((int)X - 1) != (int)X) num *= (long)((int)X - 1);          /* i = 2 */
+    if (((int)Y - 2) != (int)Y) num *= (long)((int)Y - 2);          /* i = 1 */
+    if (halo_size_x) *halo_size_x = 0;
+    if (num <= 1 || Z < 2) {
+        /* the reference takes its single-offset branch (offset 1, halo_size_x = length-1) and
+         * reads in front of the buffer: undefined there, refused here (0 offsets). */
+        return 0;
+    }
+    size_t n = 0, first = 0;
+    for (size_t z = 1; z < X; ++z) {
+        for (size_t y = 1; y + 1 < Y; ++y) {
+            const size_t off = z * Y * X + y * X + 1;
+            if (off < length) {
+                if (n == 0) first = off;
+                if (out && n < cap) out[n] = off;
+                ++n;
+            }
+        }
+    }
+    if (halo_size_x) *halo_size_x = (n == 1) ? (length - first) : (Z - 2); /* diff_scheme_impl.hpp:97-101 */
+    return n;
+}
+
+/* diff_scheme_utils.hpp:70-99 (naive_sum): the 9 neighbours in plane z-1 are addressed through
+ * the flat index (coordinates are re-derived from it, so idx-frame+dy*X+dx for 16-bit data where
+ * coord_t = short holds every coordinate); the sum is accumulated in the PIXEL type (wraps). */
+#define SQO_DIFF_BODY(T, ST, SUMT)                                                                       \
+    const size_t Z = shape[0], Y = shape[1], X = shape[2];                                               \
+    const size_t length = Z * Y * X;                                                                     \
+    const size_t frame = X * Y;                                                                          \
+    memcpy(out, in, length * sizeof(T));                                                                 \
+    size_t hx = 0;                                                                                       \
+    size_t noff = sqo_diff3x3x1_offsets(shape, NULL, 0, &hx);                                            \
+    if (noff == 0) return 1;                                                                             \
+    size_t* offs = (size_t*)malloc((noff ? noff : 1) * sizeof(size_t));                                  \
+    if (!offs) return 1;                                                                                 \
+    sqo_diff3x3x1_offsets(shape, offs, noff, &hx);                                                       \
+    for (size_t o = 0; o < noff; ++o) {                                                                  \
+        for (size_t k = 0; k < hx; ++k) {                                                                \
+            const size_t idx = offs[o] + k;                                                              \
+            T sum = 0;                                                                                   \
+            for (long dy = -1; dy <= 1; ++dy)                                                            \
+                for (long dx = -1; dx <= 1; ++dx)                                                        \
+                    sum = (T)(sum + src[(size_t)((long)idx - (long)frame + dy * (long)X + dx)]);         \
+            const SUMT local_sum = (SUMT)sum;                                                            \
+            BODY_STORE                                                                                   \
+        }                                                                                                \
+    }                                                                                                    \
+    free(offs);                                                                                          \
+    return 0;
+
+int sqo_diff3x3x1_encode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3])
+{
+    const uint16_t* src = in;
+#define BODY_STORE out[idx] = (uint16_t)(int16_t)(in[idx] - local_sum / 9u);
+    SQO_DIFF_BODY(uint16_t, int16_t, unsigned int)
+#undef BODY_STORE
+}
+
+/* 8-bit: coord_t = char (traits.hpp:10-11), so z/y/x derived from the flat index are truncated to
+ * 8 bits; with every extent <= 127 they are exact and the flat-index form above holds.  Larger
+ * 8-bit volumes index out of bounds in the reference (undefined); refused here. */
+int sqo_diff3x3x1_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3])
+{
+    if (shape[0] > 127 || shape[1] > 127 || shape[2] > 127) return 1;
+    const uint8_t* src = in;
+#define BODY_STORE out[idx] = (uint8_t)(int8_t)(in[idx] - local_sum / 9u);
+    SQO_DIFF_BODY(uint8_t, int8_t, unsigned short)
+#undef BODY_STORE
+}
+
+/* diff_scheme_impl.hpp:143-194: decode walks the same offsets in order and reads the ALREADY
+ * DECODED output (plane z-1 is complete before plane z only in serial order; restated serially). */
+int sqo_diff3x3x1_decode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3])
+{
+    const uint16_t* src = out;
+#define BODY_STORE out[idx] = (uint16_t)((int16_t)in[idx] + local_sum / 9u);
+    SQO_DIFF_BODY(uint16_t, int16_t, unsigned int)
+#undef BODY_STORE
+}
+
+int sqo_diff3x3x1_decode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3])
+{
+    if (shape[0] > 127 || shape[1] > 127 || shape[2] > 127) return 1;
+    const uint8_t* src = out;
+#define BODY_STORE out[idx] = (uint8_t)((int8_t)in[idx] + local_sum / 9u);
+    SQO_DIFF_BODY(uint8_t, int8_t, unsigned short)
+#undef BODY_STORE
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LZ4 block compressor -- liblz4 1.9.3, LZ4_compress_generic(byU32, limitedOutput, accel 1)   */
+/* as reached from LZ4F_compressUpdate -> LZ4F_makeBlock -> LZ4_compress_fast_continue on a    */
+/* fresh stream (sqeazy call sites: encoders/lz4_utils.hpp:118-170).  Third-party dependency,  */
+/* not in the reference tree; restated from the block format + upstream behaviour and pinned   */
+/* against liblz4.so.1.9.3 by oracle/gen_golden.py.                                            */
+/* ------------------------------------------------------------------------------------------ */
+#define LZ4_MINMATCH 4
+#define LZ4_MFLIMIT 12
+#define LZ4_LASTLITERALS 5
+#define LZ4_MINLENGTH (LZ4_MFLIMIT + 1)
+#define LZ4_MAXD 65535
+#define LZ4_MLBITS 4
+#define LZ4_MLMASK 15u
+#define LZ4_RUNMASK 15u
+#define LZ4_SKIPTRIGGER 6
+#define LZ4_HASHLOG 12
+
+static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
+static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
+
+static inline uint32_t lz4_hash5(const uint8_t* p)
+{
+    return (uint32_t)(((rd64(p) << 24) * 889523592379ULL) >> (64 - LZ4_HASHLOG));
+}
+
+int sqo_lz4_block_compress(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    uint32_t table[1 << LZ4_HASHLOG];
+    memset(table, 0, sizeof(table));
+    if (n <= 0) return 0;
+
+    const uint8_t* const base = src;
+    const uint8_t* ip = src;
+    const uint8_t* anchor = src;
+    const uint8_t* const iend = src + n;
+    const uint8_t* const mflimitPlusOne = iend - LZ4_MFLIMIT + 1;
+    const uint8_t* const matchlimit = iend - LZ4_LASTLITERALS;
+    uint8_t* op = dst;
+    uint8_t* const olimit = dst + cap;
+    uint32_t forwardH;
+
+    if (n < LZ4_MINLENGTH) goto last_literals;
+
+    table[lz4_hash5(ip)] = 0;
+    ip++;
+    forwardH = lz4_hash5(ip);
+
+    for (;;) {
+        const uint8_t* match;
+        uint8_t* token;
+        {
+            const uint8_t* forwardIp = ip;
+            int step = 1;
+            int searchMatchNb = 1 << LZ4_SKIPTRIGGER;
+            do {
+                const uint32_t h = forwardH;
+                const uint32_t current = (uint32_t)(forwardIp - base);
+                uint32_t matchIndex = table[h];
+                ip = forwardIp;
+                forwardIp += step;
+                step = (searchMatchNb++ >> LZ4_SKIPTRIGGER);
+                if (forwardIp > mflimitPlusOne) goto last_literals;
+                match = base + matchIndex;
+                forwardH = lz4_hash5(forwardIp);
+                table[h] = current;
+                if (matchIndex + LZ4_MAXD < current) continue;
+                if (rd32(match) == rd32(ip)) break;
+            } while (1);
+        }
+        while ((ip > anchor) && (match > src) && (ip[-1] == match[-1])) { ip--; match--; }
+
+        {
+            const unsigned litLength = (unsigned)(ip - anchor);
+            token = op++;
+            if (op + litLength + (2 + 1 + LZ4_LASTLITERALS) + (litLength / 255) > olimit) return 0;
+            if (litLength >= LZ4_RUNMASK) {
+                int len = (int)(litLength - LZ4_RUNMASK);
+                *token = (uint8_t)(LZ4_RUNMASK << LZ4_MLBITS);
+                for (; len >= 255; len -= 255) *op++ = 255;
+                *op++ = (uint8_t)len;
+            } else {
+                *token = (uint8_t)(litLength << LZ4_MLBITS);
+            }
+            memcpy(op, anchor, litLength);
+            op += litLength;
+        }
+    next_match:
+        {
+            const unsigned offset = (unsigned)(ip - match);
+            *op++ = (uint8_t)offset;
+            *op++ = (uint8_t)(offset >> 8);
+        }
+        {
+            unsigned matchCode;
+            {
+                const uint8_t* pi = ip + LZ4_MINMATCH;
+                const uint8_t* pm = match + LZ4_MINMATCH;
+                while (pi < matchlimit && *pi == *pm) { pi++; pm++; }
+                matchCode = (unsigned)(pi - (ip + LZ4_MINMATCH));
+            }
+            ip += (size_t)matchCode + LZ4_MINMATCH;
+            if (op + (1 + LZ4_LASTLITERALS) + (matchCode + 240) / 255 > olimit) return 0;
+            if (matchCode >= LZ4_MLMASK) {
+                *token = (uint8_t)(*token + LZ4_MLMASK);
+                matchCode -= LZ4_MLMASK;
+                while (matchCode >= 255) { *op++ = 255; matchCode -= 255; }
+                *op++ = (uint8_t)matchCode;
+            } else {
+                *token = (uint8_t)(*token + matchCode);
+            }
+        }
+        anchor = ip;
+        if (ip >= mflimitPlusOne) break;
+
+        table[lz4_hash5(ip - 2)] = (uint32_t)(ip - 2 - base);
+        {
+            const uint32_t h = lz4_hash5(ip);
+            const uint32_t current = (uint32_t)(ip - base);
+            const uint32_t matchIndex = table[h];
+            match = base + matchIndex;
+            table[h] = current;
+            if ((matchIndex + LZ4_MAXD >= current) && (rd32(match) == rd32(ip))) {
+                token = op++;
+                *token = 0;
+                goto next_match;
+            }
+        }
+        forwardH = lz4_hash5(++ip);
+    }
+
+last_literals:
+    {
+        const size_t lastRun = (size_t)(iend - anchor);
+        if (op + lastRun + 1 + ((lastRun + 255 - LZ4_RUNMASK) / 255) > olimit) return 0;
+        if (lastRun >= LZ4_RUNMASK) {
+            size_t acc = lastRun - LZ4_RUNMASK;
+            *op++ = (uint8_t)(LZ4_RUNMASK << LZ4_MLBITS);
+            for (; acc >= 255; acc -= 255) *op++ = 255;
+            *op++ = (uint8_t)acc;
+        } else {
+            *op++ = (uint8_t)(lastRun << LZ4_MLBITS);
+        }
+        memcpy(op, anchor, lastRun);
+        op += lastRun;
+    }
+    return (int)(op - dst);
+}
+
+int sqo_lz4_block_decompress(const uint8_t* src, int n, uint8_t* dst, int cap)
+{
+    const uint8_t* ip = src;
+    const uint8_t* const iend = src + n;
+    uint8_t* op = dst;
+    uint8_t* const oend = dst + cap;
+    while (ip < iend) {
+        const unsigned token = *ip++;
+        size_t lit = token >> 4;
+        if (lit == 15) {
+            unsigned s;
+            do { if (ip >= iend) return -1; s = *ip++; lit += s; } while (s == 255);
+        }
+        if ((size_t)(iend - ip) < lit || (size_t)(oend - op) < lit) return -1;
+        memcpy(op, ip, lit);
+        op += lit;
+        ip += lit;
+        if (ip >= iend) break;
+        if (iend - ip < 2) return -1;
+        const size_t offset = (size_t)ip[0] | ((size_t)ip[1] << 8);
+        ip += 2;
+        if (offset == 0 || offset > (size_t)(op - dst)) return -1;
+        size_t ml = token & 15u;
+        if (ml == 15) {
+            unsigned s;
+            do { if (ip >= iend) return -1; s = *ip++; ml += s; } while (s == 255);
+        }
+        ml += LZ4_MINMATCH;
+        if ((size_t)(oend - op) < ml) return -1;
+        const uint8_t* m = op - offset;
+        for (size_t i = 0; i < ml; ++i) op[i] = m[i];
+        op += ml;
+    }
+    return (int)(op - dst);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* xxh32 (LZ4 frame header checksum) -- public XXH32 definition                               */
+/* ------------------------------------------------------------------------------------------ */
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+
+uint32_t sqo_xxh32(const uint8_t* p, size_t len, uint32_t seed)
+{
+    const uint32_t P1 = 2654435761U, P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
+    const uint8_t* const end = p + len;
+    uint32_t h;
+    if (len >= 16) {
+        const uint8_t* const limit = end - 16;
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = rotl32(v1 + rd32(p) * P2, 13) * P1; p += 4;
+            v2 = rotl32(v2 + rd32(p) * P2, 13) * P1; p += 4;
+            v3 = rotl32(v3 + rd32(p) * P2, 13) * P1; p += 4;
+            v4 = rotl32(v4 + rd32(p) * P2, 13) * P1; p += 4;
+        } while (p <= limit);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint32_t)len;
+    while (p + 4 <= end) { h = rotl32(h + rd32(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; p++; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* LZ4 framing as sqeazy drives it                                                             */
+/* ------------------------------------------------------------------------------------------ */
+static const size_t lz4f_block_bytes[8] = {0, 0, 0, 0, 64u << 10, 256u << 10, 1u << 20, 4u << 20};
+
+/* LZ4F_compressBound(chunk, prefs) + LZ4F_HEADER_SIZE_MAX for autoFlush=0, no checksums
+ * (values pinned by tests/test_lz4_sandbox.cpp:387-430: 256 KiB -> 262152; header max 19). */
+static size_t lz4f_compress_bound(size_t srcSize, int blocksize_id)
+{
+    const size_t blockSize = lz4f_block_bytes[blocksize_id];
+    const size_t bufferedSize = blockSize - 1; /* autoFlush == 0: assume a full tmp buffer */
+    const size_t maxSrcSize = srcSize + bufferedSize;
+    const unsigned nbFullBlocks = (unsigned)(maxSrcSize / blockSize);
+    const size_t partialBlockSize = maxSrcSize & (blockSize - 1);
+    const int flush = (srcSize == 0); /* autoFlush | (srcSize == 0) */
+    const size_t lastBlockSize = flush ? partialBlockSize : 0;
+    const unsigned nbBlocks = nbFullBlocks + (lastBlockSize > 0);
+    const size_t blockCRCSize = 0, frameEnd = 4; /* no block / content checksum */
+    return (4 + blockCRCSize) * nbBlocks + (blockSize * nbFullBlocks) + lastBlockSize + frameEnd;
+}
+
+size_t sqo_lz4_max_encoded_size(size_t n, size_t chunk, int blocksize_id, int nthreads)
+{
+    /* encoders/lz4.hpp:166-188 */
+    if (chunk >= n) return 19 + lz4f_compress_bound(chunk, blocksize_id);
+    const size_t nchunks = (n + chunk - 1) / chunk;
+    const size_t per_thread = (nchunks + (size_t)nthreads - 1) / (size_t)nthreads;
+    return per_thread * (lz4f_compress_bound(chunk, blocksize_id) + 19) * (size_t)nthreads;
+}
+
+static size_t lz4f_write_single_block_frame(const uint8_t* src, size_t n, uint8_t* dst, int blocksize_id)
+{
+    /* LZ4F_compressBegin: magic, FLG (version 01, block-linked => B.Indep = 0, no checksums, no
+     * content size, no dictID) = 0x40, BD = blocksize_id << 4, HC = (xxh32(FLG,BD) >> 8) & 0xff */
+    uint8_t* op = dst;
+    op[0] = 0x04; op[1] = 0x22; op[2] = 0x4D; op[3] = 0x18;
+    op[4] = 0x40;
+    op[5] = (uint8_t)(blocksize_id << 4);
+    op[6] = (uint8_t)((sqo_xxh32(op + 4, 2, 0) >> 8) & 0xff);
+    op += 7;
+    if (n > 0) {
+        /* LZ4F_makeBlock: compress with capacity n-1, store raw when that fails */
+        int c = sqo_lz4_block_compress(src, (int)n, op + 4, (int)n - 1);
+        uint32_t field;
+        if (c == 0) {
+            field = (uint32_t)n | 0x80000000u;
+            memcpy(op + 4, src, n);
+            c = (int)n;
+        } else {
+            field = (uint32_t)c;
+        }
+        op[0] = (uint8_t)field; op[1] = (uint8_t)(field >> 8); op[2] = (uint8_t)(field >> 16); op[3] = (uint8_t)(field >> 24);
+        op += 4 + (size_t)c;
+    }
+    op[0] = op[1] = op[2] = op[3] = 0; /* LZ4F_compressEnd: end mark, no content checksum */
+    op += 4;
+    return (size_t)(op - dst);
+}
+
+size_t sqo_lz4_encode_chunked(const uint8_t* src, size_t n, uint8_t* dst, size_t chunk, int blocksize_id)
+{
+    if (blocksize_id < 4 || blocksize_id > 7) return 0;
+    if (chunk == 0 || chunk > lz4f_block_bytes[blocksize_id]) return 0; /* linked multi-block frames not restated */
+    uint8_t* op = dst;
+    if (n == 0) return lz4f_write_single_block_frame(src, 0, dst, blocksize_id);
+    for (size_t off = 0; off < n; off += chunk) {
+        const size_t len = (n - off < chunk) ? (n - off) : chunk;
+        op += lz4f_write_single_block_frame(src + off, len, op, blocksize_id);
+    }
+    return (size_t)(op - dst);
+}
+
+size_t sqo_lz4_decode_frames(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
+{
+    const uint8_t* ip = src;
+    const uint8_t* const iend = src + n;
+    uint8_t* op = dst;
+    while (ip < iend) {
+        if (iend - ip < 7) return (size_t)-1;
+        if (!(ip[0] == 0x04 && ip[1] == 0x22 && ip[2] == 0x4D && ip[3] == 0x18)) return (size_t)-1;
+        const unsigned flg = ip[4];
+        if ((flg >> 6) != 1) return (size_t)-1;
+        if (flg & 0x0D) return (size_t)-1; /* content size / checksum / dictID variants not produced by sqeazy */
+        const int block_checksum = (flg >> 4) & 1;
+        ip += 7;
+        uint8_t* const frame_start = op;
+        for (;;) {
+            if (iend - ip < 4) return (size_t)-1;
+            const uint32_t field = rd32(ip);
+            ip += 4;
+            if (field == 0) break;
+            const uint32_t bsz = field & 0x7FFFFFFFu;
+            if ((size_t)(iend - ip) < bsz) return (size_t)-1;
+            if (field & 0x80000000u) {
+                if ((size_t)(dst + cap - op) < bsz) return (size_t)-1;
+                memcpy(op, ip, bsz);
+                op += bsz;
+            } else {
+                /* linked blocks: matches may reach back into earlier blocks of this frame */
+                const uint8_t* bp = ip;
+                const uint8_t* const bend = ip + bsz;
+                while (bp < bend) {
+                    const unsigned token = *bp++;
+                    size_t lit = token >> 4;
+                    if (lit == 15) { unsigned s; do { if (bp >= bend) return (size_t)-1; s = *bp++; lit += s; } while (s == 255); }
+                    if ((size_t)(bend - bp) < lit || (size_t)(dst + cap - op) < lit) return (size_t)-1;
+                    memcpy(op, bp, lit); op += lit; bp += lit;
+                    if (bp >= bend) break;
+                    if (bend - bp < 2) return (size_t)-1;
+                    const size_t offset = (size_t)bp[0] | ((size_t)bp[1] << 8);
+                    bp += 2;
+                    if (offset == 0 || offset > (size_t)(op - frame_start)) return (size_t)-1;
+                    size_t ml = token & 15u;
+                    if (ml == 15) { unsigned s; do { if (bp >= bend) return (size_t)-1; s = *bp++; ml += s; } while (s == 255); }
+                    ml += LZ4_MINMATCH;
+                    if ((size_t)(dst + cap - op) < ml) return (size_t)-1;
+                    const uint8_t* m = op - offset;
+                    for (size_t i = 0; i < ml; ++i) op[i] = m[i];
+                    op += ml;
+                }
+            }
+            ip += bsz;
+            if (block_checksum) ip += 4;
+        }
+    }
+    return (size_t)(op - dst);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* base64 -- base64.hpp:135-162 (standard alphabet, '=' padding)                               */
+/* ------------------------------------------------------------------------------------------ */
+size_t sqo_base64_encode(const uint8_t* src, size_t n, char* dst)
+{
+    static const char tbl[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    size_t o = 0, i = 0;
+    for (; i + 2 < n; i += 3) {
+        const unsigned v = ((unsigned)src[i] << 16) | ((unsigned)src[i + 1] << 8) | src[i + 2];
+        dst[o++] = tbl[(v >> 18) & 63]; dst[o++] = tbl[(v >> 12) & 63]; dst[o++] = tbl[(v >> 6) & 63]; dst[o++] = tbl[v & 63];
+    }
+    if (n - i == 1) {
+        const unsigned v = (unsigned)src[i] << 16;
+        dst[o++] = tbl[(v >> 18) & 63]; dst[o++] = tbl[(v >> 12) & 63]; dst[o++] = '='; dst[o++] = '=';
+    } else if (n - i == 2) {
+        const unsigned v = ((unsigned)src[i] << 16) | ((unsigned)src[i + 1] << 8);
+        dst[o++] = tbl[(v >> 18) & 63]; dst[o++] = tbl[(v >> 12) & 63]; dst[o++] = tbl[(v >> 6) & 63]; dst[o++] = '=';
+    }
+    return o;
+}

@@ -1,0 +1,81 @@
+/*
+ * sqy_oracle.h -- CPU restatement of the sqeazy hot path (TEST INFRASTRUCTURE ONLY).
+ *
+ * This is the parity oracle for sqeazy_amd.  It is NOT part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.  The product path
+ * (sqeazy_amd/csrc) never includes, links or calls anything in this directory.
+ *
+ * Every function cites the reference file:line it restates (paths relative to
+ * /root/reference/src/cpp/src unless stated).  LZ4 arithmetic is not in the reference tree:
+ * it is liblz4 (Frame API), pinned here to v1.9.3, restated from the published block format
+ * and checked byte-for-byte against liblz4.so.1.9.3 by oracle/gen_golden.py.
+ */
+#ifndef SQY_ORACLE_H_
+#define SQY_ORACLE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- bitswap1 : encoders/bitswap_scheme_impl.hpp:97-145, bitplane_reorder_scalar.hpp:27-74 ---- */
+void sqo_bitswap1_encode_u16(const uint16_t* in, uint16_t* out, size_t len);
+void sqo_bitswap1_encode_u8(const uint8_t* in, uint8_t* out, size_t len);
+/* SSE-shaped variant (16 passes, one per plane, movemask gather) used as the CPU baseline:
+ * encoders/sse_utils.hpp:1150-1217,1365-1433.  Same bytes as the scalar form. */
+void sqo_bitswap1_encode_u16_planes(const uint16_t* in, uint16_t* out, size_t len, int nthreads);
+/* inverse: bitplane_reorder_scalar.hpp:81-116 */
+void sqo_bitswap1_decode_u16(const uint16_t* in, uint16_t* out, size_t len);
+void sqo_bitswap1_decode_u8(const uint8_t* in, uint8_t* out, size_t len);
+
+/* ---- diff3x3x1 : encoders/diff_scheme_impl.hpp:78-139, diff_scheme_utils.hpp:70-99,
+ *                  neighborhood_utils.hpp:160-240.  shape = {z,y,x}.  returns 0 on success. ---- */
+int sqo_diff3x3x1_encode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3]);
+int sqo_diff3x3x1_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3]);
+int sqo_diff3x3x1_decode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3]);
+int sqo_diff3x3x1_decode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3]);
+/* number of row offsets the reference's halo::compute_offsets_in_x yields, and the i-th one */
+size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, size_t* halo_size_x);
+
+/* ---- LZ4 block, liblz4 1.9.3 LZ4_compress_fast_continue(fresh stream, .., cap, accel=1) ----
+ * returns compressed size, 0 when the result does not fit `cap`. */
+int sqo_lz4_block_compress(const uint8_t* src, int n, uint8_t* dst, int cap);
+/* plain LZ4 block decoder (format spec); returns decoded size or -1 */
+int sqo_lz4_block_decompress(const uint8_t* src, int n, uint8_t* dst, int cap);
+
+/* ---- LZ4 framing as sqeazy calls it ----
+ * chunked layout: encoders/lz4_utils.hpp:193-274 (encode_parallel): every `chunk` bytes of input
+ * becomes its own LZ4 frame; frames concatenated.  Only chunk <= block_bytes is restated
+ * (one block per frame).  blocksize_id is LZ4F's 4..7 (64K,256K,1M,4M).  returns bytes written. */
+size_t sqo_lz4_encode_chunked(const uint8_t* src, size_t n, uint8_t* dst, size_t chunk, int blocksize_id);
+/* upper bound of the above as the reference computes it: encoders/lz4.hpp:166-188 */
+size_t sqo_lz4_max_encoded_size(size_t n, size_t chunk, int blocksize_id, int nthreads);
+/* decoder for concatenated frames: encoders/lz4.hpp:257-339.  returns decoded bytes or (size_t)-1 */
+size_t sqo_lz4_decode_frames(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+
+/* ---- quantiser : encoders/quantiser_utils.hpp, quantiser_scheme_impl.hpp:176-226 ---- */
+void sqo_histogram_u16(const uint16_t* in, size_t len, uint32_t* histo /*65536*/);
+void sqo_histogram_u8(const uint8_t* in, size_t len, uint32_t* histo /*256*/);
+/* builds lut_encode[nbins] (bytes) and lut_decode[256] (as raw type, widened to u16) from a histogram,
+ * weighting_function=none.  nbins = 65536 (u16) or 256 (u8). */
+void sqo_quantiser_build_luts(const uint32_t* histo, size_t nbins, uint8_t* lut_encode, uint16_t* lut_decode);
+void sqo_quantiser_apply_u16(const uint16_t* in, size_t len, const uint8_t* lut_encode, uint8_t* out);
+void sqo_quantiser_apply_u8(const uint8_t* in, size_t len, const uint8_t* lut_encode, uint8_t* out);
+
+/* ---- frame_shuffle : encoders/frame_shuffle_utils.hpp:91-172 (frame_chunk_size=1) ----
+ * writes permuted volume and decode_map[z] (source frame of output slot z). */
+int sqo_frame_shuffle_encode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3], uint64_t* decode_map);
+int sqo_frame_shuffle_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3], uint64_t* decode_map);
+
+/* ---- base64 : base64.hpp:135-162 (RFC 4648, '=' padded) ---- */
+size_t sqo_base64_encode(const uint8_t* src, size_t n, char* dst);
+
+/* xxh32 of a short buffer (LZ4 frame header checksum byte) */
+uint32_t sqo_xxh32(const uint8_t* p, size_t len, uint32_t seed);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,611 @@
+"""CPU oracle for the sqeazy hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+module.  The product (``sqeazy_amd``) never imports it and fails loudly when its HIP library is missing.
+
+Byte/integer arithmetic lives in ``sqy_oracle.c`` / ``sqy_oracle_float.c`` (plain C, built by
+``oracle/Makefile``); this file composes the stages the way the reference's ``dynamic_pipeline`` does
+and renders the sqy header.  Reference citations are relative to /root/reference/src/cpp/src.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+SQY_VERSION = "0.5.2"      # build-time constant in the reference (sqeazy_header.hpp:172)
+SQY_HEADREF = "mi355x"     # ditto (git describe --always at build time)
+HEADER_END = b"|01307#!"   # sqeazy_header.hpp:586
+
+_u8p = ctypes.POINTER(ctypes.c_uint8)
+_u16p = ctypes.POINTER(ctypes.c_uint16)
+_u32p = ctypes.POINTER(ctypes.c_uint32)
+_u64p = ctypes.POINTER(ctypes.c_uint64)
+_szp = ctypes.POINTER(ctypes.c_size_t)
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "_build", "libsqy_oracle.so")
+        src_newer = (not os.path.exists(path)) or any(
+            os.path.getmtime(os.path.join(_HERE, f)) > os.path.getmtime(path)
+            for f in ("sqy_oracle.c", "sqy_oracle_float.c", "sqy_oracle.h"))
+        if src_newer:
+            build()
+        L = ctypes.CDLL(path)
+        L.sqo_lz4_block_compress.restype = ctypes.c_int
+        L.sqo_lz4_block_decompress.restype = ctypes.c_int
+        for f in ("sqo_lz4_encode_chunked", "sqo_lz4_max_encoded_size", "sqo_lz4_decode_frames",
+                  "sqo_base64_encode", "sqo_diff3x3x1_offsets"):
+            getattr(L, f).restype = ctypes.c_size_t
+        L.sqo_xxh32.restype = ctypes.c_uint32
+        _LIB = L
+    return _LIB
+
+
+def _ptr(a, t):
+    return a.ctypes.data_as(t)
+
+
+def _c(a, dtype):
+    a = np.ascontiguousarray(a, dtype=dtype)
+    return a
+
+
+# ------------------------------------------------------------------------------------------------
+# stage-level wrappers
+# ------------------------------------------------------------------------------------------------
+def bitswap1_encode(a):
+    a = np.ascontiguousarray(a)
+    flat = a.reshape(-1)
+    out = np.empty_like(flat)
+    if flat.dtype == np.uint16:
+        lib().sqo_bitswap1_encode_u16(_ptr(flat, _u16p), _ptr(out, _u16p), ctypes.c_size_t(flat.size))
+    elif flat.dtype in (np.uint8, np.int8):
+        lib().sqo_bitswap1_encode_u8(_ptr(flat, _u8p), _ptr(out, _u8p), ctypes.c_size_t(flat.size))
+    else:
+        raise TypeError(flat.dtype)
+    return out.reshape(a.shape)
+
+
+def bitswap1_encode_planes(a, nthreads=1):
+    flat = _c(a, np.uint16).reshape(-1)
+    out = np.empty_like(flat)
+    lib().sqo_bitswap1_encode_u16_planes(_ptr(flat, _u16p), _ptr(out, _u16p), ctypes.c_size_t(flat.size),
+                                         ctypes.c_int(nthreads))
+    return out
+
+
+def bitswap1_decode(a):
+    a = np.ascontiguousarray(a)
+    flat = a.reshape(-1)
+    out = np.empty_like(flat)
+    if flat.dtype == np.uint16:
+        lib().sqo_bitswap1_decode_u16(_ptr(flat, _u16p), _ptr(out, _u16p), ctypes.c_size_t(flat.size))
+    else:
+        lib().sqo_bitswap1_decode_u8(_ptr(flat, _u8p), _ptr(out, _u8p), ctypes.c_size_t(flat.size))
+    return out.reshape(a.shape)
+
+
+def _shape3(shape):
+    return (ctypes.c_size_t * 3)(*[int(s) for s in shape])
+
+
+def diff3x3x1_encode(a):
+    a = np.ascontiguousarray(a)
+    if a.ndim != 3:
+        raise ValueError("diff3x3x1 needs a 3D shape (diff_scheme_impl.hpp:84-87)")
+    out = np.empty_like(a)
+    if a.dtype == np.uint16:
+        rc = lib().sqo_diff3x3x1_encode_u16(_ptr(a, _u16p), _ptr(out, _u16p), _shape3(a.shape))
+    else:
+        rc = lib().sqo_diff3x3x1_encode_u8(_ptr(a, _u8p), _ptr(out, _u8p), _shape3(a.shape))
+    if rc:
+        raise ValueError("diff3x3x1: shape outside the reference's defined behaviour")
+    return out
+
+
+def diff3x3x1_decode(a):
+    a = np.ascontiguousarray(a)
+    out = np.empty_like(a)
+    if a.dtype == np.uint16:
+        rc = lib().sqo_diff3x3x1_decode_u16(_ptr(a, _u16p), _ptr(out, _u16p), _shape3(a.shape))
+    else:
+        rc = lib().sqo_diff3x3x1_decode_u8(_ptr(a, _u8p), _ptr(out, _u8p), _shape3(a.shape))
+    if rc:
+        raise ValueError("diff3x3x1: shape outside the reference's defined behaviour")
+    return out
+
+
+def diff3x3x1_offsets(shape):
+    hx = ctypes.c_size_t(0)
+    n = lib().sqo_diff3x3x1_offsets(_shape3(shape), None, ctypes.c_size_t(0), ctypes.byref(hx))
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    lib().sqo_diff3x3x1_offsets(_shape3(shape), _ptr(out, _szp), ctypes.c_size_t(n), ctypes.byref(hx))
+    return out[:n], hx.value
+
+
+def lz4_block_compress(data, cap=None):
+    src = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else _c(data, np.uint8)
+    n = src.size
+    if cap is None:
+        cap = n - 1
+    dst = np.zeros(max(cap, 1) + 16, dtype=np.uint8)
+    r = lib().sqo_lz4_block_compress(_ptr(src, _u8p), ctypes.c_int(n), _ptr(dst, _u8p), ctypes.c_int(cap))
+    return dst[:r].tobytes() if r > 0 else None
+
+
+def lz4_block_decompress(data, cap):
+    src = np.frombuffer(bytes(data), dtype=np.uint8)
+    dst = np.zeros(cap + 8, dtype=np.uint8)
+    r = lib().sqo_lz4_block_decompress(_ptr(src, _u8p), ctypes.c_int(src.size), _ptr(dst, _u8p), ctypes.c_int(cap))
+    if r < 0:
+        raise ValueError("corrupt lz4 block")
+    return dst[:r].tobytes()
+
+
+_BLOCK_ID = {64: 4, 256: 5, 1024: 6, 4096: 7}
+
+
+def closest_blocksize_kb(kb):
+    """encoders/lz4_utils.hpp:60-93 (closest_blocksize::of)"""
+    sizes = [64, 256, 1024, 4096]
+    import bisect
+    i = bisect.bisect_left(sizes, kb)
+    if i == len(sizes):
+        return sizes[-1]
+    if i == 0:
+        return sizes[0]
+    middle = sizes[i - 1] + (sizes[i] - sizes[i - 1]) // 2
+    return sizes[i] if kb >= middle else sizes[i - 1]
+
+
+class Lz4Config:
+    """encoders/lz4.hpp:58-114 parameter logic + :132-141 config string + :146-156 bytes_per_chunk."""
+
+    def __init__(self, cfg=""):
+        self.accel, self.blocksize_kb, self.framestep_kb, self.n_chunks = 1, 256, 256, 0
+        for k, v in parse_minors(cfg).items():
+            if k == "accel":
+                self.accel = int(float(v))
+            elif k == "blocksize_kb":
+                self.blocksize_kb = int(float(v))
+            elif k == "framestep_kb":
+                self.framestep_kb = int(float(v))
+            elif k == "n_chunks_of_input":
+                self.n_chunks = int(float(v))
+        if self.framestep_kb < self.blocksize_kb:
+            self.framestep_kb = self.blocksize_kb
+        else:
+            ratio = float(np.float32(self.framestep_kb) / np.float32(self.blocksize_kb))
+            self.framestep_kb = int(np.floor(ratio + 0.5)) * self.blocksize_kb   # std::round: half away from zero
+        if self.n_chunks != 0:
+            self.framestep_kb = 0
+        self.block_id = _BLOCK_ID[closest_blocksize_kb(self.blocksize_kb)]
+
+    def config(self):
+        return "accel=%d,blocksize_kb=%d,framestep_kb=%d,n_chunks_of_input=%d" % (
+            self.accel, self.blocksize_kb, self.framestep_kb, self.n_chunks)
+
+    def bytes_per_chunk(self, nbytes):
+        value = (self.framestep_kb << 10) if self.framestep_kb else nbytes // self.n_chunks
+        if value >= nbytes or self.n_chunks >= nbytes:
+            value = nbytes
+        return value
+
+    def max_encoded_size(self, nbytes, nthreads=1):
+        return lib().sqo_lz4_max_encoded_size(ctypes.c_size_t(nbytes), ctypes.c_size_t(self.bytes_per_chunk(nbytes)),
+                                              ctypes.c_int(self.block_id), ctypes.c_int(nthreads))
+
+
+def lz4_encode_chunked(data, cfg=None):
+    """nthreads >= 2 layout (encoders/lz4.hpp:227-239 -> lz4_utils.hpp:193-274)."""
+    cfg = cfg or Lz4Config()
+    src = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    src = np.ascontiguousarray(src).view(np.uint8).reshape(-1)
+    n = src.size
+    chunk = cfg.bytes_per_chunk(n) if n else 1
+    if cfg.accel >= 3:
+        raise NotImplementedError("accel >= 3 selects LZ4HC in liblz4 (not restated)")
+    nchunks = (n + chunk - 1) // chunk if n else 1
+    dst = np.zeros(nchunks * (chunk + 15 + 8) + 64, dtype=np.uint8)
+    r = lib().sqo_lz4_encode_chunked(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(chunk),
+                                     ctypes.c_int(cfg.block_id))
+    if r == 0:
+        raise NotImplementedError("chunk larger than one LZ4F block (linked multi-block frames not restated)")
+    return dst[:r]
+
+
+def lz4_decode_frames(data, cap):
+    src = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    src = np.ascontiguousarray(src).view(np.uint8).reshape(-1)
+    dst = np.zeros(cap + 8, dtype=np.uint8)
+    r = lib().sqo_lz4_decode_frames(_ptr(src, _u8p), ctypes.c_size_t(src.size), _ptr(dst, _u8p), ctypes.c_size_t(cap))
+    if r == ctypes.c_size_t(-1).value:
+        raise ValueError("corrupt lz4 frame stream")
+    return dst[:r]
+
+
+def histogram(a):
+    flat = np.ascontiguousarray(a).reshape(-1)
+    if flat.dtype == np.uint16:
+        h = np.zeros(65536, dtype=np.uint32)
+        lib().sqo_histogram_u16(_ptr(flat, _u16p), ctypes.c_size_t(flat.size), _ptr(h, _u32p))
+    else:
+        h = np.zeros(256, dtype=np.uint32)
+        lib().sqo_histogram_u8(_ptr(flat.view(np.uint8), _u8p), ctypes.c_size_t(flat.size), _ptr(h, _u32p))
+    return h
+
+
+def quantiser_build_luts(histo):
+    histo = _c(histo, np.uint32)
+    enc = np.zeros(histo.size, dtype=np.uint8)
+    dec = np.zeros(256, dtype=np.uint16)
+    lib().sqo_quantiser_build_luts(_ptr(histo, _u32p), ctypes.c_size_t(histo.size), _ptr(enc, _u8p), _ptr(dec, _u16p))
+    return enc, dec
+
+
+def quantiser_encode(a):
+    """quantiser_scheme<T,char>::encode (quantiser_scheme_impl.hpp:176-226), weighting none.
+    returns (bytes as uint8 array of a.shape, lut_decode as array of a.dtype[256])"""
+    a = np.ascontiguousarray(a)
+    enc, dec = quantiser_build_luts(histogram(a))
+    flat = a.reshape(-1)
+    out = np.empty(flat.size, dtype=np.uint8)
+    if a.dtype == np.uint16:
+        lib().sqo_quantiser_apply_u16(_ptr(flat, _u16p), ctypes.c_size_t(flat.size), _ptr(enc, _u8p), _ptr(out, _u8p))
+    else:
+        lib().sqo_quantiser_apply_u8(_ptr(flat, _u8p), ctypes.c_size_t(flat.size), _ptr(enc, _u8p), _ptr(out, _u8p))
+    return out.reshape(a.shape), dec.astype(a.dtype)
+
+
+def frame_shuffle_encode(a):
+    a = np.ascontiguousarray(a)
+    if a.ndim != 3:
+        raise ValueError("frame_shuffle needs a 3D shape")
+    out = np.empty_like(a)
+    dmap = np.zeros(a.shape[0], dtype=np.uint64)
+    if a.dtype == np.uint16:
+        rc = lib().sqo_frame_shuffle_encode_u16(_ptr(a, _u16p), _ptr(out, _u16p), _shape3(a.shape), _ptr(dmap, _u64p))
+    else:
+        rc = lib().sqo_frame_shuffle_encode_u8(_ptr(a.view(np.uint8), _u8p), _ptr(out.view(np.uint8), _u8p),
+                                               _shape3(a.shape), _ptr(dmap, _u64p))
+    if rc:
+        raise MemoryError
+    return out, dmap
+
+
+def base64_encode(raw):
+    src = np.frombuffer(bytes(raw), dtype=np.uint8)
+    dst = ctypes.create_string_buffer(4 * ((src.size + 2) // 3) + 4)
+    n = lib().sqo_base64_encode(_ptr(src, _u8p), ctypes.c_size_t(src.size), dst)
+    return dst.raw[:n].decode("ascii")
+
+
+def to_verbatim(arr):
+    """parsing::range_to_verbatim (string_parsers.hpp:507-534)"""
+    raw = np.ascontiguousarray(arr).tobytes()
+    if not raw:
+        return ""
+    return "<verbatim>" + base64_encode(raw) + "</verbatim>"
+
+
+# ------------------------------------------------------------------------------------------------
+# pipeline grammar (string_parsers.hpp:285-471) -- separators '->' ',' '=' with <verbatim> protection
+# ------------------------------------------------------------------------------------------------
+def _split_outside_verbatim(s, sep):
+    out, cur, i = [], "", 0
+    while i < len(s):
+        if s.startswith("<verbatim>", i):
+            j = s.find("</verbatim>", i)
+            if j < 0:
+                return []
+            cur += s[i:j + len("</verbatim>")]
+            i = j + len("</verbatim>")
+            continue
+        if s.startswith(sep, i):
+            out.append(cur)
+            cur = ""
+            i += len(sep)
+            continue
+        cur += s[i]
+        i += 1
+    out.append(cur)
+    return out
+
+
+def parse_pairs(pipeline):
+    """pipeline_parser::to_pairs (string_parsers.hpp:354-395)"""
+    if not pipeline:
+        return []
+    pairs = []
+    for major in _split_outside_verbatim(pipeline, "->"):
+        d = major.find("(")
+        if d < 0:
+            pairs.append((major, ""))
+        else:
+            pairs.append((major[:d], major[d + 1:-1]))
+    return pairs
+
+
+def parse_minors(cfg):
+    """pipeline_parser::minors (string_parsers.hpp:433-467)"""
+    out = {}
+    if not cfg:
+        return out
+    for item in _split_outside_verbatim(cfg, ","):
+        d = item.find("=")
+        if d < 0:
+            out[item] = item
+        else:
+            out[item[:d]] = item[d + 1:] if d + 1 < len(item) else item
+    return out
+
+
+HEAD_FILTERS = ("diff3x3x1", "bitswap1", "remove_background", "rmbkrd_neighbor5x5x5", "rmestbkrd", "raster_reorder",
+                "tile_shuffle", "frame_shuffle", "zcurve_reorder")
+SINKS = ("pass_through", "quantiser", "lz4")
+TAIL_FILTERS = ("diff3x3x1", "bitswap1", "lz4", "raster_reorder", "tile_shuffle", "frame_shuffle", "zcurve_reorder")
+
+
+def can_be_built_from(pipeline):
+    """dynamic_pipeline::can_be_built_from (dynamic_pipeline.hpp:177-226) against the reference's full
+    stage lists (sqeazy_pipelines.hpp:31-77)."""
+    pairs = parse_pairs(pipeline)
+    majors = _split_outside_verbatim(pipeline, "->") if pipeline else []
+    if len(majors) != len(pairs):
+        return False
+    found, sink_matched = 0, False
+    for name, _ in pairs:
+        if not sink_matched and name in HEAD_FILTERS:
+            found += 1
+            continue
+        if name in SINKS:
+            found += 1
+            sink_matched = True
+            continue
+        if name in TAIL_FILTERS:
+            found += 1
+    if found != len(pairs) or not pairs:
+        return False
+    rebuilt = 2 * (len(pairs) - 1)
+    for name, cfg in pairs:
+        rebuilt += len(name) + ((2 + len(cfg)) if cfg else 0)
+    return rebuilt == len(pipeline)
+
+
+# ------------------------------------------------------------------------------------------------
+# header (sqeazy_header.hpp:146-193): Boost.PropertyTree write_json pretty output + delimiter,
+# left-padded with spaces to a multiple of sizeof(T)
+# ------------------------------------------------------------------------------------------------
+_TYPE_NAME = {np.dtype(np.uint8): "uint8", np.dtype(np.uint16): "uint16", np.dtype(np.int8): "int8"}
+
+
+def _json_escape(s):
+    out = []
+    for ch in s:
+        c = ord(ch)
+        if ch == '"':
+            out.append('\\"')
+        elif ch == "\\":
+            out.append("\\\\")
+        elif ch == "/":
+            out.append("\\/")
+        elif ch == "\b":
+            out.append("\\b")
+        elif ch == "\f":
+            out.append("\\f")
+        elif ch == "\n":
+            out.append("\\n")
+        elif ch == "\r":
+            out.append("\\r")
+        elif ch == "\t":
+            out.append("\\t")
+        elif c < 0x20:
+            out.append("\\u%04X" % c)
+        else:
+            out.append(ch)
+    return "".join(out)
+
+
+def header_pack(dtype, shape, pipename, payload_bytes, version=SQY_VERSION, headref=SQY_HEADREF):
+    dtype = np.dtype(dtype)
+    q = lambda s: '"' + _json_escape(str(s)) + '"'
+    lines = ["{",
+             '    "pipename": %s,' % q(pipename),
+             '    "raw": {',
+             '        "type": %s,' % q(_TYPE_NAME[dtype]),
+             '        "rank": %s,' % q(len(shape)),
+             '        "shape": {']
+    dims = ['            "dim": %s' % q(int(d)) for d in shape]
+    lines.append(",\n".join(dims))
+    lines += ["        }",
+              "    },",
+              '    "encoded": {',
+              '        "bytes": %s' % q(int(payload_bytes)),
+              "    },",
+              '    "sqy": {',
+              '        "version": %s,' % q(version),
+              '        "headref": %s' % q(headref),
+              "    }",
+              "}"]
+    text = ("\n".join(lines) + "\n").encode("ascii") + HEADER_END
+    if len(text) % dtype.itemsize:
+        text = b" " * (dtype.itemsize - len(text) % dtype.itemsize) + text
+    return text
+
+
+def header_unpack(blob):
+    """returns dict(pipename, type, shape, bytes, size) -- sqeazy_header.hpp:294-344"""
+    import json
+    blob = bytes(blob)
+    pos = blob.find(HEADER_END)
+    if pos < 0:
+        raise ValueError("no sqy header")
+    text = blob[:pos].decode("ascii")
+
+    dims = []
+
+    def hook(pairs):
+        d = {}
+        for k, v in pairs:
+            if k == "dim":
+                dims.append(int(v))
+            d[k] = v
+        return d
+    tree = json.loads(text, object_pairs_hook=hook)
+    return dict(pipename=tree["pipename"], type=tree["raw"]["type"], shape=tuple(dims),
+                bytes=int(tree["encoded"]["bytes"]), size=pos + len(HEADER_END),
+                version=tree["sqy"]["version"], headref=tree["sqy"]["headref"])
+
+
+# ------------------------------------------------------------------------------------------------
+# pipeline level (dynamic_pipeline.hpp:560-690)
+# ------------------------------------------------------------------------------------------------
+class _Stage:
+    def __init__(self, name, cfg):
+        self.name, self.cfg_in = name, cfg
+        self.extra = None
+        if name == "lz4":
+            self.lz4 = Lz4Config(cfg)
+        if name == "quantiser":
+            self.cmap = parse_minors(cfg)
+        if name == "frame_shuffle":
+            m = parse_minors(cfg)
+            self.chunk = int(m.get("frame_chunk_size", "1"))
+            self.map = m.get("reorder_map", "") if "reorder_map" in m else ""
+
+    def config(self):
+        if self.name == "bitswap1":
+            return "num_bits_per_plane=1"
+        if self.name == "diff3x3x1":
+            return ""
+        if self.name == "lz4":
+            return self.lz4.config()
+        if self.name == "quantiser":
+            return ",".join("%s=%s" % kv for kv in sorted(self.cmap.items()))
+        if self.name == "frame_shuffle":
+            return "frame_chunk_size=%d,reorder_map=%s" % (self.chunk, self.map)
+        raise NotImplementedError(self.name)
+
+    def full_name(self):
+        c = self.config()
+        return self.name + ("(" + c + ")" if c else "")
+
+
+def pipeline_name(stages):
+    return "->".join(s.full_name() for s in stages)
+
+
+def build_stages(pipeline):
+    return [_Stage(n, c) for n, c in parse_pairs(pipeline)]
+
+
+def pipeline_max_encoded_size(pipeline, nbytes, dtype, nthreads=1):
+    """dynamic_pipeline::max_encoded_size (dynamic_pipeline.hpp:866-890)"""
+    dtype = np.dtype(dtype)
+    stages = build_stages(pipeline)
+    hdr = header_pack(dtype, (nbytes,), pipeline_name(stages), nbytes * dtype.itemsize)
+    sizes = []
+    for s in stages:
+        if s.name == "lz4":
+            sizes.append(s.lz4.max_encoded_size(nbytes, nthreads))
+        elif s.name == "quantiser":
+            sizes.append(nbytes * dtype.itemsize + 256 * dtype.itemsize)
+        else:
+            sizes.append(nbytes)
+    # head chain / sink / tail chain each contribute the max over their members; a max over all is equal
+    return 2 * len(hdr) + (max(sizes) if sizes else 0)
+
+
+def pipeline_encode(pipeline, vol, nthreads=2):
+    """Whole-blob oracle for the supported stage set, chunked (nthreads >= 2) LZ4 layout.
+    `vol` is a uint8/uint16 ndarray in {z,y,x} order.  Returns bytes."""
+    if nthreads < 2:
+        raise NotImplementedError("serial single-frame LZ4 layout is not restated (block-linked frame)")
+    vol = np.ascontiguousarray(vol)
+    if not can_be_built_from(pipeline):
+        raise ValueError("invalid pipeline")
+    stages = build_stages(pipeline)
+    dtype = vol.dtype
+    cur = vol
+    seen_sink = False
+    payload = None
+    for s in stages:
+        is_sink = (not seen_sink) and s.name in SINKS
+        if s.name == "bitswap1":
+            cur = bitswap1_encode(cur)
+        elif s.name == "diff3x3x1":
+            if cur.dtype == np.int8 or (seen_sink and cur.dtype == np.uint8):
+                raise NotImplementedError("diff3x3x1 on char is not restated")
+            cur = diff3x3x1_encode(cur)
+        elif s.name == "frame_shuffle":
+            cur, dmap = frame_shuffle_encode(cur)
+            s.map = to_verbatim(dmap)
+        elif s.name == "quantiser":
+            cur, dec = quantiser_encode(cur)
+            s.cmap["decode_lut_string"] = to_verbatim(dec)
+        elif s.name == "lz4":
+            payload = lz4_encode_chunked(cur.reshape(-1).view(np.uint8), s.lz4)
+            cur = payload
+        else:
+            raise NotImplementedError(s.name)
+        if is_sink:
+            seen_sink = True
+    body = cur.reshape(-1).view(np.uint8)
+    hdr = header_pack(dtype, vol.shape, pipeline_name(stages), body.size)
+    return hdr + body.tobytes()
+
+
+def pipeline_decode(blob):
+    """inverse for round-trip checks (dynamic_pipeline.hpp:740-846); lossy for quantiser."""
+    h = header_unpack(blob)
+    dtype = np.dtype(h["type"])
+    stages = build_stages(h["pipename"])
+    body = np.frombuffer(bytes(blob), dtype=np.uint8)[h["size"]:h["size"] + h["bytes"]]
+    n = int(np.prod(h["shape"]))
+    sink_idx = next((i for i, s in enumerate(stages) if s.name in SINKS), None)
+    cur = body
+    # tail filters^-1 then sink^-1 then head filters^-1
+    order = list(range(len(stages)))[::-1]
+    cur_dtype = np.uint8
+    for i in order:
+        s = stages[i]
+        after_sink = sink_idx is not None and i > sink_idx
+        work_dtype = np.uint8 if (after_sink or (sink_idx is not None and stages[sink_idx].name == "quantiser"
+                                                 and i > sink_idx)) else dtype
+        if s.name == "lz4":
+            elem = 1 if (i != sink_idx or True) else dtype.itemsize
+            quant = sink_idx is not None and stages[sink_idx].name == "quantiser"
+            nbytes = n if quant else n * dtype.itemsize
+            cur = lz4_decode_frames(cur, nbytes)
+        elif s.name == "bitswap1":
+            t = np.uint8 if after_sink else dtype
+            cur = bitswap1_decode(np.ascontiguousarray(cur).view(t))
+        elif s.name == "diff3x3x1":
+            cur = diff3x3x1_decode(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]))
+        elif s.name == "quantiser":
+            import base64
+            lut = s.cmap["decode_lut_string"]
+            lut = lut[len("<verbatim>"):-len("</verbatim>")]
+            dec = np.frombuffer(base64.b64decode(lut), dtype=dtype)
+            cur = dec[np.ascontiguousarray(cur).view(np.uint8)]
+        elif s.name == "frame_shuffle":
+            import base64
+            m = s.map[len("<verbatim>"):-len("</verbatim>")]
+            dmap = np.frombuffer(base64.b64decode(m), dtype=np.uint64)
+            v = np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
+            out = np.empty_like(v)
+            out[dmap.astype(np.int64)] = v
+            cur = out
+        else:
+            raise NotImplementedError(s.name)
+    return np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
