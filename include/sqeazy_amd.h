@@ -1,0 +1,117 @@
+/*
+ * sqeazy_amd.h -- C-ABI of libsqeazy_amd.so, the MI355X-native drop-in for sqeazy's pipeline
+ * encode path (filter stages + LZ4 block compression).
+ *
+ * Section A re-declares, with identical names, argument order and meaning, the entry points of the
+ * reference's libsqeazy that belong to this path.  Each declaration cites the reference interface
+ * it replaces (paths relative to /root/reference/src/cpp): `inc/sqeazy.h` for the declaration and
+ * `src/sqeazy.cpp` for the behaviour.  A maintainer binds them exactly as they bind libsqeazy
+ * today.  All pointers are HOST pointers; the library stages data through
+ * HBM itself.  Return convention: 0 success, 1 failure ("[sqeazy]\t..." on stderr), never throws.
+ *
+ * Section B adds entry points for callers whose volumes already live in MI355X HBM.
+ *
+ * No HDF5 entry points (SQY_h5_*): out of scope of the hot path.
+ */
+#ifndef SQEAZY_AMD_H_
+#define SQEAZY_AMD_H_
+
+#ifdef __cplusplus
+#define SQY_FUNCTION_PREFIX extern "C" __attribute__((visibility("default")))
+#else
+#include <stdbool.h>
+#define SQY_FUNCTION_PREFIX __attribute__((visibility("default")))
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Section A -- sqeazy's own C-ABI for the pipeline path
+ * ---------------------------------------------------------------------------------------------- */
+
+/* inc/sqeazy.h:26, src/sqeazy.cpp:16-22.  *length in: bytes available at src; out: header bytes
+ * (JSON + "|01307#!" delimiter, including leading pad). */
+SQY_FUNCTION_PREFIX int SQY_Header_Size(const char* src, long* length);
+
+/* inc/sqeazy.h:40, src/sqeazy.cpp:24-34.  *num in: bytes at src; out: rank of the stored volume. */
+SQY_FUNCTION_PREFIX int SQY_Decompressed_NDims(const char* src, long* num);
+
+/* inc/sqeazy.h:55, src/sqeazy.cpp:36-47.  shape[0] in: bytes at src; out: shape[0..rank) = {z,y,x}. */
+SQY_FUNCTION_PREFIX int SQY_Decompressed_Shape(const char* src, long* shape);
+
+/* inc/sqeazy.h:69, src/sqeazy.cpp:49-59.  *Sizeof in: bytes at src; out: bytes per voxel. */
+SQY_FUNCTION_PREFIX int SQY_Decompressed_Sizeof(const char* src, long* Sizeof);
+
+/* inc/sqeazy.h:81, src/sqeazy.cpp:62-69.  version[0..3) = major, minor, patch. */
+SQY_FUNCTION_PREFIX int SQY_Version_Triple(int* version);
+
+/* inc/sqeazy.h:109-115, src/sqeazy.cpp:72-106.  Encode a uint8 volume.
+ *   pipeline    e.g. "frame_shuffle->lz4"; must satisfy SQY_Pipeline_Possible_UI8
+ *   src         contiguous voxels, row-major {z,y,x}, x fastest
+ *   shape       long[shape_size], voxels per dimension
+ *   dst         at least SQY_Pipeline_Max_Compressed_Length_* bytes
+ *   dstlength   out only: bytes written (header + payload)
+ *   nthreads    <=0 or > hardware threads: all hardware threads.  The value selects the LZ4 LAYOUT
+ *               exactly as in the reference (encoders/lz4.hpp:227-239): effective 1 -> one
+ *               block-linked frame (NOT available on MI355X, returns 1 unless the stream fits one
+ *               chunk); >=2 -> one independent frame per 256 KiB chunk (byte-identical for every
+ *               count >= 2), which is what the GPU produces. */
+SQY_FUNCTION_PREFIX int SQY_PipelineEncode_UI8(const char* pipeline, const char* src, long* shape, unsigned shape_size,
+                                               char* dst, long* dstlength, int nthreads);
+
+/* inc/sqeazy.h:140-146, src/sqeazy.cpp:108-142.  Same for uint16 voxels (little endian). */
+SQY_FUNCTION_PREFIX int SQY_PipelineEncode_UI16(const char* pipeline, const char* src, long* shape, unsigned shape_size,
+                                                char* dst, long* dstlength, int nthreads);
+
+/* inc/sqeazy.h:159-161 / :190, src/sqeazy.cpp:144-183.  *length in: raw bytes; out: upper bound of
+ * the encoded blob = 2*header + max over stages (dynamic_pipeline.hpp:866-890). */
+SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_UI8(const char* pipeline, long pipeline_length, long* length);
+SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_UI16(const char* pipeline, long pipeline_length, long* length);
+
+/* inc/sqeazy.h:175-178 / :204-207, src/sqeazy.cpp:185-231.  *length in: strlen(pipeline) (sic); out: bound. */
+SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI8(const char* pipeline, long* shape, unsigned shape_size, long* length);
+SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI16(const char* pipeline, long* shape, unsigned shape_size, long* length);
+
+/* inc/sqeazy.h:219-243, src/sqeazy.cpp:233-268.  true iff the string parses as head filters -> sink ->
+ * tail filters AND every stage is implemented here: diff3x3x1, bitswap1, frame_shuffle, quantiser, lz4.
+ * (The reference additionally accepts its background-removal / reorder filters and pass_through.) */
+SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI16(const char* pipeline_string);
+SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI8(const char* pipeline_string);
+SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible(const char* pipeline_string, int sizeofpixel);
+
+/* inc/sqeazy.h:255, src/sqeazy.cpp:270-279.  *length in: bytes at data; out: decoded bytes. */
+SQY_FUNCTION_PREFIX int SQY_Decompressed_Length(const char* data, long* length);
+
+/* inc/sqeazy.h:274-299, src/sqeazy.cpp:281-335.  Decode a blob produced by SQY_PipelineEncode_* (either
+ * LZ4 layout).  dst must hold SQY_Decompressed_Length bytes. */
+SQY_FUNCTION_PREFIX int SQY_Decode_UI16(const char* src, long srclength, char* dst, int nthreads);
+SQY_FUNCTION_PREFIX int SQY_Decode_UI8(const char* src, long srclength, char* dst, int nthreads);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section B -- HBM-resident variants (no reference counterpart; same semantics as above)
+ * ---------------------------------------------------------------------------------------------- */
+
+/* d_src / d_dst are device pointers on the current HIP device; dst_capacity is checked (1 when the
+ * blob does not fit).  hip_stream is a hipStream_t (NULL = default stream).  The call returns after the
+ * blob is complete in d_dst. */
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, const void* d_src, const long* shape,
+                                                          unsigned shape_size, void* d_dst, long dst_capacity,
+                                                          long* dstlength, int nthreads, void* hip_stream);
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, const long* shape,
+                                                         unsigned shape_size, void* d_dst, long dst_capacity,
+                                                         long* dstlength, int nthreads, void* hip_stream);
+SQY_FUNCTION_PREFIX int SQYAMD_Decode_UI16_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream);
+SQY_FUNCTION_PREFIX int SQYAMD_Decode_UI8_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream);
+
+/* per-kernel device timing (hipEvents on the call's stream), for bench.py's roofline line.
+ *   enable != 0 starts collecting, Reset clears.  Get: i-th kernel name seen since the last reset
+ *   (NULL when i is past the end), total milliseconds and number of launches. */
+SQY_FUNCTION_PREFIX void SQYAMD_Profile_Enable(int enable);
+SQY_FUNCTION_PREFIX void SQYAMD_Profile_Reset(void);
+SQY_FUNCTION_PREFIX const char* SQYAMD_Profile_Get(int i, double* total_ms, long* launches);
+
+/* release the cached HBM workspace of the current device */
+SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
+
+/* "sqeazy_amd <version> (gfx950)" */
+SQY_FUNCTION_PREFIX const char* SQYAMD_Version(void);
+
+#endif /* SQEAZY_AMD_H_ */

@@ -142,10 +142,10 @@ size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, siz
     if (((int)X - 1) != (int)X) num *= (long)((int)X - 1);          /* i = 2 */
     if (((int)Y - 2) != (int)Y) num *= (long)((int)Y - 2);          /* i = 1 */
     if (halo_size_x) *halo_size_x = 0;
-    if (num <= 1 || Z < 2) {
+    if (num <= 1) {
         /* the reference takes its single-offset branch (offset 1, halo_size_x = length-1) and
-         * reads in front of the buffer: undefined there, refused here (0 offsets). */
-        return 0;
+         * reads in front of the buffer: undefined there, refused here. */
+        return (size_t)-1;
     }
     size_t n = 0, first = 0;
     for (size_t z = 1; z < X; ++z) {
@@ -158,7 +158,8 @@ size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, siz
             }
         }
     }
-    if (halo_size_x) *halo_size_x = (n == 1) ? (length - first) : (Z - 2); /* diff_scheme_impl.hpp:97-101 */
+    /* diff_scheme_impl.hpp:97-101; with Z == 1 there are no offsets and the value is unused */
+    if (halo_size_x) *halo_size_x = (n == 1) ? (length - first) : (Z >= 2 ? Z - 2 : 0);
     return n;
 }
 
@@ -172,7 +173,8 @@ size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, siz
     memcpy(out, in, length * sizeof(T));                                                                 \
     size_t hx = 0;                                                                                       \
     size_t noff = sqo_diff3x3x1_offsets(shape, NULL, 0, &hx);                                            \
-    if (noff == 0) return 1;                                                                             \
+    if (noff == (size_t)-1) return 1;                                                                    \
+    if (noff == 0) return 0;                                                                             \
     size_t* offs = (size_t*)malloc((noff ? noff : 1) * sizeof(size_t));                                  \
     if (!offs) return 1;                                                                                 \
     sqo_diff3x3x1_offsets(shape, offs, noff, &hx);                                                       \

@@ -128,6 +128,8 @@ def diff3x3x1_decode(a):
 def diff3x3x1_offsets(shape):
     hx = ctypes.c_size_t(0)
     n = lib().sqo_diff3x3x1_offsets(_shape3(shape), None, ctypes.c_size_t(0), ctypes.byref(hx))
+    if n == ctypes.c_size_t(-1).value:
+        raise ValueError("diff3x3x1: shape outside the reference's defined behaviour")
     out = np.zeros(max(n, 1), dtype=np.uint64)
     lib().sqo_diff3x3x1_offsets(_shape3(shape), _ptr(out, _szp), ctypes.c_size_t(n), ctypes.byref(hx))
     return out[:n], hx.value

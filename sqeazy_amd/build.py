@@ -1,0 +1,58 @@
+"""Builds sqeazy_amd/lib/libsqeazy_amd.so (HIP kernels + C-ABI) for gfx950 with hipcc.
+
+In-tree on purpose: the built .so travels to the GPU box with the snapshot.  hipcc cross-compiles
+without a GPU.  `python -m sqeazy_amd.build` or `sqeazy_amd.build.build()`.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+LIB = os.path.join(LIBDIR, "libsqeazy_amd.so")
+SOURCES = ["sqy_kernels.hip", "sqy_pipeline.cpp", "sqy_capi.cpp"]
+HEADERS = ["sqy_kernels.h", "sqy_pipeline.hpp", os.path.join("..", "..", "include", "sqeazy_amd.h")]
+ARCH = "gfx950"
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    os.makedirs(LIBDIR, exist_ok=True)
+    objs = []
+    common = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+    for src in SOURCES:
+        obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
+        cmd = [_hipcc(), "--offload-arch=" + ARCH] + common + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src.endswith(".cpp"):
+            cmd.insert(1, "-x")
+            cmd.insert(2, "hip")
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        objs.append(obj)
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

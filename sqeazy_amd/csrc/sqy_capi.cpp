@@ -1,0 +1,548 @@
+// sqy_capi.cpp -- the C-ABI of libsqeazy_amd.so (include/sqeazy_amd.h) and the stage sequencing on the GPU.
+//
+// Mirrors src/cpp/src/sqeazy.cpp:16-335 (entry points) and dynamic_pipeline.hpp:560-690 (encode:
+// header, head filters, sink, tail filters, header rewrite), with every stage a HIP kernel launch on
+// device-resident ping-pong buffers instead of an OpenMP loop over host memory.
+#include "../../include/sqeazy_amd.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "sqy_kernels.h"
+#include "sqy_pipeline.hpp"
+
+namespace {
+
+using sqy::Pipeline;
+using sqy::Stage;
+using sqy::StageKind;
+
+#define SQY_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess) {                                                                         \
+            std::fprintf(stderr, "[sqeazy]\t HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); \
+            return 1;                                                                                   \
+        }                                                                                               \
+    } while (0)
+
+// ---- per-kernel timing -------------------------------------------------------------------------
+struct ProfEntry { std::string name; double ms = 0; long launches = 0; };
+struct PendingEvent { int entry; hipEvent_t a, b; };
+bool g_prof_on = false;
+std::vector<ProfEntry> g_prof;
+std::vector<PendingEvent> g_pending;
+
+int prof_index(const char* name)
+{
+    for (size_t i = 0; i < g_prof.size(); ++i) if (g_prof[i].name == name) return (int)i;
+    g_prof.push_back(ProfEntry{name, 0, 0});
+    return (int)g_prof.size() - 1;
+}
+
+struct ProfScope {
+    hipStream_t s;
+    PendingEvent ev{};
+    bool on;
+    ProfScope(const char* name, hipStream_t stream) : s(stream), on(g_prof_on)
+    {
+        if (!on) return;
+        ev.entry = prof_index(name);
+        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+        hipEventRecord(ev.a, s);
+    }
+    ~ProfScope()
+    {
+        if (!on) return;
+        hipEventRecord(ev.b, s);
+        g_pending.push_back(ev);
+    }
+};
+
+void prof_collect()
+{
+    for (PendingEvent& p : g_pending) {
+        float ms = 0;
+        if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+            g_prof[p.entry].ms += ms;
+            g_prof[p.entry].launches += 1;
+        }
+        hipEventDestroy(p.a);
+        hipEventDestroy(p.b);
+    }
+    g_pending.clear();
+}
+
+// ---- HBM workspace (grow-only, one per device, guarded by g_mu) ----------------------------------
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        if (p) { hipFree(p); p = nullptr; cap = 0; }
+        const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        if (hipMalloc(&p, want) != hipSuccess) {
+            std::fprintf(stderr, "[sqeazy]\t unable to allocate %zu bytes of HBM workspace\n", want);
+            p = nullptr;
+            return 1;
+        }
+        cap = want;
+        return 0;
+    }
+    void release() { if (p) hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct Workspace {
+    DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small;
+    void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
+    void release()
+    {
+        ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
+        io_src.release(); io_dst.release(); small.release();
+        if (pinned) { hipHostFree(pinned); pinned = nullptr; }
+    }
+};
+
+constexpr int kMaxDev = 16;
+std::mutex g_mu;
+Workspace g_ws[kMaxDev];
+
+Workspace* workspace()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    Workspace* w = &g_ws[dev];
+    if (!w->pinned && hipHostMalloc(&w->pinned, 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return w;
+}
+
+bool device_present()
+{
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess && n > 0;
+}
+
+// ---- encode --------------------------------------------------------------------------------------
+// The body of dynamic_pipeline::encode (dynamic_pipeline.hpp:560-616) on device buffers.
+int encode_on_device(const char* pipeline_c, const void* d_src, const long* shape, unsigned rank, int elem_size,
+                     void* d_dst, uint64_t dst_capacity, long* dstlength, int nthreads, hipStream_t stream)
+{
+    if (!pipeline_c || !d_src || !shape || !d_dst || !dstlength) return 1;
+    const std::string pipeline(pipeline_c);
+    std::string why;
+    if (!Pipeline::supported(pipeline, elem_size, &why)) {
+        if (Pipeline::reference_accepts(pipeline))
+            std::fprintf(stderr, "[sqeazy]\t pipeline %s: %s\n", pipeline.c_str(), why.c_str());
+        return 1;
+    }
+    Pipeline pipe = Pipeline::from_string(pipeline);
+    if (pipe.stages.empty()) {
+        std::fprintf(stderr, "[sqeazy]\t received %spipeline of size 0, cannot encode buffer\n", pipe.name().c_str());
+        return 1;
+    }
+    pipe.set_n_threads(nthreads);
+
+    std::vector<uint64_t> dims(shape, shape + rank);
+    uint64_t len = 1;
+    for (uint64_t d : dims) {
+        if ((long)d <= 0) { std::fprintf(stderr, "[sqeazy]\t non-positive extent in shape\n"); return 1; }
+        len *= d;
+        if (len >= ((uint64_t)1 << 31)) {
+            // the reference multiplies the extents into an `int` (dynamic_pipeline.hpp:565): one call is < 2^31 voxels
+            std::fprintf(stderr, "[sqeazy]\t %llu+ voxels in one call overflow the reference's int voxel count; encode z-slabs\n",
+                         (unsigned long long)len);
+            return 1;
+        }
+    }
+    const uint64_t raw_bytes = len * (uint64_t)elem_size;
+
+    Workspace* ws = workspace();
+    if (!ws) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+
+    // ---- walk the stages ----
+    const uint8_t* cur = static_cast<const uint8_t*>(d_src);
+    int cur_elem = elem_size;            // bytes per element of the stream between stages
+    uint64_t cur_len = len;              // elements
+    bool use_ping = true;
+    auto next_buf = [&](size_t bytes) -> uint8_t* {
+        DevBuf& b = use_ping ? ws->ping : ws->pong;
+        use_ping = !use_ping;
+        if (b.ensure(bytes)) return nullptr;
+        return static_cast<uint8_t*>(b.p);
+    };
+
+    uint64_t payload_bytes = 0;
+    bool payload_is_lz4 = false;
+    const sqy::Lz4Params* lz4p = nullptr;
+    uint64_t lz4_total = 0, lz4_nchunks = 0, lz4_chunk = 0, lz4_stride = 0;
+
+    for (size_t si = 0; si < pipe.stages.size(); ++si) {
+        Stage& st = pipe.stages[si];
+        switch (st.kind) {
+            case StageKind::bitswap1: {
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream);
+                if (cur_elem == 2)
+                    SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream));
+                else
+                    SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
+                cur = out;
+                break;
+            }
+            case StageKind::diff3x3x1: {
+                if (dims.size() != 3) {
+                    // diff_scheme_impl.hpp:84-87 returns the output pointer unmoved -> the chain throws
+                    // (dynamic_stage_chain.hpp:313-317); no exception may cross this ABI
+                    std::fprintf(stderr, "[diff_scheme] unable to process input data that is not 3D\n");
+                    return 1;
+                }
+                const uint64_t Z = dims[0], Y = dims[1], X = dims[2];
+                if ((int64_t)(X - 1) * (int64_t)(Y - 2) <= 1 || Y < 3 || X < 2) {
+                    std::fprintf(stderr, "[sqeazy]\t diff3x3x1: shape %llux%llux%llu reads out of bounds in the reference; refused\n",
+                                 (unsigned long long)Z, (unsigned long long)Y, (unsigned long long)X);
+                    return 1;
+                }
+                if (cur_elem == 1 && (Z > 127 || Y > 127 || X > 127)) {
+                    std::fprintf(stderr, "[sqeazy]\t diff3x3x1 on 8-bit voxels: extents > 127 overflow the reference's char coordinates; refused\n");
+                    return 1;
+                }
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                ProfScope ps("diff3x3x1", stream);
+                SQY_HIP(sqy::launch_diff3x3x1(cur, out, Z, Y, X, cur_elem, stream));
+                cur = out;
+                break;
+            }
+            case StageKind::lz4: {
+                lz4p = &st.lz4;
+                lz4_total = cur_len * (uint64_t)cur_elem;
+                lz4_chunk = lz4_total ? st.lz4.bytes_per_chunk(lz4_total) : 1;
+                lz4_nchunks = lz4_total ? (lz4_total + lz4_chunk - 1) / lz4_chunk : 0;
+                if (lz4_chunk > st.lz4.block_bytes()) {
+                    std::fprintf(stderr, "[sqeazy]\t lz4: %llu-byte chunks span several linked LZ4 blocks; not available on MI355X\n",
+                                 (unsigned long long)lz4_chunk);
+                    return 1;
+                }
+                if (pipe.nthreads == 1 && lz4_nchunks > 1) {
+                    std::fprintf(stderr, "[sqeazy]\t lz4: nthreads=1 asks for one block-linked frame over %llu chunks (inherently serial); "
+                                         "not available on MI355X, pass nthreads=0 or >=2\n", (unsigned long long)lz4_nchunks);
+                    return 1;
+                }
+                lz4_stride = (lz4_chunk + 15) & ~(uint64_t)15;
+                if (ws->lz4_scratch.ensure(std::max<uint64_t>(lz4_nchunks * lz4_stride, 16))) return 1;
+                if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
+                if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
+                {
+                    ProfScope ps("lz4_chunks", stream);
+                    SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
+                                                   static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream));
+                }
+                {
+                    ProfScope ps("lz4_frame_scan", stream);
+                    SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
+                                                       static_cast<uint64_t*>(ws->frame_off.p), stream));
+                }
+                payload_is_lz4 = true;
+                break;
+            }
+            default:
+                std::fprintf(stderr, "[sqeazy]\t stage %s is not implemented on MI355X\n", st.name.c_str());
+                return 1;
+        }
+    }
+
+    // ---- payload size ----
+    if (payload_is_lz4) {
+        if (lz4_nchunks == 0) {
+            payload_bytes = 7 + 4;                     // empty input: frame header + end mark
+        } else {
+            SQY_HIP(hipMemcpyAsync(ws->pinned, static_cast<uint64_t*>(ws->frame_off.p) + lz4_nchunks, sizeof(uint64_t),
+                                   hipMemcpyDeviceToHost, stream));
+            SQY_HIP(hipStreamSynchronize(stream));
+            payload_bytes = *static_cast<uint64_t*>(ws->pinned);
+        }
+        if (payload_bytes > (uint64_t)INT_MAX) {
+            // encode_parallel sums the chunk sizes into an `int` and rejects the result (lz4_utils.hpp:264-273)
+            std::fprintf(stderr, "[sqeazy]\t lz4: %llu payload bytes overflow the reference's int byte count\n",
+                         (unsigned long long)payload_bytes);
+            return 1;
+        }
+    } else {
+        payload_bytes = cur_len * (uint64_t)cur_elem;
+    }
+
+    // ---- header (written after encoding, as the reference rewrites it: dynamic_pipeline.hpp:599-612) ----
+    const std::string hdr = sqy::header_pack(elem_size, false, dims, pipe.name(), payload_bytes);
+    const uint64_t blob_bytes = hdr.size() + payload_bytes;
+    if (blob_bytes > dst_capacity) {
+        std::fprintf(stderr, "[sqeazy]\t destination buffer too small (%llu > %llu bytes)\n", (unsigned long long)blob_bytes,
+                     (unsigned long long)dst_capacity);
+        return 1;
+    }
+    uint8_t* out = static_cast<uint8_t*>(d_dst);
+    SQY_HIP(hipMemcpyAsync(out, hdr.data(), hdr.size(), hipMemcpyHostToDevice, stream));
+    if (payload_is_lz4) {
+        const unsigned char fd[2] = {0x40, (unsigned char)(lz4p->block_id << 4)};
+        const uint32_t hc = (sqy::xxh32(fd, 2, 0) >> 8) & 0xff;
+        if (lz4_nchunks == 0) {
+            const unsigned char empty[11] = {0x04, 0x22, 0x4D, 0x18, fd[0], fd[1], (unsigned char)hc, 0, 0, 0, 0};
+            SQY_HIP(hipMemcpyAsync(out + hdr.size(), empty, sizeof(empty), hipMemcpyHostToDevice, stream));
+        } else {
+            ProfScope ps("lz4_frame_gather", stream);
+            SQY_HIP(sqy::launch_lz4_frame_gather(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
+                                                 static_cast<uint32_t*>(ws->csize.p), static_cast<uint64_t*>(ws->frame_off.p),
+                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream));
+        }
+    } else {
+        ProfScope ps("payload_copy", stream);
+        SQY_HIP(hipMemcpyAsync(out + hdr.size(), cur, payload_bytes, hipMemcpyDeviceToDevice, stream));
+    }
+    SQY_HIP(hipStreamSynchronize(stream));
+    if (g_prof_on) prof_collect();
+    *dstlength = (long)blob_bytes;
+    (void)raw_bytes;
+    return 0;
+}
+
+int encode_from_host(const char* pipeline, const char* src, long* shape, unsigned rank, int elem_size, char* dst,
+                     long* dstlength, int nthreads)
+{
+    if (!pipeline || !src || !shape || !dst || !dstlength) return 1;
+    {
+        std::string why;
+        if (!Pipeline::supported(pipeline, elem_size, &why)) {
+            if (Pipeline::reference_accepts(pipeline)) std::fprintf(stderr, "[sqeazy]\t pipeline %s: %s\n", pipeline, why.c_str());
+            return 1;   // sqeazy.cpp:81-82,118-119: invalid pipeline -> 1 before touching any buffer
+        }
+    }
+    if (!device_present()) { std::fprintf(stderr, "[sqeazy]\t no MI355X (HIP device) visible: sqeazy_amd has no CPU path\n"); return 1; }
+    std::lock_guard<std::mutex> lock(g_mu);
+    Workspace* ws = workspace();
+    if (!ws) return 1;
+    uint64_t len = 1;
+    for (unsigned i = 0; i < rank; ++i) {
+        if (shape[i] <= 0) return 1;
+        len *= (uint64_t)shape[i];
+        if (len >= ((uint64_t)1 << 31)) break;
+    }
+    if (len >= ((uint64_t)1 << 31)) {
+        std::fprintf(stderr, "[sqeazy]\t 2^31 or more voxels in one call overflow the reference's int voxel count; encode z-slabs\n");
+        return 1;
+    }
+    const uint64_t raw = len * (uint64_t)elem_size;
+    Pipeline pipe = Pipeline::from_string(pipeline);
+    pipe.set_n_threads(nthreads);
+    const uint64_t bound = pipe.max_encoded_size(raw, elem_size);
+    if (ws->io_src.ensure(std::max<uint64_t>(raw, 16)) || ws->io_dst.ensure(bound)) return 1;
+    SQY_HIP(hipMemcpy(ws->io_src.p, src, raw, hipMemcpyHostToDevice));
+    long out_len = 0;
+    const int rc = encode_on_device(pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, nullptr);
+    if (rc) return rc;
+    SQY_HIP(hipMemcpy(dst, ws->io_dst.p, (size_t)out_len, hipMemcpyDeviceToHost));
+    *dstlength = out_len;
+    return 0;
+}
+
+int max_compressed_length(const char* pipeline, long pipeline_length, long* length, int elem_size, uint64_t raw_bytes)
+{
+    if (!pipeline || !length || pipeline_length < 0) return 1;
+    const std::string s(pipeline, pipeline + pipeline_length);
+    if (!Pipeline::supported(s, elem_size)) return 1;
+    const Pipeline p = Pipeline::from_string(s);
+    if (p.stages.empty()) {
+        std::fprintf(stderr, "[sqeazy]\t received %spipeline of size 0, cannot compite Max_Compressed_Length\n", p.name().c_str());
+        return 1;
+    }
+    *length = (long)p.max_encoded_size(raw_bytes, elem_size);
+    return 0;
+}
+
+} // namespace
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+int SQY_Header_Size(const char* src, long* length)
+{
+    if (!src || !length) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(src, src + *length);
+    *length = h.valid ? (long)h.size : 0;
+    return 0;
+}
+
+int SQY_Decompressed_NDims(const char* src, long* num)
+{
+    if (!src || !num) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(src, src + *num);
+    *num = (long)h.shape.size();
+    return 0;
+}
+
+int SQY_Decompressed_Shape(const char* src, long* shape)
+{
+    if (!src || !shape) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(src, src + shape[0]);
+    for (size_t i = 0; i < h.shape.size(); ++i) shape[i] = (long)h.shape[i];
+    return 0;
+}
+
+int SQY_Decompressed_Sizeof(const char* src, long* Sizeof)
+{
+    if (!src || !Sizeof) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(src, src + *Sizeof);
+    *Sizeof = h.valid ? h.elem_size() : 0;
+    return 0;
+}
+
+int SQY_Decompressed_Length(const char* data, long* length)
+{
+    if (!data || !length) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(data, data + *length);
+    uint64_t n = 1;
+    for (uint64_t d : h.shape) n *= d;
+    *length = h.valid ? (long)(n * (uint64_t)h.elem_size()) : 0;
+    return 0;
+}
+
+int SQY_Version_Triple(int* version)
+{
+    if (!version) return 1;
+    version[0] = sqy::kVersionTriple[0];
+    version[1] = sqy::kVersionTriple[1];
+    version[2] = sqy::kVersionTriple[2];
+    return 0;
+}
+
+int SQY_PipelineEncode_UI8(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst, long* dstlength, int nthreads)
+{
+    return encode_from_host(pipeline, src, shape, shape_size, 1, dst, dstlength, nthreads);
+}
+
+int SQY_PipelineEncode_UI16(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst, long* dstlength, int nthreads)
+{
+    return encode_from_host(pipeline, src, shape, shape_size, 2, dst, dstlength, nthreads);
+}
+
+int SQY_Pipeline_Max_Compressed_Length_UI8(const char* pipeline, long pipeline_length, long* length)
+{
+    return length ? max_compressed_length(pipeline, pipeline_length, length, 1, (uint64_t)*length) : 1;
+}
+
+int SQY_Pipeline_Max_Compressed_Length_UI16(const char* pipeline, long pipeline_length, long* length)
+{
+    return length ? max_compressed_length(pipeline, pipeline_length, length, 2, (uint64_t)*length) : 1;
+}
+
+static int max_len_3d(const char* pipeline, long* shape, unsigned shape_size, long* length, int elem)
+{
+    if (!shape || !length) return 1;
+    long n = 1;
+    for (unsigned i = 0; i < shape_size; ++i) n *= shape[i];   // std::accumulate(..., 1, multiplies<long>) (sqeazy.cpp:195)
+    return max_compressed_length(pipeline, *length, length, elem, (uint64_t)n * (uint64_t)elem);
+}
+
+int SQY_Pipeline_Max_Compressed_Length_3D_UI8(const char* pipeline, long* shape, unsigned shape_size, long* length)
+{
+    return max_len_3d(pipeline, shape, shape_size, length, 1);
+}
+
+int SQY_Pipeline_Max_Compressed_Length_3D_UI16(const char* pipeline, long* shape, unsigned shape_size, long* length)
+{
+    return max_len_3d(pipeline, shape, shape_size, length, 2);
+}
+
+bool SQY_Pipeline_Possible_UI16(const char* s) { return s && Pipeline::supported(s, 2); }
+bool SQY_Pipeline_Possible_UI8(const char* s) { return s && Pipeline::supported(s, 1); }
+bool SQY_Pipeline_Possible(const char* s, int sizeofpixel)
+{
+    if (!s) return false;
+    if (sizeofpixel == 2) return Pipeline::supported(s, 2);
+    if (sizeofpixel == 1) return Pipeline::supported(s, 1);
+    return false;
+}
+
+int SQY_Decode_UI16(const char* src, long srclength, char* dst, int nthreads)
+{
+    (void)src; (void)srclength; (void)dst; (void)nthreads;
+    std::fprintf(stderr, "[sqeazy]\t SQY_Decode_UI16: decode is not implemented on MI355X yet\n");
+    return 1;
+}
+
+int SQY_Decode_UI8(const char* src, long srclength, char* dst, int nthreads)
+{
+    (void)src; (void)srclength; (void)dst; (void)nthreads;
+    std::fprintf(stderr, "[sqeazy]\t SQY_Decode_UI8: decode is not implemented on MI355X yet\n");
+    return 1;
+}
+
+int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
+                                      long dst_capacity, long* dstlength, int nthreads, void* hip_stream)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return encode_on_device(pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+                            static_cast<hipStream_t>(hip_stream));
+}
+
+int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
+                                     long dst_capacity, long* dstlength, int nthreads, void* hip_stream)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    return encode_on_device(pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+                            static_cast<hipStream_t>(hip_stream));
+}
+
+int SQYAMD_Decode_UI16_Device(const void*, long, void*, long, void*)
+{
+    std::fprintf(stderr, "[sqeazy]\t decode is not implemented on MI355X yet\n");
+    return 1;
+}
+
+int SQYAMD_Decode_UI8_Device(const void*, long, void*, long, void*)
+{
+    std::fprintf(stderr, "[sqeazy]\t decode is not implemented on MI355X yet\n");
+    return 1;
+}
+
+void SQYAMD_Profile_Enable(int enable)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_prof_on = enable != 0;
+}
+
+void SQYAMD_Profile_Reset(void)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    g_prof.clear();
+}
+
+const char* SQYAMD_Profile_Get(int i, double* total_ms, long* launches)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    if (i < 0 || (size_t)i >= g_prof.size()) return nullptr;
+    if (total_ms) *total_ms = g_prof[i].ms;
+    if (launches) *launches = g_prof[i].launches;
+    return g_prof[i].name.c_str();
+}
+
+void SQYAMD_Release_Workspace(void)
+{
+    std::lock_guard<std::mutex> lock(g_mu);
+    int dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) g_ws[dev].release();
+}
+
+const char* SQYAMD_Version(void) { return "sqeazy_amd 0.1.0 (gfx950, sqy header 0.5.2)"; }
+
+} // extern "C"

@@ -1,0 +1,30 @@
+// sqy_kernels.h -- launchers of the HIP kernels in sqy_kernels.hip (device pointers, explicit stream).
+#ifndef SQY_KERNELS_H_
+#define SQY_KERNELS_H_
+
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+
+namespace sqy {
+
+// bitswap1: bit-plane transpose of `len` elements (encoders/bitswap_scheme_impl.hpp:97-145)
+hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream);
+hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
+
+// diff3x3x1 on a {Z,Y,X} volume of 1- or 2-byte unsigned voxels (encoders/diff_scheme_impl.hpp:78-139)
+hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream);
+
+// LZ4: every `chunk` bytes of in[0,total) compressed on its own into scratch + k*stride (capacity chunk-1);
+// csize[k] = compressed bytes, 0 when the chunk has to be stored raw.
+hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
+                             uint32_t* csize, uint64_t nchunks, hipStream_t stream);
+// frame_off[k] = byte offset of frame k in the concatenated stream, frame_off[nchunks] = total payload bytes
+hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
+                                 uint64_t* frame_off, hipStream_t stream);
+// writes [04 22 4D 18 | 40 | BD | HC][u32 size][data][00 00 00 00] per chunk at out + frame_off[k]
+hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
+                                   const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
+                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream);
+
+} // namespace sqy
+#endif

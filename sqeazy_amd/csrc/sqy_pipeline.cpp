@@ -1,0 +1,538 @@
+// sqy_pipeline.cpp -- see sqy_pipeline.hpp.  Pure host logic, no HIP.
+#include "sqy_pipeline.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <sstream>
+#include <thread>
+
+namespace sqy {
+
+const char* const kVersion = "0.5.2";    // sqy.version: a build-time constant in the reference (sqeazy_header.hpp:172)
+const char* const kHeadRef = "mi355x";   // sqy.headref: `git describe --always` of the reference build (:173)
+const int kVersionTriple[3] = {0, 5, 2};
+
+static const std::string kVerbOpen = "<verbatim>";
+static const std::string kVerbClose = "</verbatim>";
+static const std::string kHeaderEnd = "|01307#!";   // sqeazy_header.hpp:586
+
+std::vector<std::string> split_outside_verbatim(const std::string& s, const std::string& sep, bool* ok)
+{
+    std::vector<std::string> out;
+    if (ok) *ok = true;
+    std::string cur;
+    size_t i = 0;
+    while (i < s.size()) {
+        if (s.compare(i, kVerbOpen.size(), kVerbOpen) == 0) {
+            const size_t j = s.find(kVerbClose, i);
+            if (j == std::string::npos) {            // "found only 1 verbatim delimeter" (string_parsers.hpp:150-153)
+                if (ok) *ok = false;
+                return {};
+            }
+            cur.append(s, i, j + kVerbClose.size() - i);
+            i = j + kVerbClose.size();
+            continue;
+        }
+        if (s.compare(i, sep.size(), sep) == 0) {
+            out.push_back(cur);
+            cur.clear();
+            i += sep.size();
+            continue;
+        }
+        cur.push_back(s[i]);
+        ++i;
+    }
+    out.push_back(cur);
+    return out;
+}
+
+pairs_t parse_pairs(const std::string& pipeline)
+{
+    pairs_t value;
+    if (pipeline.empty()) return value;
+    for (const std::string& major : split_outside_verbatim(pipeline, "->")) {
+        const size_t d = major.find('(');
+        if (d == std::string::npos)
+            value.emplace_back(major, "");
+        else
+            value.emplace_back(major.substr(0, d), major.size() > d + 1 ? major.substr(d + 1, major.size() - d - 2) : "");
+    }
+    return value;
+}
+
+std::map<std::string, std::string> parse_minors(const std::string& cfg)
+{
+    std::map<std::string, std::string> value;
+    if (cfg.empty()) return value;
+    for (const std::string& item : split_outside_verbatim(cfg, ",")) {
+        const size_t d = item.find('=');
+        if (d == std::string::npos) {
+            value[item] = item;
+        } else {
+            value[item.substr(0, d)] = (d + 1 < item.size()) ? item.substr(d + 1) : item;
+        }
+    }
+    return value;
+}
+
+// ---- lz4 parameters (encoders/lz4.hpp:58-114) ----
+static uint32_t closest_blocksize_kb(uint32_t kb)
+{
+    static const uint32_t sizes[4] = {64, 256, 1024, 4096};   // lz4_utils.hpp:60-93
+    const uint32_t* it = std::lower_bound(sizes, sizes + 4, kb);
+    if (it == sizes + 4) return sizes[3];
+    if (it == sizes) return sizes[0];
+    const uint32_t lo = *(it - 1), hi = *it;
+    const uint32_t middle = lo + (hi - lo) / 2;
+    return kb >= middle ? hi : lo;
+}
+
+static float stof_or(const std::string& s, float dflt)
+{
+    char* end = nullptr;
+    const float v = std::strtof(s.c_str(), &end);
+    return (end == s.c_str()) ? dflt : v;
+}
+
+Lz4Params::Lz4Params(const std::string& cfg)
+{
+    const auto m = parse_minors(cfg);
+    auto f = m.find("accel");
+    if (f != m.end()) accel = (int)stof_or(f->second, 1.f);
+    f = m.find("blocksize_kb");
+    if (f != m.end()) blocksize_kb = (uint32_t)stof_or(f->second, 256.f);
+    f = m.find("framestep_kb");
+    if (f != m.end()) framestep_kb = (uint32_t)stof_or(f->second, 256.f);
+    f = m.find("n_chunks_of_input");
+    if (f != m.end()) n_chunks = (uint32_t)stof_or(f->second, 0.f);
+    if (blocksize_kb == 0) blocksize_kb = 256;
+    if (framestep_kb < blocksize_kb)
+        framestep_kb = blocksize_kb;
+    else
+        framestep_kb = (uint32_t)(std::round(framestep_kb / float(blocksize_kb)) * blocksize_kb);
+    if (n_chunks != 0) framestep_kb = 0;
+    const uint32_t c = closest_blocksize_kb(blocksize_kb);
+    block_id = c == 64 ? 4 : c == 256 ? 5 : c == 1024 ? 6 : 7;
+}
+
+std::string Lz4Params::config() const
+{
+    std::ostringstream msg;
+    msg << "accel=" << accel << ",blocksize_kb=" << blocksize_kb << ",framestep_kb=" << framestep_kb
+        << ",n_chunks_of_input=" << n_chunks;
+    return msg.str();
+}
+
+uint64_t Lz4Params::block_bytes() const
+{
+    static const uint64_t b[8] = {0, 0, 0, 0, 64u << 10, 256u << 10, 1u << 20, 4u << 20};
+    return b[block_id];
+}
+
+uint64_t Lz4Params::bytes_per_chunk(uint64_t nbytes) const
+{
+    uint64_t value = framestep_kb ? (uint64_t)framestep_kb << 10 : (n_chunks ? nbytes / n_chunks : nbytes);
+    if (value >= nbytes || n_chunks >= nbytes) value = nbytes;
+    return value;
+}
+
+uint64_t Lz4Params::compress_bound(uint64_t srcSize, int block_id)
+{
+    static const uint64_t b[8] = {0, 0, 0, 0, 64u << 10, 256u << 10, 1u << 20, 4u << 20};
+    const uint64_t blockSize = b[block_id];
+    const uint64_t maxSrcSize = srcSize + (blockSize - 1);        // autoFlush = 0: a full tmp buffer is assumed
+    const uint64_t nbFullBlocks = maxSrcSize / blockSize;
+    const uint64_t partial = maxSrcSize & (blockSize - 1);
+    const uint64_t last = (srcSize == 0) ? partial : 0;
+    const uint64_t nbBlocks = nbFullBlocks + (last > 0);
+    return 4 * nbBlocks + blockSize * nbFullBlocks + last + 4;
+}
+
+uint64_t Lz4Params::max_encoded_size(uint64_t nbytes, unsigned nthreads) const
+{
+    const uint64_t per_chunk = bytes_per_chunk(nbytes);
+    const uint64_t hdr_max = 19;                                   // LZ4F_HEADER_SIZE_MAX (liblz4 1.9.3)
+    if (per_chunk >= nbytes) return hdr_max + compress_bound(per_chunk, block_id);
+    if (nthreads == 0) nthreads = 1;
+    const uint64_t nchunks = (nbytes + per_chunk - 1) / per_chunk;
+    const uint64_t per_thread = (nchunks + nthreads - 1) / nthreads;
+    return per_thread * (compress_bound(per_chunk, block_id) + hdr_max) * nthreads;
+}
+
+// ---- stages ----
+static StageKind kind_of(const std::string& n)
+{
+    if (n == "diff3x3x1") return StageKind::diff3x3x1;
+    if (n == "bitswap1") return StageKind::bitswap1;
+    if (n == "frame_shuffle") return StageKind::frame_shuffle;
+    if (n == "quantiser") return StageKind::quantiser;
+    if (n == "lz4") return StageKind::lz4;
+    if (n == "pass_through") return StageKind::pass_through;
+    return StageKind::unsupported;
+}
+
+std::string Stage::config() const
+{
+    switch (kind) {
+        case StageKind::bitswap1: return "num_bits_per_plane=1";                 // bitswap_scheme_impl.hpp:84-90
+        case StageKind::diff3x3x1: return "";                                    // diff_scheme_impl.hpp:55-59
+        case StageKind::lz4: return lz4.config();                                // lz4.hpp:132-141
+        case StageKind::pass_through: return "";
+        case StageKind::quantiser: {                                             // quantiser_scheme_impl.hpp:102-118
+            std::string s;
+            size_t count = 0;
+            for (const auto& kv : cfg) {
+                s += kv.first + "=" + kv.second;
+                if (count++ < cfg.size() - 1) s += ",";
+            }
+            return s;
+        }
+        case StageKind::frame_shuffle: {                                         // frame_shuffle_scheme_impl.hpp:58-66
+            auto c = cfg.find("frame_chunk_size");
+            auto m = cfg.find("reorder_map");
+            const int chunk = c != cfg.end() ? std::atoi(c->second.c_str()) : 1;
+            return "frame_chunk_size=" + std::to_string(chunk) + ",reorder_map=" + (m != cfg.end() ? m->second : "");
+        }
+        default: return "";
+    }
+}
+
+std::string Stage::full_name() const
+{
+    const std::string c = config();
+    return c.empty() ? name : name + "(" + c + ")";
+}
+
+static bool in_list(const std::string& n, const char* const* list, size_t cnt)
+{
+    for (size_t i = 0; i < cnt; ++i) if (n == list[i]) return true;
+    return false;
+}
+
+bool known_head_filter(const std::string& n)
+{
+    static const char* const l[] = {"diff3x3x1", "bitswap1", "remove_background", "rmbkrd_neighbor5x5x5", "rmestbkrd",
+                                    "raster_reorder", "tile_shuffle", "frame_shuffle", "zcurve_reorder"};
+    return in_list(n, l, sizeof(l) / sizeof(l[0]));
+}
+bool known_sink(const std::string& n)
+{
+    static const char* const l[] = {"pass_through", "quantiser", "lz4"};
+    return in_list(n, l, sizeof(l) / sizeof(l[0]));
+}
+bool known_tail_filter(const std::string& n)
+{
+    static const char* const l[] = {"diff3x3x1", "bitswap1", "lz4", "raster_reorder", "tile_shuffle", "frame_shuffle",
+                                    "zcurve_reorder"};
+    return in_list(n, l, sizeof(l) / sizeof(l[0]));
+}
+
+bool Pipeline::reference_accepts(const std::string& s)
+{
+    // dynamic_pipeline.hpp:177-226
+    const pairs_t pairs = parse_pairs(s);
+    bool ok = true;
+    const std::vector<std::string> majors = s.empty() ? std::vector<std::string>() : split_outside_verbatim(s, "->", &ok);
+    if (!ok || majors.size() != pairs.size()) return false;
+    uint32_t found = 0;
+    bool sink_matched = false;
+    for (const auto& p : pairs) {
+        if (!sink_matched && known_head_filter(p.first)) { found++; continue; }
+        if (known_sink(p.first)) { found++; sink_matched = true; continue; }
+        if (known_tail_filter(p.first)) found++;
+    }
+    bool value = found == pairs.size();
+    size_t rebuild = 2 * (pairs.size() - 1);          // size_t arithmetic, wraps for the empty string like the reference
+    for (const auto& p : pairs) {
+        rebuild += p.first.size();
+        if (!p.second.empty()) rebuild += 2 + p.second.size();
+    }
+    return value && rebuild == s.size();
+}
+
+Pipeline Pipeline::from_string(const std::string& s)
+{
+    // dynamic_pipeline.hpp:137-170: head filters until the first sink, then tail filters; unknown names are skipped
+    Pipeline p;
+    for (const auto& pr : parse_pairs(s)) {
+        Stage st;
+        st.name = pr.first;
+        st.kind = kind_of(pr.first);
+        st.cfg = parse_minors(pr.second);
+        if (st.kind == StageKind::lz4) st.lz4 = Lz4Params(pr.second);
+        if (p.sink_index < 0) {
+            if (known_head_filter(pr.first)) { p.stages.push_back(st); continue; }
+            if (known_sink(pr.first)) { p.sink_index = (int)p.stages.size(); p.stages.push_back(st); }
+        } else if (known_tail_filter(pr.first)) {
+            p.stages.push_back(st);
+        }
+    }
+    return p;
+}
+
+bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
+{
+    auto fail = [&](const std::string& m) { if (why) *why = m; return false; };
+    if (!reference_accepts(s)) return fail("not a valid sqeazy pipeline");
+    const Pipeline p = from_string(s);
+    if (p.stages.empty()) return fail("empty pipeline");
+    for (size_t i = 0; i < p.stages.size(); ++i) {
+        const Stage& st = p.stages[i];
+        const bool after_sink = p.sink_index >= 0 && (int)i > p.sink_index;
+        switch (st.kind) {
+            case StageKind::bitswap1: break;
+            case StageKind::diff3x3x1:
+                if (after_sink) return fail("diff3x3x1 as a tail filter (on char) is not implemented on MI355X");
+                break;
+            case StageKind::frame_shuffle: {
+                if (after_sink) return fail("frame_shuffle as a tail filter is not implemented on MI355X");
+                auto c = st.cfg.find("frame_chunk_size");
+                if (c != st.cfg.end() && std::atoi(c->second.c_str()) != 1)
+                    return fail("frame_shuffle: only frame_chunk_size=1 is implemented on MI355X");
+                break;
+            }
+            case StageKind::quantiser: {
+                if (elem_size != 2) return fail("quantiser: only 16-bit input is implemented on MI355X");
+                auto w = st.cfg.find("weighting_function");
+                if (w != st.cfg.end() && w->second.find("none") == std::string::npos)
+                    return fail("quantiser: only weighting_function=none is implemented on MI355X");
+                if (st.cfg.count("decode_lut_path")) return fail("quantiser: decode_lut_path is not implemented on MI355X");
+                break;
+            }
+            case StageKind::lz4:
+                if (i + 1 != p.stages.size()) return fail("lz4 must be the last stage on MI355X");
+                if (st.lz4.accel >= 3) return fail("lz4 accel >= 3 selects LZ4HC in liblz4; not implemented on MI355X");
+                break;
+            case StageKind::pass_through:
+            default:
+                return fail("stage '" + st.name + "' is not implemented on MI355X");
+        }
+    }
+    return true;
+}
+
+std::string Pipeline::name() const
+{
+    std::string v;
+    for (size_t i = 0; i < stages.size(); ++i) {
+        if (i) v += "->";
+        v += stages[i].full_name();
+    }
+    return v;
+}
+
+int clean_number_of_threads(int n)
+{
+    static int max_threads = (int)std::thread::hardware_concurrency();
+    if (n > max_threads || n <= 0) n = max_threads;
+    return n;
+}
+
+void Pipeline::set_n_threads(int n) { nthreads = (unsigned)clean_number_of_threads(n); }
+
+uint64_t Pipeline::max_encoded_size(uint64_t nbytes, int elem_size) const
+{
+    // header(incoming_t(), nbytes, name()): rank-1 shape {nbytes}, payload = nbytes*sizeof(T) (sqeazy_header.hpp:229-251)
+    const std::string hdr = header_pack(elem_size, false, std::vector<uint64_t>(1, nbytes), name(), nbytes * (uint64_t)elem_size);
+    uint64_t best = 0;
+    for (const Stage& st : stages) {
+        uint64_t v = nbytes;
+        if (st.kind == StageKind::lz4) v = st.lz4.max_encoded_size(nbytes, nthreads);
+        else if (st.kind == StageKind::quantiser) v = nbytes * (uint64_t)elem_size + 256u * (uint64_t)elem_size;
+        best = std::max(best, v);
+    }
+    return 2 * hdr.size() + best;
+}
+
+// ---- header ----
+static void json_escape(const std::string& s, std::string& out)
+{
+    // Boost.PropertyTree json writer escapes: " \ / and control characters
+    static const char* hex = "0123456789ABCDEF";
+    for (unsigned char c : s) {
+        switch (c) {
+            case '"': out += "\\\""; break;
+            case '\\': out += "\\\\"; break;
+            case '/': out += "\\/"; break;
+            case '\b': out += "\\b"; break;
+            case '\f': out += "\\f"; break;
+            case '\n': out += "\\n"; break;
+            case '\r': out += "\\r"; break;
+            case '\t': out += "\\t"; break;
+            default:
+                if (c < 0x20) { out += "\\u00"; out += hex[c >> 4]; out += hex[c & 15]; }
+                else out += (char)c;
+        }
+    }
+}
+
+std::string header_pack(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
+                        uint64_t payload_bytes)
+{
+    const char* type = elem_size == 2 ? "uint16" : (is_signed8 ? "int8" : "uint8");   // header_utils.hpp:19-34
+    std::string j;
+    j += "{\n    \"pipename\": \"";
+    json_escape(pipename, j);
+    j += "\",\n    \"raw\": {\n        \"type\": \"";
+    j += type;
+    j += "\",\n        \"rank\": \"" + std::to_string(shape.size()) + "\",\n        \"shape\": {\n";
+    for (size_t i = 0; i < shape.size(); ++i) {
+        j += "            \"dim\": \"" + std::to_string(shape[i]) + "\"";
+        j += (i + 1 < shape.size()) ? ",\n" : "\n";
+    }
+    j += "        }\n    },\n    \"encoded\": {\n        \"bytes\": \"" + std::to_string(payload_bytes) + "\"\n    },\n";
+    j += "    \"sqy\": {\n        \"version\": \"";
+    j += kVersion;
+    j += "\",\n        \"headref\": \"";
+    j += kHeadRef;
+    j += "\"\n    }\n}\n";
+    j += kHeaderEnd;
+    if (j.size() % (size_t)elem_size != 0) j.insert(0, (size_t)elem_size - j.size() % (size_t)elem_size, ' ');
+    return j;
+}
+
+int HeaderInfo::elem_size() const
+{
+    if (type == "uint16" || type == "int16") return 2;
+    if (type == "uint8" || type == "int8") return 1;
+    if (type == "uint32" || type == "int32") return 4;
+    if (type == "uint64" || type == "int64") return 8;
+    return 0;
+}
+
+static bool read_json_string(const char*& p, const char* end, std::string& out)
+{
+    out.clear();
+    if (p >= end || *p != '"') return false;
+    ++p;
+    while (p < end && *p != '"') {
+        if (*p == '\\' && p + 1 < end) {
+            ++p;
+            switch (*p) {
+                case 'n': out += '\n'; break; case 't': out += '\t'; break; case 'r': out += '\r'; break;
+                case 'b': out += '\b'; break; case 'f': out += '\f'; break;
+                case 'u':
+                    if (p + 4 < end) { out += (char)std::strtol(std::string(p + 1, p + 5).c_str(), nullptr, 16); p += 4; }
+                    break;
+                default: out += *p;
+            }
+            ++p;
+        } else {
+            out += *p++;
+        }
+    }
+    if (p >= end) return false;
+    ++p;
+    return true;
+}
+
+HeaderInfo header_unpack(const char* begin, const char* end)
+{
+    HeaderInfo h;
+    const char* delim = std::search(begin, end, kHeaderEnd.begin(), kHeaderEnd.end());
+    if (delim == end) return h;
+    // sqeazy_header.hpp:520-531 (valid_header): balanced braces, more than one ':'
+    if (std::count(begin, delim, '{') == 0 || std::count(begin, delim, '{') != std::count(begin, delim, '}')) return h;
+    if (std::count(begin, delim, ':') <= 1) return h;
+    const char* p = begin;
+    std::string key, val;
+    bool have_pipe = false, have_bytes = false;
+    while (p < delim) {
+        if (*p != '"') { ++p; continue; }
+        if (!read_json_string(p, delim, key)) break;
+        while (p < delim && (*p == ' ' || *p == '\t' || *p == '\n')) ++p;
+        if (p >= delim || *p != ':') continue;
+        ++p;
+        while (p < delim && (*p == ' ' || *p == '\t' || *p == '\n')) ++p;
+        if (p < delim && *p == '"') {
+            if (!read_json_string(p, delim, val)) break;
+            if (key == "pipename") { h.pipename = val; have_pipe = true; }
+            else if (key == "type") h.type = val;
+            else if (key == "dim") h.shape.push_back(std::strtoull(val.c_str(), nullptr, 10));
+            else if (key == "bytes") { h.payload_bytes = std::strtoull(val.c_str(), nullptr, 10); have_bytes = true; }
+        }
+    }
+    h.size = (uint64_t)(delim - begin) + kHeaderEnd.size();
+    h.valid = have_pipe && have_bytes && !h.type.empty();
+    return h;
+}
+
+// ---- base64 (base64.hpp:135-162: standard alphabet, '=' padded) ----
+std::string base64_encode(const unsigned char* src, size_t n)
+{
+    static const char tbl[] = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+    std::string o;
+    o.reserve(4 * ((n + 2) / 3));
+    size_t i = 0;
+    for (; i + 2 < n; i += 3) {
+        const unsigned v = ((unsigned)src[i] << 16) | ((unsigned)src[i + 1] << 8) | src[i + 2];
+        o += tbl[(v >> 18) & 63]; o += tbl[(v >> 12) & 63]; o += tbl[(v >> 6) & 63]; o += tbl[v & 63];
+    }
+    if (n - i == 1) {
+        const unsigned v = (unsigned)src[i] << 16;
+        o += tbl[(v >> 18) & 63]; o += tbl[(v >> 12) & 63]; o += "==";
+    } else if (n - i == 2) {
+        const unsigned v = ((unsigned)src[i] << 16) | ((unsigned)src[i + 1] << 8);
+        o += tbl[(v >> 18) & 63]; o += tbl[(v >> 12) & 63]; o += tbl[(v >> 6) & 63]; o += '=';
+    }
+    return o;
+}
+
+std::vector<unsigned char> base64_decode(const std::string& s)
+{
+    std::vector<unsigned char> out;
+    unsigned acc = 0;
+    int bits = 0;
+    for (char ch : s) {
+        int v;
+        if (ch >= 'A' && ch <= 'Z') v = ch - 'A';
+        else if (ch >= 'a' && ch <= 'z') v = ch - 'a' + 26;
+        else if (ch >= '0' && ch <= '9') v = ch - '0' + 52;
+        else if (ch == '+') v = 62;
+        else if (ch == '/') v = 63;
+        else continue;
+        acc = (acc << 6) | (unsigned)v;
+        bits += 6;
+        if (bits >= 8) { bits -= 8; out.push_back((unsigned char)((acc >> bits) & 0xff)); }
+    }
+    return out;
+}
+
+std::string to_verbatim(const void* data, size_t bytes)
+{
+    if (!bytes) return "";
+    return kVerbOpen + base64_encode(static_cast<const unsigned char*>(data), bytes) + kVerbClose;   // string_parsers.hpp:507-534
+}
+
+// ---- xxh32 (LZ4 frame descriptor checksum) ----
+static inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+static inline uint32_t rd32(const unsigned char* p) { uint32_t v; std::memcpy(&v, p, 4); return v; }
+
+uint32_t xxh32(const unsigned char* p, size_t len, uint32_t seed)
+{
+    const uint32_t P1 = 2654435761U, P2 = 2246822519U, P3 = 3266489917U, P4 = 668265263U, P5 = 374761393U;
+    const unsigned char* const end = p + len;
+    uint32_t h;
+    if (len >= 16) {
+        const unsigned char* const limit = end - 16;
+        uint32_t v1 = seed + P1 + P2, v2 = seed + P2, v3 = seed, v4 = seed - P1;
+        do {
+            v1 = rotl32(v1 + rd32(p) * P2, 13) * P1; p += 4;
+            v2 = rotl32(v2 + rd32(p) * P2, 13) * P1; p += 4;
+            v3 = rotl32(v3 + rd32(p) * P2, 13) * P1; p += 4;
+            v4 = rotl32(v4 + rd32(p) * P2, 13) * P1; p += 4;
+        } while (p <= limit);
+        h = rotl32(v1, 1) + rotl32(v2, 7) + rotl32(v3, 12) + rotl32(v4, 18);
+    } else {
+        h = seed + P5;
+    }
+    h += (uint32_t)len;
+    while (p + 4 <= end) { h = rotl32(h + rd32(p) * P3, 17) * P4; p += 4; }
+    while (p < end) { h = rotl32(h + (*p) * P5, 11) * P1; p++; }
+    h ^= h >> 15; h *= P2; h ^= h >> 13; h *= P3; h ^= h >> 16;
+    return h;
+}
+
+} // namespace sqy

@@ -1,0 +1,100 @@
+// sqy_pipeline.hpp -- host-side mirror of the reference's pipeline object for the hot path:
+// pipeline grammar, per-stage configuration strings, size bounds and the sqy header.
+//
+// Mirrors (paths relative to /root/reference/src/cpp/src):
+//   string_parsers.hpp:285-471        pipeline_parser::to_pairs / minors (with <verbatim> protection)
+//   dynamic_pipeline.hpp:137-226      from_string / can_be_built_from
+//   dynamic_pipeline.hpp:476-503      name()
+//   dynamic_pipeline.hpp:866-890      max_encoded_size
+//   sqeazy_header.hpp:146-193,294-344 header pack / unpack
+//   encoders/lz4.hpp:58-188           lz4 parameter logic, config string, chunking, size bound
+//   sqeazy_algorithms.hpp:14-22       thread-count clamp
+#ifndef SQY_PIPELINE_HPP_
+#define SQY_PIPELINE_HPP_
+
+#include <cstdint>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+namespace sqy {
+
+typedef std::vector<std::pair<std::string, std::string>> pairs_t;
+
+// split on `sep` outside <verbatim>...</verbatim>; returns {} for a malformed (unbalanced) string
+std::vector<std::string> split_outside_verbatim(const std::string& s, const std::string& sep, bool* ok = nullptr);
+pairs_t parse_pairs(const std::string& pipeline);
+std::map<std::string, std::string> parse_minors(const std::string& cfg);
+
+enum class StageKind { diff3x3x1, bitswap1, frame_shuffle, quantiser, lz4, pass_through, unsupported };
+
+struct Lz4Params {
+    int accel = 1;
+    uint32_t blocksize_kb = 256, framestep_kb = 256, n_chunks = 0;
+    int block_id = 5;                       // LZ4F blockSizeID 4..7
+    explicit Lz4Params(const std::string& cfg = "");
+    std::string config() const;
+    uint64_t block_bytes() const;
+    uint64_t bytes_per_chunk(uint64_t nbytes) const;                       // lz4.hpp:146-156
+    uint64_t max_encoded_size(uint64_t nbytes, unsigned nthreads) const;   // lz4.hpp:166-188
+    static uint64_t compress_bound(uint64_t src, int block_id);            // LZ4F_compressBound, autoFlush = 0
+};
+
+struct Stage {
+    std::string name;
+    StageKind kind = StageKind::unsupported;
+    std::map<std::string, std::string> cfg;   // parsed (k=v,...) payload; std::map => sorted like the reference's config_map
+    Lz4Params lz4;
+    std::string config() const;               // re-serialised configuration, as the reference's config()
+    std::string full_name() const;            // name or name(config)
+};
+
+// which factory lists know a name (sqeazy_pipelines.hpp:31-77; optional ffmpeg/bitshuffle stages are not built)
+bool known_head_filter(const std::string& n);
+bool known_sink(const std::string& n);
+bool known_tail_filter(const std::string& n);
+
+struct Pipeline {
+    std::vector<Stage> stages;
+    int sink_index = -1;                      // index of the sink stage, -1 when the pipeline only filters
+    unsigned nthreads = 1;                    // stage default (dynamic_stage.hpp:21-24)
+
+    // the reference's validity rule over its full stage lists
+    static bool reference_accepts(const std::string& s);
+    // true when every stage is one this library implements (subset of the above)
+    static bool supported(const std::string& s, int elem_size, std::string* why = nullptr);
+    static Pipeline from_string(const std::string& s);
+
+    std::string name() const;
+    uint64_t max_encoded_size(uint64_t nbytes, int elem_size) const;
+    void set_n_threads(int n);
+};
+
+int clean_number_of_threads(int n);
+
+// ---- header ----
+std::string header_pack(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
+                        uint64_t payload_bytes);
+struct HeaderInfo {
+    bool valid = false;
+    std::string pipename, type;
+    std::vector<uint64_t> shape;
+    uint64_t payload_bytes = 0;
+    uint64_t size = 0;       // header bytes including the delimiter
+    int elem_size() const;
+};
+HeaderInfo header_unpack(const char* begin, const char* end);
+
+std::string base64_encode(const unsigned char* src, size_t n);
+std::vector<unsigned char> base64_decode(const std::string& s);
+std::string to_verbatim(const void* data, size_t bytes);
+
+uint32_t xxh32(const unsigned char* p, size_t len, uint32_t seed);
+
+extern const char* const kVersion;
+extern const char* const kHeadRef;
+extern const int kVersionTriple[3];
+
+} // namespace sqy
+#endif
