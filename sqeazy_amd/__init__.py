@@ -40,6 +40,15 @@ def lib():
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise LibraryMissing("%s not built: run `python -m sqeazy_amd.build` (hipcc, gfx950)" % LIB_PATH)
+        # One HIP runtime per process: PyTorch-ROCm ships its own libamdhip64.so.7.  When it is loaded first,
+        # our DT_NEEDED libamdhip64.so.7 resolves to that same copy; loaded the other way round the process
+        # ends up with two runtimes and the second one sees no device.  So bring torch's in first when torch
+        # is installed (tests / bench use torch for device memory); plain C/C++ callers simply get /opt/rocm's.
+        if os.environ.get("SQEAZY_AMD_NO_TORCH_PRELOAD", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         L = ctypes.CDLL(LIB_PATH)
         c_long_p = ctypes.POINTER(ctypes.c_long)
         L.SQY_Pipeline_Possible_UI16.restype = ctypes.c_bool

@@ -60,3 +60,46 @@ def stack(shape, dtype=np.uint16, seed=SEED, frames_per_step=16):
             raise TypeError(dtype)
         out[z0:z0 + nz] = v.astype(dtype)
     return out
+
+
+# ---- the same generator on an HBM-resident torch tensor (bench.py; inputs never touch the host) ----
+def _i64(x):
+    x &= (1 << 64) - 1
+    return x - (1 << 64) if x >= (1 << 63) else x
+
+
+def stack_torch(shape, dtype, device, seed=SEED, z_offset=0, z_total=None, frames_per_step=32):
+    """torch twin of `stack`: frames [z_offset, z_offset + shape[0]) of a (z_total, Y, X) volume.
+    Bit-identical to the numpy generator (checked in tests/)."""
+    import torch
+    Z, Y, X = (int(s) for s in shape)
+    ZT = int(z_total) if z_total is not None else Z
+    tdtype = {np.dtype(np.uint16): torch.uint16, np.dtype(np.uint8): torch.uint8}[np.dtype(dtype)]
+    out = torch.empty((Z, Y, X), dtype=tdtype, device=device)
+    per = Y * X
+    m34, m37, m33 = (1 << 34) - 1, (1 << 37) - 1, (1 << 33) - 1
+    c0, c1, c2 = _i64(0x9E3779B97F4A7C15), _i64(0xBF58476D1CE4E5B9), _i64(0x94D049BB133111EB)
+    ax, ay, az = max(X // 4, 1) ** 2, max(Y // 4, 1) ** 2, max((6 * ZT) // 10, 1) ** 2
+    dy = (2 * torch.arange(Y, dtype=torch.int64, device=device) - Y)[None, :, None]
+    dx = (2 * torch.arange(X, dtype=torch.int64, device=device) - X)[None, None, :]
+    qyx = torch.div(64 * dx * dx, ax, rounding_mode="floor") + torch.div(64 * dy * dy, ay, rounding_mode="floor")
+    for z0 in range(0, Z, frames_per_step):
+        nz = min(frames_per_step, Z - z0)
+        zg = z0 + z_offset
+        i = torch.arange(zg * per, (zg + nz) * per, dtype=torch.int64, device=device)
+        x = (i ^ seed) + c0
+        z = (x ^ ((x >> 30) & m34)) * c1
+        z = (z ^ ((z >> 27) & m37)) * c2
+        r = z ^ ((z >> 31) & m33)
+        noise = (r & 0xFF) + ((r >> 8) & 0xFF) + ((r >> 16) & 0xFF) + ((r >> 24) & 0xFF)
+        noise = noise.reshape(nz, Y, X)
+        zz = torch.arange(zg, zg + nz, dtype=torch.int64, device=device)
+        dz = (2 * zz - ZT)[:, None, None]
+        q = qyx + torch.div(64 * dz * dz, az, rounding_mode="floor")
+        sh = ((q - 64).abs() < 5).to(torch.int64)
+        if tdtype == torch.uint16:
+            v = 100 + (noise >> 2) + sh * 6000
+        else:
+            v = 16 + (noise >> 4) + sh * 120 + ((zz * 37) % 13)[:, None, None]
+        out[z0:z0 + nz] = v.to(tdtype)
+    return out
