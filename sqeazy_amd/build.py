@@ -36,7 +36,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
-    common = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function"]
+    common = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=" + ARCH] + common + ["-c", os.path.join(CSRC, src), "-o", obj]

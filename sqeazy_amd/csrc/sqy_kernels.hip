@@ -42,6 +42,30 @@ __device__ __forceinline__ void st_u128(uint8_t* p, uint4 v)
 
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));
 
+// explicit address spaces: without them the compiler merges "read from the LDS ring or from global memory"
+// into one pointer select and emits flat_load + s_waitcnt vmcnt(0) lgkmcnt(0) (seen in the ISA: ~1000 cycles each)
+#define SQY_LDS __attribute__((address_space(3)))
+#define SQY_GLB __attribute__((address_space(1)))
+typedef SQY_LDS uint8_t lds_u8;
+typedef SQY_GLB const uint8_t glb_u8;
+
+__device__ __forceinline__ uint32_t lds_ld_u8(const lds_u8* p) { return *p; }
+__device__ __forceinline__ uint32_t lds_ld_u32(const lds_u8* p) { return reinterpret_cast<const SQY_LDS pk_u32*>(p)->v; }
+__device__ __forceinline__ uint64_t lds_ld_u64(const lds_u8* p) { return reinterpret_cast<const SQY_LDS pk_u64*>(p)->v; }
+__device__ __forceinline__ uint4 lds_ld_u128(const lds_u8* p)
+{
+    const SQY_LDS pk_u128* q = reinterpret_cast<const SQY_LDS pk_u128*>(p);
+    return make_uint4(q->x, q->y, q->z, q->w);
+}
+__device__ __forceinline__ uint32_t glb_ld_u8(glb_u8* p) { return *p; }
+__device__ __forceinline__ uint32_t glb_ld_u32(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u32*>(p)->v; }
+__device__ __forceinline__ uint64_t glb_ld_u64(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u64*>(p)->v; }
+__device__ __forceinline__ uint4 glb_ld_u128(glb_u8* p)
+{
+    SQY_GLB const pk_u128* q = reinterpret_cast<SQY_GLB const pk_u128*>(p);
+    return make_uint4(q->x, q->y, q->z, q->w);
+}
+
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
@@ -283,45 +307,196 @@ __device__ __forceinline__ uint32_t lz4_hash5(uint64_t seq)
     return (uint32_t)(((seq << 24) * 889523592379ULL) >> 52);
 }
 
-// copy `len` bytes (uniform) from s to d, any alignment, no overlap; all 64 lanes call it
-__device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const uint8_t* __restrict__ s, uint32_t len, int lane)
+// Sliding window of the chunk's source bytes in LDS (ring of WIN bytes + a 16-byte mirror of its head so
+// that unaligned 16-byte reads never have to split at the wrap, filled FB bytes at a time).
+// The parse only ever needs bytes around ip (probe sequences, catch-up, match extension, literals) and
+// candidates a short distance back; everything resident is read with LDS latency instead of a dependent
+// HBM/L2 round trip.  Positions outside [wlo, whi) -- far candidates, skip-accelerated probes on
+// incompressible data, very long matches -- fall back to global loads.
+// The block [whi, whi+FB) is prefetched into registers one refill ahead (plain loads: the compiler counts
+// vmcnt for us) and committed to the ring when ip gets within AHEAD bytes of whi.
+constexpr uint32_t LZ4_WIN = 8192, LZ4_FB = 2048, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
+
+struct Lz4Window {
+    glb_u8* src;           // chunk source (global)
+    lds_u8* win;           // LDS ring (WIN + MIRROR bytes)
+    uint32_t n;            // chunk bytes
+    uint32_t whi, wlo;     // resident range [wlo, whi), whi a multiple of FB
+    uint32_t lane16;       // lane * 16
+    uint4 pf[LZ4_FB / 1024];   // block [whi, whi + FB)
+
+    __device__ __forceinline__ void issue()
+    {
+#pragma unroll
+        for (uint32_t j = 0; j < LZ4_FB / 1024; ++j) {
+            const uint32_t a = whi + j * 1024u + lane16;
+            pf[j] = (a + 16u <= n) ? glb_ld_u128(src + a) : make_uint4(0, 0, 0, 0);
+        }
+    }
+    __device__ __forceinline__ void commit()
+    {
+#pragma unroll
+        for (uint32_t j = 0; j < LZ4_FB / 1024; ++j) {
+            const uint32_t o = (whi + j * 1024u + lane16) & (LZ4_WIN - 1);
+            const v4u val = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
+            *reinterpret_cast<SQY_LDS v4u*>(win + o) = val;
+            if (j == 0 && o == 0) *reinterpret_cast<SQY_LDS v4u*>(win + LZ4_WIN) = val;   // mirror of ring[0..16)
+        }
+        whi += LZ4_FB;
+        if (whi - wlo > LZ4_WIN) wlo = whi - LZ4_WIN;
+    }
+    // make [ip - some history, ip + AHEAD) resident as far as the chunk goes (uniform control flow)
+    __device__ __forceinline__ void ensure(uint32_t ip)
+    {
+        if (ip + LZ4_AHEAD <= whi || whi >= n) return;
+        if (ip >= whi + (LZ4_WIN - LZ4_FB)) {                 // jumped past everything resident: restart the ring
+            uint32_t start = ip & ~(LZ4_FB - 1);
+            if (start >= LZ4_FB) start -= LZ4_FB;              // keep one block of history
+            whi = wlo = start;
+            issue();
+        }
+        do {
+            commit();
+            if (whi < n) issue();
+        } while (ip + LZ4_AHEAD > whi && whi < n);
+    }
+    // end of the bytes that can be read from the ring: the last (n & 15) bytes are never filled
+    __device__ __forceinline__ uint32_t hi_valid() const { return whi < (n & ~15u) ? whi : (n & ~15u); }
+    __device__ __forceinline__ bool inside(uint32_t p, uint32_t len) const { return p >= wlo && p + len <= hi_valid(); }
+    __device__ __forceinline__ const lds_u8* at(uint32_t p) const { return win + (p & (LZ4_WIN - 1)); }
+
+    // ring-only reads (caller has established residency)
+    __device__ __forceinline__ uint4 lds128(uint32_t p) const { return lds_ld_u128(at(p)); }
+    __device__ __forceinline__ uint32_t lds32(uint32_t p) const { return lds_ld_u32(at(p)); }
+    __device__ __forceinline__ uint32_t lds8(uint32_t p) const { return lds_ld_u8(at(p)); }
+
+    // per-lane "ring or global" reads; the two loads live in different address spaces and stay separate
+    __device__ __forceinline__ uint64_t rd64(uint32_t p) const
+    {
+        uint64_t v;
+        if (inside(p, 8)) v = lds_ld_u64(at(p)); else v = glb_ld_u64(src + p);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t rd32(uint32_t p) const
+    {
+        uint32_t v;
+        if (inside(p, 4)) v = lds_ld_u32(at(p)); else v = glb_ld_u32(src + p);
+        return v;
+    }
+    __device__ __forceinline__ uint32_t rd8(uint32_t p) const
+    {
+        uint32_t v;
+        if (inside(p, 1)) v = lds_ld_u8(at(p)); else v = glb_ld_u8(src + p);
+        return v;
+    }
+    __device__ __forceinline__ uint4 rd128(uint32_t p) const   // caller guarantees p + 16 <= n
+    {
+        uint4 v;
+        if (inside(p, 16)) v = lds_ld_u128(at(p)); else v = glb_ld_u128(src + p);
+        return v;
+    }
+};
+
+// copy `len` bytes (uniform) of the chunk starting at position `from` to d, any alignment; all 64 lanes call it
+__device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const Lz4Window& w, uint32_t from, uint32_t len, int lane)
 {
     if (len <= 64) {
-        if ((uint32_t)lane < len) d[lane] = s[lane];
+        if ((uint32_t)lane < len) d[lane] = (uint8_t)w.rd8(from + lane);
         return;
     }
     // head: bring d to 16-byte alignment
     const uint32_t head = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15);
-    if ((uint32_t)lane < head) d[lane] = s[lane];
-    d += head; s += head; len -= head;
+    if ((uint32_t)lane < head) d[lane] = (uint8_t)w.rd8(from + lane);
+    d += head; from += head; len -= head;
     const uint32_t nvec = len >> 4;
     for (uint32_t i = lane; i < nvec; i += 64) {
-        *reinterpret_cast<uint4*>(d + (size_t)i * 16) = ld_u128(s + (size_t)i * 16);
+        *reinterpret_cast<uint4*>(d + (size_t)i * 16) = w.rd128(from + i * 16);   // from + 16 i + 16 <= from + len <= n
     }
     const uint32_t done = nvec << 4;
-    if ((uint32_t)lane < len - done) d[done + lane] = s[done + lane];
+    if ((uint32_t)lane < len - done) d[done + lane] = (uint8_t)w.rd8(from + done + lane);
 }
 
-// number of equal leading bytes of a[0..maxlen) and b[0..maxlen), maxlen <= 16; loads stay inside [.., lim)
-__device__ __forceinline__ uint32_t common16(const uint8_t* a, const uint8_t* b, uint32_t maxlen, bool wide_ok)
+// index of the first differing byte of two 16-byte values (16 when equal)
+__device__ __forceinline__ uint32_t first_diff16(uint4 x, uint4 y)
 {
-    if (wide_ok) {
-        const uint4 x = ld_u128(a), y = ld_u128(b);
-        const uint64_t lo = ((uint64_t)(x.y ^ y.y) << 32) | (uint64_t)(x.x ^ y.x);
-        const uint64_t hi = ((uint64_t)(x.w ^ y.w) << 32) | (uint64_t)(x.z ^ y.z);
-        uint32_t n = lo ? (ctz64(lo) >> 3) : (hi ? 8 + (ctz64(hi) >> 3) : 16);
-        return n < maxlen ? n : maxlen;
-    }
-    uint32_t n = 0;
-    while (n < maxlen && a[n] == b[n]) ++n;
-    return n;
+    const uint64_t lo = ((uint64_t)(x.y ^ y.y) << 32) | (uint64_t)(x.x ^ y.x);
+    const uint64_t hi = ((uint64_t)(x.w ^ y.w) << 32) | (uint64_t)(x.z ^ y.z);
+    return lo ? (ctz64(lo) >> 3) : (hi ? 8 + (ctz64(hi) >> 3) : 16);
 }
+
+// number of equal leading bytes of chunk[a..a+maxlen) and chunk[b..b+maxlen), maxlen <= 16, b < a
+__device__ __forceinline__ uint32_t common16(const Lz4Window& w, uint32_t a, uint32_t b, uint32_t maxlen)
+{
+    if (a + 16u <= w.n) {
+        const uint32_t c = first_diff16(w.rd128(a), w.rd128(b));
+        return c < maxlen ? c : maxlen;
+    }
+    uint32_t c = 0;
+    while (c < maxlen && glb_ld_u8(w.src + a + c) == glb_ld_u8(w.src + b + c)) ++c;
+    return c;
+}
+
+// h of the lane `d` lanes below (DPP row_shr, valid inside a row of 16 lanes; lanes < d get ~0)
+template <int D>
+__device__ __forceinline__ uint32_t row_shr(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x110 + D, 0xf, 0xf, false);
+}
+
+// Compressed bytes are staged in LDS and written out in 16-byte pieces when the stage fills: the parse then
+// issues almost no global stores, so the s_waitcnt vmcnt(0) in front of the occasional global LOAD (far
+// candidate, window refill) no longer queues behind a stream of tiny stores on the critical path.
+constexpr uint32_t LZ4_OB = 2048;
+
+struct Lz4Out {
+    SQY_GLB uint8_t* dst;        // chunk's scratch (global)
+    lds_u8* ob;                  // LDS stage
+    uint32_t base;               // dst offset of ob[0]; bytes [base, op) live in the stage
+    int lane;
+
+    // write everything staged; afterwards base == op
+    __device__ __forceinline__ void flush(uint32_t op)
+    {
+        const uint32_t cnt = op - base;
+        const uint32_t nvec = cnt >> 4;
+        for (uint32_t i = lane; i < nvec; i += 64) {
+            const v4u v = *reinterpret_cast<const SQY_LDS v4u*>(ob + i * 16u);
+            SQY_GLB pk_u128* q = reinterpret_cast<SQY_GLB pk_u128*>(dst + base + i * 16u);
+            q->x = v.x; q->y = v.y; q->z = v.z; q->w = v.w;
+        }
+        const uint32_t done = nvec << 4;
+        if ((uint32_t)lane < cnt - done) dst[base + done + lane] = ob[done + lane];
+        base = op;
+    }
+    // room for `len` more staged bytes at op (uniform)
+    __device__ __forceinline__ void reserve(uint32_t op, uint32_t len)
+    {
+        if (op - base + len > LZ4_OB) flush(op);
+    }
+    __device__ __forceinline__ lds_u8* at(uint32_t o) const { return ob + (o - base); }
+};
+
+// SQY_LZ4_DIAG (tools/lz4_diag.hip only): per-phase cycle accounting with s_memtime; never set in the product build
+#ifdef SQY_LZ4_DIAG
+#define SQY_DIAG_ARG , unsigned long long* __restrict__ diag
+#define SQY_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
+                          __builtin_amdgcn_s_waitcnt(0xC07F); dacc[i] += t_ - tprev; tprev = t_; dcnt[i] += 1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define SQY_DIAG_ARG
+#define SQY_STAMP(i) do { } while (0)
+#endif
 
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
-                       uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize)
+                       uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize SQY_DIAG_ARG)
 {
+#ifdef SQY_LZ4_DIAG
+    unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+#endif
     __shared__ uint32_t table[4096];
+    __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
+    __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
     const uint64_t blk = blockIdx.x;
     const uint8_t* __restrict__ src = in + blk * chunk;
@@ -329,6 +504,11 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     const uint32_t n = (uint32_t)(left < chunk ? left : chunk);
     uint8_t* __restrict__ dst = scratch + blk * stride;
 
+    Lz4Window w;
+    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = n; w.whi = 0; w.wlo = 0; w.lane16 = (uint32_t)lane * 16u;
+    w.issue();
+    Lz4Out o;
+    o.dst = (SQY_GLB uint8_t*)dst; o.ob = (lds_u8*)stage; o.base = 0; o.lane = lane;
     {
         uint4* t4 = reinterpret_cast<uint4*>(table);
 #pragma unroll
@@ -344,126 +524,207 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         const uint32_t mflimitPlusOne = n - LZ4_MFLIMIT + 1;
         const uint32_t matchlimit = n - LZ4_LASTLITERALS;
         uint32_t P = 1, U = 1;           // first probe of the block: search from ip = 1 (table[hash(0)] = 0 is a no-op)
+        uint32_t put2 = 0xffffffffu;     // position whose hash has to enter the table before the next batch (ip - 2)
 
         for (;;) {
-            // ---- positions of the 64 probes of this batch ----
-            const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
-            const uint32_t ustar = 64 * (s_first + 1) - 62;          // first unified index with step s_first+1
-            const uint32_t u = U + lane;
-            const uint32_t bump = u > ustar ? u - ustar : 0;          // #earlier lanes already at the larger step
-            const uint32_t pos = P + s_first * lane + bump;
-            const uint32_t adv = (u >= ustar) ? s_first + 1 : s_first;
-            const uint32_t nxt = pos + adv;
-            const bool valid = nxt <= mflimitPlusOne;
-            const uint64_t vmask = ballot(valid);                     // a prefix of the lanes
-            const uint32_t nvalid = (uint32_t)__builtin_popcountll(vmask);
+            SQY_STAMP(7);
+            w.ensure(P);
+            SQY_STAMP(0);
 
-            uint64_t seq = 0;
-            uint32_t h = 0, old = 0, fl = 0;
-            if (valid) {
-                seq = ld_u64(src + pos);
-                h = lz4_hash5(seq);
-                old = table[h];
-                atomicMax(&table[h], 0x80000000u | (uint32_t)(63 - lane));
-                fl = table[h];
-            }
-            const uint32_t seq32 = (uint32_t)seq;
-            const bool hazard = valid && ((63u - (fl & 63u)) != (uint32_t)lane);
-            const uint64_t hz = ballot(hazard);
+            uint32_t f = 64, fcand = 0;      // first matching probe of the batch and its candidate
+            uint32_t ipf = 0;                // its position
+            uint32_t fwl = 0xffffffffu;      // bytes known equal beyond MINMATCH for the winner (0..11 exact), ~0 = unknown
+            uint32_t bkl = 0xffffffffu;      // bytes known equal in front of (ip, match) for the winner (0..3 exact), ~0 = unknown
+            bool batch_done = false;         // fast path handled table commit
+            uint32_t nvalid = 64, next_P = 0;
 
-            // non-hazard lanes: candidate is the pre-batch table entry
-            const bool near = valid && !hazard && (old + LZ4_MAXD >= pos);
-            uint32_t m32 = ~seq32;
-            if (near) m32 = ld_u32(src + old);
-            const uint64_t mm = ballot(near && m32 == seq32);
-
-            uint32_t f = mm ? ctz64(mm) : 64u;
-            uint32_t fcand = 0;
-            if (f < 64) fcand = lane_read(old, f);
-
-            // hazard lanes in front of f, in lane order: candidate = latest earlier probe with the same hash
-            uint64_t hzq = hz & ((f < 64) ? ((1ull << f) - 1ull) : ~0ull);
-            while (hzq) {
-                const uint32_t c = ctz64(hzq);
-                hzq &= hzq - 1;
-                const uint32_t hc = lane_read(h, c);
-                const uint64_t grp = ballot(valid && h == hc) & ((1ull << c) - 1ull);
-                const uint32_t j = 63u - (uint32_t)__builtin_clzll(grp);
-                const uint32_t pj = lane_read(pos, j), pc = lane_read(pos, c);
-                if (pj + LZ4_MAXD >= pc && lane_read(seq32, j) == lane_read(seq32, c)) {
-                    f = c;
-                    fcand = pj;
-                    break;
+            // ---------------------------------------------------------------------------------------
+            // fast path: 64 probes at consecutive positions, everything they touch resident in the ring
+            // ---------------------------------------------------------------------------------------
+            const bool step1 = (U + 64u <= 66u);                                  // all 64 advances are 1
+            const bool interior = step1 && P >= w.wlo + 4u && P + 64u + 16u <= w.hi_valid() && P + 64u <= mflimitPlusOne - 1u &&
+                                  P + 64u + 16u + 12u <= matchlimit;
+            if (interior) {
+                const uint32_t pos = P + (uint32_t)lane;
+                const uint4 s16 = w.lds128(pos);
+                const uint32_t b4 = w.lds32(pos - 4u);
+                if (put2 != 0xffffffffu) {
+                    const uint32_t h2 = lz4_hash5(w.rd64(put2));
+                    if (lane == 0) table[h2] = put2;
+                    put2 = 0xffffffffu;
                 }
+                SQY_STAMP(1);
+                const uint32_t h = lz4_hash5(((uint64_t)s16.y << 32) | s16.x);
+                const uint32_t old = table[h];
+                SQY_STAMP(2);
+                const bool near = (old + LZ4_MAXD >= pos);
+                const bool cin = near && old >= w.wlo + 4u;                        // old + 16 <= pos + 16 <= hi_valid
+                uint32_t fw = 0xffffffffu, bk = 0xffffffffu;
+                bool hit = false;
+                if (cin) {
+                    const uint4 c16 = w.lds128(old);
+                    const uint32_t cb4 = w.lds32(old - 4u);
+                    const uint32_t d = first_diff16(s16, c16);
+                    hit = d >= 4u;
+                    fw = d - 4u;                                                   // 0..12 (12 = all 16 equal: continue wide)
+                    const uint32_t x = b4 ^ cb4;
+                    bk = x ? ((uint32_t)__builtin_clz(x) >> 3) : 4u;               // equal bytes counted backwards, 4 = maybe more
+                } else if (near) {
+                    hit = w.rd32(old) == s16.x;                                    // far candidate: global read, lengths unknown
+                }
+                const uint64_t mm = ballot(hit);
+                const uint32_t f0 = mm ? ctz64(mm) : 64u;
+                bool clean = false;
+                if (f0 == 0) {
+                    clean = true;
+                } else if (f0 <= 4) {
+                    // any probe <= f0 sharing a hash bucket with an earlier probe of this batch?
+                    // DPP reads need their SOURCE lane active: fetch the four neighbours with every lane enabled,
+                    // combine afterwards (a short-circuit && would mask the low lanes off and hide the hazard)
+                    const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
+                    const bool hz = (h == h1) | (h == h2s) | (h == h3) | (h == h4);   // lanes < d read ~0, never a hash
+                    clean = (ballot(hz && (uint32_t)lane <= f0) == 0);
+                } else if (f0 <= 24) {
+                    clean = true;
+                    for (uint32_t c = 1; c <= f0; ++c) {
+                        if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { clean = false; break; }
+                    }
+                }
+                if (clean) {
+                    f = f0;
+                    fcand = lane_read(old, f);
+                    ipf = P + f;
+                    fwl = lane_read(fw, f);
+                    bkl = lane_read(bk, f);
+                    if (fwl >= 12u) fwl = (fwl == 12u) ? 12u : 0xffffffffu;
+                    if ((uint32_t)lane <= f) atomicMax(&table[h], pos);             // commit probes 0..f (positions grow)
+                    batch_done = true;
+                }
+                SQY_STAMP(3);
             }
 
-            // ---- table: restore, then insert the committed prefix (lanes <= f, or every valid lane) ----
-            const uint32_t ncommit = (f < 64) ? f + 1 : nvalid;
-            if (valid) table[h] = old;
-            if ((uint32_t)lane < ncommit) atomicMax(&table[h], pos);
+            // ---------------------------------------------------------------------------------------
+            // generic path: any step schedule, chunk borders, hazards -- exact but slower
+            // ---------------------------------------------------------------------------------------
+            if (!batch_done) {
+                const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
+                const uint32_t ustar = 64 * (s_first + 1) - 62;          // first unified index with step s_first+1
+                const uint32_t u = U + lane;
+                const uint32_t bump = u > ustar ? u - ustar : 0;          // #earlier lanes already at the larger step
+                const uint32_t pos = P + s_first * lane + bump;
+                const uint32_t adv = (u >= ustar) ? s_first + 1 : s_first;
+                const uint32_t nxt = pos + adv;
+                const bool valid = nxt <= mflimitPlusOne;
+                const uint64_t vmask = ballot(valid);                     // a prefix of the lanes
+                nvalid = (uint32_t)__builtin_popcountll(vmask);
+
+                uint64_t seq = 0;
+                if (valid) seq = w.rd64(pos);
+                if (put2 != 0xffffffffu) {
+                    // LZ4_putPosition(ip - 2) of the previous match, fetched together with this batch's sequences
+                    const uint32_t h2 = lz4_hash5(w.rd64(put2));
+                    if (lane == 0) table[h2] = put2;
+                    put2 = 0xffffffffu;
+                }
+                uint32_t h = 0, old = 0, fl = 0;
+                if (valid) {
+                    h = lz4_hash5(seq);
+                    old = table[h];
+                    atomicMax(&table[h], 0x80000000u | (uint32_t)(63 - lane));
+                    fl = table[h];
+                }
+                const uint32_t seq32 = (uint32_t)seq;
+                const bool hazard = valid && ((63u - (fl & 63u)) != (uint32_t)lane);
+                const uint64_t hz = ballot(hazard);
+
+                // non-hazard lanes: candidate is the pre-batch table entry
+                const bool near = valid && !hazard && (old + LZ4_MAXD >= pos);
+                uint32_t m32 = ~seq32;
+                if (near) m32 = w.rd32(old);
+                const uint64_t mm = ballot(near && m32 == seq32);
+
+                f = mm ? ctz64(mm) : 64u;
+                if (f < 64) fcand = lane_read(old, f);
+
+                // hazard lanes in front of f, in lane order: candidate = latest earlier probe with the same hash
+                uint64_t hzq = hz & ((f < 64) ? ((1ull << f) - 1ull) : ~0ull);
+                while (hzq) {
+                    const uint32_t c = ctz64(hzq);
+                    hzq &= hzq - 1;
+                    const uint32_t hc = lane_read(h, c);
+                    const uint64_t grp = ballot(valid && h == hc) & ((1ull << c) - 1ull);
+                    const uint32_t j = 63u - (uint32_t)__builtin_clzll(grp);
+                    const uint32_t pj = lane_read(pos, j), pc = lane_read(pos, c);
+                    if (pj + LZ4_MAXD >= pc && lane_read(seq32, j) == lane_read(seq32, c)) {
+                        f = c;
+                        fcand = pj;
+                        break;
+                    }
+                }
+
+                // table: restore, then insert the committed prefix (lanes <= f, or every valid lane)
+                const uint32_t ncommit = (f < 64) ? f + 1 : nvalid;
+                if (valid) table[h] = old;
+                if ((uint32_t)lane < ncommit) atomicMax(&table[h], pos);
+                if (f < 64) ipf = lane_read(pos, f);
+                next_P = lane_read(nxt, 63);
+                SQY_STAMP(3);
+            } else {
+                next_P = P + 64u;
+            }
 
             if (f >= 64) {
                 if (nvalid < 64) break;                               // forwardIp > mflimitPlusOne -> last literals
-                P = sgpr(lane_read(nxt, 63));
+                P = sgpr(next_P);
                 U += 64;
                 continue;
             }
 
             // ---- a match: ip = pos[f], match = fcand ----
-            uint32_t ip = sgpr(lane_read(pos, f));
-            uint32_t mt = sgpr(fcand);
+            const uint32_t ip0 = sgpr(ipf);
+            const uint32_t mt0 = sgpr(fcand);
+            fwl = sgpr(fwl);
+            bkl = sgpr(bkl);
+            const uint32_t q = ip0 + 4, r = mt0 + 4;
 
-            // backward catch-up: while (ip > anchor && match > 0 && ip[-1] == match[-1])
-            for (;;) {
-                const uint32_t k = lane + 1;
-                bool ok = (ip >= anchor + k) && (mt >= k);
-                if (ok) ok = src[ip - k] == src[mt - k];
-                const uint64_t bad = ~ballot(ok);
-                const uint32_t nb = bad ? ctz64(bad) : 64u;
-                ip -= nb; mt -= nb;
-                if (nb < 64) break;
-            }
-
-            // ---- literals ----
-            const uint32_t lit = ip - anchor;
-            const uint32_t token_pos = op;
-            op += 1;
-            if (op + lit + (2 + 1 + LZ4_LASTLITERALS) + lit / 255 > olimit) { failed = true; break; }
-            if (lit >= 15) {
-                const uint32_t rest = lit - 15;
-                const uint32_t n255 = rest / 255;
-                for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
-                if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
-                op += n255 + 1;
-            }
-            wave_copy(dst + op, src + anchor, lit, lane);
-            op += lit;
-
-            // ---- offset + match length ----
-            const uint32_t offset = ip - mt;
-            if (lane == 0) { dst[op] = (uint8_t)offset; dst[op + 1] = (uint8_t)(offset >> 8); }
-            op += 2;
-
-            uint32_t ml = 0;                                          // bytes matched beyond MINMATCH
-            {
-                const uint32_t q = ip + 4, r = mt + 4;
+            // forward extension: bytes equal beyond MINMATCH (upstream's LZ4_count from ip+4), up to matchlimit
+            uint32_t ml;
+            if (fwl < 12u) {
+                ml = fwl;                                                 // settled by the speculative 16-byte compare
+            } else {
+                ml = (fwl == 12u) ? 12u : 0u;
                 for (;;) {
-                    // 4 x 16 bytes per lane and round = 4 KiB per round; first round only 1 KiB matters most
                     uint32_t got[4];
-                    bool full[4];
+                    // uniform test: both operands of the whole 4 KiB round resident in the ring and clear of matchlimit
+                    const uint32_t qa = q + ml, ra = r + ml;
+                    const bool round_in_lds = ra >= w.wlo && qa + 4096u + 16u <= w.hi_valid() && qa + 4096u + 16u <= matchlimit;
+                    if (round_in_lds) {
 #pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        const uint32_t a = q + ml + (uint32_t)t * 1024u + (uint32_t)lane * 16u;
-                        const uint32_t room = a < matchlimit ? matchlimit - a : 0u;
-                        const uint32_t maxlen = room < 16u ? room : 16u;
-                        got[t] = (maxlen == 0) ? 0u : common16(src + a, src + (a - q + r), maxlen, a + 16u <= n);
-                        full[t] = got[t] == 16u;
+                        for (int t = 0; t < 4; ++t) {
+                            const uint32_t d = (uint32_t)t * 1024u + (uint32_t)lane * 16u;
+                            got[t] = first_diff16(w.lds128(qa + d), w.lds128(ra + d));
+                            if (t == 0) {
+                                // most matches end inside the first KiB: look at it before paying for the other three
+                                if (ballot(got[0] != 16u)) { got[1] = got[2] = got[3] = 0; break; }
+                            }
+                        }
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            const uint32_t a = qa + (uint32_t)t * 1024u + (uint32_t)lane * 16u;
+                            const uint32_t room = a < matchlimit ? matchlimit - a : 0u;
+                            const uint32_t maxlen = room < 16u ? room : 16u;
+                            got[t] = (maxlen == 0) ? 0u : common16(w, a, a - q + r, maxlen);
+                            if (t == 0) {
+                                if (ballot(got[0] != 16u)) { got[1] = got[2] = got[3] = 0; break; }
+                            }
+                        }
                     }
                     bool stop = false;
 #pragma unroll
                     for (int t = 0; t < 4; ++t) {
                         if (!stop) {
-                            const uint64_t nf = ballot(!full[t]);
+                            const uint64_t nf = ballot(got[t] != 16u);
                             if (nf) {
                                 const uint32_t l = ctz64(nf);
                                 ml += l * 16u + lane_read(got[t], l);
@@ -475,32 +736,111 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     }
                     if (stop) break;
                 }
+                ml = sgpr(ml);
             }
-            ml = sgpr(ml);
-            ip += ml + 4;
-            if (op + (1 + LZ4_LASTLITERALS) + (ml + 240) / 255 > olimit) { failed = true; break; }
-            if (ml >= 15) {
-                const uint32_t rest = ml - 15;
-                const uint32_t n255 = rest / 255;
-                for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
-                if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
-                op += n255 + 1;
-            }
-            if (lane == 0) dst[token_pos] = (uint8_t)(((lit < 15 ? lit : 15u) << 4) | (ml < 15 ? ml : 15u));
-            anchor = ip;
-            if (ip >= mflimitPlusOne) break;
 
-            // LZ4_putPosition(ip - 2), then the unified batch starts with the "test next position" probe at ip
+            // backward catch-up: while (ip > anchor && match > 0 && ip[-1] == match[-1])
+            uint32_t back;
             {
-                const uint32_t h2 = lz4_hash5(ld_u64(src + ip - 2));
-                if (lane == 0) table[h2] = ip - 2;
+                const uint32_t lim_a = ip0 - anchor, lim_m = mt0;
+                const uint32_t lim = lim_a < lim_m ? lim_a : lim_m;
+                if (bkl < 4u || lim <= bkl) {
+                    back = bkl < lim ? bkl : lim;                          // settled by the speculative 4-byte compare
+                    if (bkl == 0xffffffffu) back = 0xffffffffu;
+                } else {
+                    back = 0xffffffffu;
+                }
+                if (back == 0xffffffffu) {
+                    uint32_t ip = ip0, mt = mt0;
+                    for (;;) {
+                        const uint32_t k = lane + 1;
+                        bool ok = (ip >= anchor + k) && (mt >= k);
+                        if (mt >= w.wlo + 64u && ip <= w.hi_valid()) {                   // uniform: both sides resident
+                            if (ok) ok = w.lds8(ip - k) == w.lds8(mt - k);
+                        } else {
+                            if (ok) ok = w.rd8(ip - k) == w.rd8(mt - k);
+                        }
+                        const uint64_t bad = ~ballot(ok);
+                        const uint32_t nb = bad ? ctz64(bad) : 64u;
+                        ip -= nb; mt -= nb;
+                        if (nb < 64) break;
+                    }
+                    back = ip0 - ip;
+                }
             }
-            P = ip;
+            SQY_STAMP(4);
+
+            const uint32_t ip = ip0 - back;                           // start of the match after catch-up
+            const uint32_t lit = ip - anchor;
+            const uint32_t matchCode = ml + back;                     // match length - MINMATCH as upstream counts it
+            const uint32_t offset = ip0 - mt0;
+
+            // upstream's two output-limit checks (token + literals, then offset + match length)
+            if (op + 1 + lit + (2 + 1 + LZ4_LASTLITERALS) + lit / 255 > olimit) { failed = true; break; }
+            const uint32_t lit_ext = lit >= 15 ? (lit - 15) / 255 + 1 : 0;
+            const uint32_t ml_ext = matchCode >= 15 ? (matchCode - 15) / 255 + 1 : 0;
+            if (op + 1 + lit_ext + lit + 2 + (1 + LZ4_LASTLITERALS) + (matchCode + 240) / 255 > olimit) { failed = true; break; }
+            const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (matchCode < 15 ? matchCode : 15u);
+            const uint32_t seq_bytes = 1 + lit_ext + lit + 2 + ml_ext;
+
+            if (seq_bytes <= 64 && lit < 15) {
+                // whole sequence at once into the LDS stage: lane k writes byte k
+                o.reserve(op, seq_bytes);
+                const uint32_t k = (uint32_t)lane;
+                uint32_t v = token;
+                if (k >= 1 && k <= lit) {
+                    if (anchor >= w.wlo && ip0 <= w.hi_valid()) v = w.lds8(anchor + k - 1);   // uniform: literals resident
+                    else v = w.rd8(anchor + k - 1);
+                }
+                else if (k == lit + 1) v = offset & 0xffu;
+                else if (k == lit + 2) v = offset >> 8;
+                else if (k > lit + 2) {
+                    const uint32_t j = k - (lit + 3);
+                    v = (j + 1 < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1) * 255u);
+                }
+                if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
+                op += seq_bytes;
+            } else {
+                o.flush(op);
+                if (lane == 0) dst[op] = (uint8_t)token;
+                op += 1;
+                if (lit >= 15) {
+                    const uint32_t rest = lit - 15;
+                    const uint32_t n255 = rest / 255;
+                    for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
+                    if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
+                    op += n255 + 1;
+                }
+                wave_copy(dst + op, w, anchor, lit, lane);
+                op += lit;
+                if (lane == 0) { dst[op] = (uint8_t)offset; dst[op + 1] = (uint8_t)(offset >> 8); }
+                op += 2;
+                if (matchCode >= 15) {
+                    const uint32_t rest = matchCode - 15;
+                    const uint32_t n255 = rest / 255;
+                    for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
+                    if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
+                    op += n255 + 1;
+                }
+                o.base = op;
+            }
+            SQY_STAMP(5);
+
+            const uint32_t ipn = q + ml;                              // = original ip + 4 + forward count
+            anchor = ipn;
+            SQY_STAMP(6);
+            if (ipn >= mflimitPlusOne) break;
+
+            // LZ4_putPosition(ip - 2) happens at the top of the next batch; the unified batch then starts with
+            // the "test next position" probe at ip
+            put2 = ipn - 2;
+            P = ipn;
             U = 0;
         }
     }
 
     if (!failed) {
+        o.flush(op);
         const uint32_t lastRun = n - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
             failed = true;
@@ -516,11 +856,14 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 if (lane == 0) dst[op] = (uint8_t)(lastRun << 4);
                 op += 1;
             }
-            wave_copy(dst + op, src + anchor, lastRun, lane);
+            wave_copy(dst + op, w, anchor, lastRun, lane);
             op += lastRun;
         }
     }
     if (lane == 0) csize[blk] = failed ? 0u : op;
+#ifdef SQY_LZ4_DIAG
+    if (lane == 0) for (int i = 0; i < 8; ++i) { diag[blk * 16 + i] = dacc[i]; diag[blk * 16 + 8 + i] = dcnt[i]; }
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -692,7 +1035,12 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream)
 {
     if (nchunks == 0) return hipSuccess;
+#ifdef SQY_LZ4_DIAG
+    hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+                       (unsigned long long*)nullptr);
+#else
     hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize);
+#endif
     return hipGetLastError();
 }
 
