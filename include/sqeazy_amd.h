@@ -98,6 +98,13 @@ SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, 
 SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, const long* shape,
                                                          unsigned shape_size, void* d_dst, long dst_capacity,
                                                          long* dstlength, int nthreads, void* hip_stream);
+/* host-pointer encode with an explicit destination capacity (returns 1 instead of overflowing dst; the
+ * reference-protocol entry points above assume dst holds exactly SQY_Pipeline_Max_Compressed_Length_* bytes) */
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size,
+                                                       char* dst, long dst_capacity, long* dstlength, int nthreads);
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size,
+                                                      char* dst, long dst_capacity, long* dstlength, int nthreads);
+
 SQY_FUNCTION_PREFIX int SQYAMD_Decode_UI16_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream);
 SQY_FUNCTION_PREFIX int SQYAMD_Decode_UI8_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream);
 

@@ -24,6 +24,7 @@ EXPORTED_SYMBOLS = (
     "SQY_Pipeline_Possible_UI16", "SQY_Pipeline_Possible_UI8", "SQY_Pipeline_Possible",
     "SQY_Decompressed_Length", "SQY_Decode_UI16", "SQY_Decode_UI8",
     "SQYAMD_PipelineEncode_UI16_Device", "SQYAMD_PipelineEncode_UI8_Device",
+    "SQYAMD_PipelineEncode_UI16_Cap", "SQYAMD_PipelineEncode_UI8_Cap",
     "SQYAMD_Decode_UI16_Device", "SQYAMD_Decode_UI8_Device",
     "SQYAMD_Profile_Enable", "SQYAMD_Profile_Reset", "SQYAMD_Profile_Get",
     "SQYAMD_Release_Workspace", "SQYAMD_Version",
@@ -62,6 +63,9 @@ def lib():
         for f in ("SQYAMD_PipelineEncode_UI8_Device", "SQYAMD_PipelineEncode_UI16_Device"):
             getattr(L, f).argtypes = [ctypes.c_char_p, ctypes.c_void_p, c_long_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_long,
                                       c_long_p, ctypes.c_int, ctypes.c_void_p]
+        for f in ("SQYAMD_PipelineEncode_UI8_Cap", "SQYAMD_PipelineEncode_UI16_Cap"):
+            getattr(L, f).argtypes = [ctypes.c_char_p, ctypes.c_void_p, c_long_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_long, c_long_p,
+                                      ctypes.c_int]
         for f in ("SQY_Decode_UI8", "SQY_Decode_UI16"):
             getattr(L, f).argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_int]
         for f in ("SQYAMD_Decode_UI8_Device", "SQYAMD_Decode_UI16_Device"):
@@ -113,18 +117,28 @@ def max_compressed_length_bytes(pipeline, nbytes, dtype=np.uint16):
     return length.value
 
 
-def encode(pipeline, volume, nthreads=0):
-    """SQY_PipelineEncode_UI8/UI16 on a host ndarray ({z,y,x}); returns (return code, blob bytes or None)."""
+def encode(pipeline, volume, nthreads=0, extra_capacity=None):
+    """SQY_PipelineEncode_UI8/UI16 on a host ndarray ({z,y,x}); returns (return code, blob bytes or None).
+
+    With extra_capacity=None this is the reference protocol: dst holds exactly SQY_Pipeline_Max_Compressed_Length_3D
+    bytes.  With a number, dst is that much larger and the explicit-capacity entry point is used."""
     vol = np.ascontiguousarray(volume)
     sfx = _suffix(vol.dtype)
     if not pipeline_possible(pipeline, vol.dtype):
         cap = 64
     else:
         cap = max(max_compressed_length(pipeline, vol.shape, vol.dtype), 64)
-    dst = np.empty(cap, dtype=np.uint8)
     dlen = ctypes.c_long(0)
-    rc = getattr(lib(), "SQY_PipelineEncode_" + sfx)(pipeline.encode(), vol.ctypes.data, _longs(vol.shape), ctypes.c_uint(vol.ndim),
-                                                    dst.ctypes.data, ctypes.byref(dlen), ctypes.c_int(nthreads))
+    if extra_capacity is None:
+        dst = np.empty(cap, dtype=np.uint8)
+        rc = getattr(lib(), "SQY_PipelineEncode_" + sfx)(pipeline.encode(), vol.ctypes.data, _longs(vol.shape), ctypes.c_uint(vol.ndim),
+                                                        dst.ctypes.data, ctypes.byref(dlen), ctypes.c_int(nthreads))
+    else:
+        cap += int(extra_capacity)
+        dst = np.empty(cap, dtype=np.uint8)
+        rc = getattr(lib(), "SQYAMD_PipelineEncode_%s_Cap" % sfx)(pipeline.encode(), vol.ctypes.data, _longs(vol.shape),
+                                                                 ctypes.c_uint(vol.ndim), dst.ctypes.data, ctypes.c_long(cap),
+                                                                 ctypes.byref(dlen), ctypes.c_int(nthreads))
     if rc:
         return rc, None
     return 0, dst[:dlen.value].tobytes()

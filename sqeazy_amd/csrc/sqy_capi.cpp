@@ -223,6 +223,65 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 cur = out;
                 break;
             }
+            case StageKind::frame_shuffle: {
+                if (dims.size() != 3) {
+                    std::fprintf(stderr, "[sqeazy::detail::frame_shuffle::encode] received non-3D shape which is currently unsupported!\n");
+                    return 1;
+                }
+                const uint64_t Z = dims[0], per_frame = dims[1] * dims[2];
+                if (ws->small.ensure(std::max<uint64_t>(Z * 16, 4096))) return 1;
+                float* d_sums = static_cast<float*>(ws->small.p);
+                uint64_t* d_map = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(ws->small.p) + ((Z * 4 + 15) & ~(uint64_t)15));
+                {
+                    ProfScope ps("frame_metric", stream);
+                    SQY_HIP(sqy::launch_frame_metric(cur, Z, per_frame, cur_elem, d_sums, stream));
+                }
+                std::vector<float> sums(Z);
+                std::vector<uint64_t> map(Z);
+                SQY_HIP(hipMemcpyAsync(sums.data(), d_sums, Z * sizeof(float), hipMemcpyDeviceToHost, stream));
+                SQY_HIP(hipStreamSynchronize(stream));
+                sqy::frame_shuffle_order(sums.data(), Z, per_frame, map.data());
+                SQY_HIP(hipMemcpyAsync(d_map, map.data(), Z * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                {
+                    ProfScope ps("frame_gather", stream);
+                    SQY_HIP(sqy::launch_frame_gather(cur, out, Z, per_frame * (uint64_t)cur_elem, d_map, stream));
+                }
+                SQY_HIP(hipStreamSynchronize(stream));                     // `map` (host) is read by the async copy above
+                st.cfg["frame_chunk_size"] = "1";
+                st.cfg["reorder_map"] = sqy::to_verbatim(map.data(), Z * sizeof(uint64_t));   // frame_shuffle_scheme_impl.hpp:86-90
+                cur = out;
+                break;
+            }
+            case StageKind::quantiser: {
+                // quantiser_scheme<uint16_t,char>::encode (quantiser_scheme_impl.hpp:176-226)
+                if (ws->small.ensure(65536 * sizeof(uint32_t) + 65536)) return 1;
+                uint32_t* d_histo = static_cast<uint32_t*>(ws->small.p);
+                uint8_t* d_lut = static_cast<uint8_t*>(ws->small.p) + 65536 * sizeof(uint32_t);
+                {
+                    ProfScope ps("histogram_u16", stream);
+                    SQY_HIP(sqy::launch_histogram_u16(reinterpret_cast<const uint16_t*>(cur), cur_len, d_histo, stream));
+                }
+                std::vector<uint32_t> histo(65536);
+                std::vector<unsigned char> lut_encode(65536);
+                uint16_t lut_decode[256];
+                SQY_HIP(hipMemcpyAsync(histo.data(), d_histo, 65536 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                SQY_HIP(hipStreamSynchronize(stream));
+                sqy::quantiser_build_luts(histo.data(), 65536, lut_encode.data(), lut_decode);
+                SQY_HIP(hipMemcpyAsync(d_lut, lut_encode.data(), 65536, hipMemcpyHostToDevice, stream));
+                uint8_t* out = next_buf(cur_len);
+                if (!out) return 1;
+                {
+                    ProfScope ps("quantiser_apply", stream);
+                    SQY_HIP(sqy::launch_quantiser_apply_u16(reinterpret_cast<const uint16_t*>(cur), out, cur_len, d_lut, stream));
+                }
+                SQY_HIP(hipStreamSynchronize(stream));                     // lut_encode (host) is read by the async copy above
+                st.cfg["decode_lut_string"] = sqy::to_verbatim(lut_decode, sizeof(lut_decode));
+                cur = out;
+                cur_elem = 1;                                              // sink output is `char`
+                break;
+            }
             case StageKind::lz4: {
                 lz4p = &st.lz4;
                 lz4_total = cur_len * (uint64_t)cur_elem;
@@ -314,8 +373,9 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
     return 0;
 }
 
+// dst_capacity < 0: the caller followed the reference protocol and allocated SQY_Pipeline_Max_Compressed_Length bytes
 int encode_from_host(const char* pipeline, const char* src, long* shape, unsigned rank, int elem_size, char* dst,
-                     long* dstlength, int nthreads)
+                     long* dstlength, int nthreads, long dst_capacity = -1)
 {
     if (!pipeline || !src || !shape || !dst || !dstlength) return 1;
     {
@@ -342,8 +402,12 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
     const uint64_t raw = len * (uint64_t)elem_size;
     Pipeline pipe = Pipeline::from_string(pipeline);
     pipe.set_n_threads(nthreads);
-    const uint64_t bound = pipe.max_encoded_size(raw, elem_size);
-    if (ws->io_src.ensure(std::max<uint64_t>(raw, 16)) || ws->io_dst.ensure(bound)) return 1;
+    // What the caller was told to allocate: SQY_Pipeline_Max_Compressed_Length_* evaluates the bound on a fresh
+    // pipeline (n_threads = 1, sqeazy.cpp:144-231).  The reference itself writes past that for pipelines whose
+    // header grows while encoding (frame_shuffle's reorder_map on stacks of many small frames); here the
+    // documented "error 1 - destination buffer is not large enough" (inc/sqeazy.h:105) is returned instead.
+    const uint64_t bound = dst_capacity >= 0 ? (uint64_t)dst_capacity : Pipeline::from_string(pipeline).max_encoded_size(raw, elem_size);
+    if (ws->io_src.ensure(std::max<uint64_t>(raw, 16)) || ws->io_dst.ensure(std::max<uint64_t>(bound, 16))) return 1;
     SQY_HIP(hipMemcpy(ws->io_src.p, src, raw, hipMemcpyHostToDevice));
     long out_len = 0;
     const int rc = encode_on_device(pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, nullptr);
@@ -501,6 +565,18 @@ int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, co
     std::lock_guard<std::mutex> lock(g_mu);
     return encode_on_device(pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream));
+}
+
+int SQYAMD_PipelineEncode_UI16_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst,
+                                   long dst_capacity, long* dstlength, int nthreads)
+{
+    return encode_from_host(pipeline, src, shape, shape_size, 2, dst, dstlength, nthreads, std::max(dst_capacity, 0l));
+}
+
+int SQYAMD_PipelineEncode_UI8_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst,
+                                  long dst_capacity, long* dstlength, int nthreads)
+{
+    return encode_from_host(pipeline, src, shape, shape_size, 1, dst, dstlength, nthreads, std::max(dst_capacity, 0l));
 }
 
 int SQYAMD_Decode_UI16_Device(const void*, long, void*, long, void*)

@@ -26,5 +26,13 @@ hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t c
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
                                    uint32_t hc_byte, uint64_t nchunks, hipStream_t stream);
 
+// quantiser: 65536-bin histogram of u16 voxels (histo is zeroed by the launcher), and out[i] = lut[in[i]]
+hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);
+hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t len, const uint8_t* lut, hipStream_t stream);
+
+// frame_shuffle: per-frame mean in the reference's sequential binary32 order; frame gather out[i] = in[map[i]]
+hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream);
+hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
+
 } // namespace sqy
 #endif

@@ -959,6 +959,153 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
 }
 
 // ------------------------------------------------------------------------------------------------
+// quantiser (encoders/quantiser_scheme_impl.hpp:176-226): 65536-bin histogram, then LUT apply.
+//
+// Histogram: every workgroup keeps a private 16384-bin window of the value range in LDS (64 KiB) and
+// counts there with LDS atomics; microscopy stacks concentrate in a narrow band, so nearly every voxel
+// lands in the window.  Values outside go to the global histogram directly.  The window a workgroup uses
+// is voted from the first voxels it sees (quarter of the range with the most hits).
+// ------------------------------------------------------------------------------------------------
+constexpr int HIST_WIN_BINS = 16384;
+
+__global__ __launch_bounds__(256)
+void histogram_u16_kernel(const uint16_t* __restrict__ in, uint64_t len, uint32_t* __restrict__ histo /* 65536, zeroed */)
+{
+    extern __shared__ uint32_t hwin[];      // HIST_WIN_BINS counters
+    __shared__ uint32_t votes[4];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < HIST_WIN_BINS; i += 256) hwin[i] = 0;
+    if (tid < 4) votes[tid] = 0;
+    __syncthreads();
+
+    const uint64_t nvec = len / 8;                                   // 8 voxels per 16-byte load
+    const uint64_t per_block = (nvec + gridDim.x - 1) / gridDim.x;
+    const uint64_t v0 = (uint64_t)blockIdx.x * per_block;
+    const uint64_t v1 = (v0 + per_block < nvec) ? v0 + per_block : nvec;
+    const uint4* src = reinterpret_cast<const uint4*>(in);
+
+    if (v0 + tid < v1) {
+        const uint4 x = src[v0 + tid];
+        atomicAdd(&votes[(x.x & 0xffffu) >> 14], 1u);
+    }
+    __syncthreads();
+    uint32_t best = 0;
+#pragma unroll
+    for (uint32_t q = 1; q < 4; ++q) if (votes[q] > votes[best]) best = q;
+    const uint32_t wbase = best * HIST_WIN_BINS;
+
+    for (uint64_t v = v0 + tid; v < v1; v += 256) {
+        const uint4 x = src[v];
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t a = w[j] & 0xffffu, b = w[j] >> 16;
+            const uint32_t ra = a - wbase, rb = b - wbase;
+            if (ra < (uint32_t)HIST_WIN_BINS) atomicAdd(&hwin[ra], 1u); else atomicAdd(&histo[a], 1u);
+            if (rb < (uint32_t)HIST_WIN_BINS) atomicAdd(&hwin[rb], 1u); else atomicAdd(&histo[b], 1u);
+        }
+    }
+    // tail voxels (len % 8) by the last block
+    if (blockIdx.x == gridDim.x - 1) {
+        for (uint64_t i = nvec * 8 + tid; i < len; i += 256) atomicAdd(&histo[in[i]], 1u);
+    }
+    __syncthreads();
+    for (int i = tid; i < HIST_WIN_BINS; i += 256) {
+        const uint32_t c = hwin[i];
+        if (c) atomicAdd(&histo[wbase + i], c);
+    }
+}
+
+// out[i] = lut[in[i]] with the 64 KiB encode LUT staged in LDS (quantiser_utils.hpp:26-42)
+__global__ __launch_bounds__(256)
+void quantiser_apply_u16_kernel(const uint16_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t len,
+                                const uint8_t* __restrict__ lut /* 65536 */)
+{
+    extern __shared__ uint8_t slut[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 65536 / 16; i += 256)
+        reinterpret_cast<uint4*>(slut)[i] = reinterpret_cast<const uint4*>(lut)[i];
+    __syncthreads();
+    const uint64_t nvec = len / 8;
+    const uint4* src = reinterpret_cast<const uint4*>(in);
+    uint2* dst = reinterpret_cast<uint2*>(out);
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + tid; v < nvec; v += (uint64_t)gridDim.x * 256) {
+        const uint4 x = src[v];
+        uint2 y;
+        y.x = (uint32_t)slut[x.x & 0xffffu] | ((uint32_t)slut[x.x >> 16] << 8) | ((uint32_t)slut[x.y & 0xffffu] << 16) |
+              ((uint32_t)slut[x.y >> 16] << 24);
+        y.y = (uint32_t)slut[x.z & 0xffffu] | ((uint32_t)slut[x.z >> 16] << 8) | ((uint32_t)slut[x.w & 0xffffu] << 16) |
+              ((uint32_t)slut[x.w >> 16] << 24);
+        dst[v] = y;
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t i = nvec * 8 + tid; i < len; i += 256) out[i] = slut[in[i]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// frame_shuffle (encoders/frame_shuffle_utils.hpp:91-172).
+// metric[z] = (float sum of frame z accumulated SEQUENTIALLY in binary32) / (Y*X): the additions round once
+// the sum passes 2^24, so the order is part of the result -- one lane walks one frame in index order.
+// Lanes of a wave own 64 consecutive frames and read 16 bytes at a time (the 128-byte line is reused by the
+// lane's next 7 loads).  The permuted copy is a plain frame gather.
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(64)
+void frame_metric_kernel(const T* __restrict__ in, uint64_t Z, uint64_t per_frame, float* __restrict__ metric)
+{
+    const uint64_t z = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (z >= Z) return;
+    const T* p = in + z * per_frame;
+    float sum = 0.f;
+    uint64_t i = 0;
+    const uint32_t per_vec = 16 / sizeof(T);
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const uint4* pv = reinterpret_cast<const uint4*>(p);
+        const uint64_t nv = per_frame / per_vec;
+        for (uint64_t v = 0; v < nv; ++v) {
+            const uint4 x = pv[v];
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (sizeof(T) == 2) {
+                    sum = sum + (float)(w[j] & 0xffffu);
+                    sum = sum + (float)(w[j] >> 16);
+                } else {
+                    sum = sum + (float)(w[j] & 0xffu);
+                    sum = sum + (float)((w[j] >> 8) & 0xffu);
+                    sum = sum + (float)((w[j] >> 16) & 0xffu);
+                    sum = sum + (float)(w[j] >> 24);
+                }
+            }
+        }
+        i = nv * per_vec;
+    }
+    for (; i < per_frame; ++i) sum = sum + (float)p[i];
+    metric[z] = sum;                           // the division by Y*X happens on the host (sqy::frame_shuffle_order)
+}
+
+// out frame i = in frame map[i]
+__global__ __launch_bounds__(256)
+void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t frame_bytes,
+                         const uint64_t* __restrict__ map, uint32_t blocks_per_frame)
+{
+    const uint64_t f = blockIdx.x / blocks_per_frame;
+    const uint32_t part = blockIdx.x % blocks_per_frame;
+    const uint8_t* s = in + map[f] * frame_bytes;
+    uint8_t* d = out + f * frame_bytes;
+    const uint64_t nvec = frame_bytes / 16;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < nvec; v += (uint64_t)blocks_per_frame * 256)
+            reinterpret_cast<uint4*>(d)[v] = reinterpret_cast<const uint4*>(s)[v];
+        if (part == 0)
+            for (uint64_t i = nvec * 16 + threadIdx.x; i < frame_bytes; i += 256) d[i] = s[i];
+    } else {
+        for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < frame_bytes; i += (uint64_t)blocks_per_frame * 256) d[i] = s[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int num_cus()
@@ -1059,6 +1206,51 @@ hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t c
     const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;
     hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(nchunks * slices)), dim3(256), 0, stream, in, total, chunk,
                        scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices);
+    return hipGetLastError();
+}
+
+hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream)
+{
+    hipError_t e = hipMemsetAsync(histo, 0, 65536 * sizeof(uint32_t), stream);
+    if (e != hipSuccess || len == 0) return e;
+    uint64_t blocks = (len / 8 + 256 * 64 - 1) / (256 * 64);        // >= 64 loads per thread
+    const uint64_t cap = (uint64_t)num_cus() * 2;                    // 64 KiB of LDS per workgroup: 2 resident per CU
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(histogram_u16_kernel, dim3((unsigned)blocks), dim3(256), HIST_WIN_BINS * sizeof(uint32_t), stream, in, len, histo);
+    return hipGetLastError();
+}
+
+hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t len, const uint8_t* lut, hipStream_t stream)
+{
+    if (len == 0) return hipSuccess;
+    uint64_t blocks = (len / 8 + 256 * 16 - 1) / (256 * 16);
+    const uint64_t cap = (uint64_t)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(quantiser_apply_u16_kernel, dim3((unsigned)blocks), dim3(256), 65536, stream, in, out, len, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream)
+{
+    if (Z == 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((Z + 63) / 64);
+    if (elem_size == 2)
+        hipLaunchKernelGGL((frame_metric_kernel<uint16_t>), dim3(blocks), dim3(64), 0, stream, (const uint16_t*)in, Z, per_frame, metric);
+    else
+        hipLaunchKernelGGL((frame_metric_kernel<uint8_t>), dim3(blocks), dim3(64), 0, stream, (const uint8_t*)in, Z, per_frame, metric);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream)
+{
+    if (Z == 0 || frame_bytes == 0) return hipSuccess;
+    uint64_t bpf = (frame_bytes / 16 + 256 * 8 - 1) / (256 * 8);
+    if (bpf == 0) bpf = 1;
+    if (bpf > 64) bpf = 64;
+    hipLaunchKernelGGL(frame_gather_kernel, dim3((unsigned)(Z * bpf)), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, frame_bytes,
+                       map, (uint32_t)bpf);
     return hipGetLastError();
 }
 

@@ -459,6 +459,76 @@ HeaderInfo header_unpack(const char* begin, const char* end)
     return h;
 }
 
+// ---- quantiser LUT construction (host, float) ----
+void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode)
+{
+    const size_t max_compressed = 256;                                     // quantiser<raw, char>::max_compressed_
+    std::vector<float> importance(nbins);
+    std::memset(lut_encode, 0, nbins);
+    for (size_t i = 0; i < max_compressed; ++i) lut_decode[i] = 0;
+    // computeImportance: importance = histo * weight, weights all 1.f (weighters::none)
+    for (size_t i = 0; i < nbins; ++i) importance[i] = histo[i] * 1.f;
+    // std::accumulate(importance.begin(), importance.end(), 0.) -> double accumulator, assigned to float
+    double total = 0.;
+    for (size_t i = 0; i < nbins; ++i) total = total + importance[i];
+    const float importanceSum = (float)total;
+    if (!(importanceSum != 0)) return;
+    uint32_t n_levels = 0;
+    for (size_t i = 0; i < nbins; ++i) if (importance[i] != 0.f) ++n_levels;
+
+    if (n_levels <= max_compressed) {
+        // linear_mapping_quantisation
+        uint32_t comp_idx = 0;
+        for (uint32_t raw_idx = 0; raw_idx < nbins && comp_idx < max_compressed; ++raw_idx) {
+            lut_encode[raw_idx] = (unsigned char)comp_idx;
+            lut_decode[comp_idx] = (uint16_t)raw_idx;
+            if (importance[raw_idx]) comp_idx++;
+        }
+        const uint16_t raw_max = nbins == 65536 ? 65535 : 255;
+        if (comp_idx < max_compressed && comp_idx > 0 && lut_decode[comp_idx] == raw_max)
+            for (size_t i = comp_idx; i < max_compressed; ++i) lut_decode[i] = lut_decode[comp_idx - 1];
+        return;
+    }
+    // adaptive_lloyd_com
+    size_t levels_available = max_compressed;
+    float bucketSize = importanceSum / levels_available;
+    float importanceIntegral = importance[0];
+    float quantile_sum = importance[0];
+    uint32_t comp_idx = 0;
+    float weighted_mean_importance_in_bucket = 0 * importance[0];
+    float index_weighted_mean_importance = 0;
+    for (uint32_t raw_idx = 1; raw_idx < nbins; ++raw_idx) {
+        if (quantile_sum >= bucketSize && (comp_idx < max_compressed - 1)) {
+            lut_decode[comp_idx] = static_cast<uint16_t>(index_weighted_mean_importance);
+            comp_idx++;
+            levels_available--;
+            quantile_sum = importance[raw_idx];
+            weighted_mean_importance_in_bucket = raw_idx * importance[raw_idx];
+            if (importanceIntegral < importanceSum) bucketSize = (importanceSum - importanceIntegral) / levels_available;
+            if (quantile_sum != 0.) index_weighted_mean_importance = std::round(weighted_mean_importance_in_bucket / quantile_sum);
+        } else {
+            quantile_sum += importance[raw_idx];
+            weighted_mean_importance_in_bucket += raw_idx * importance[raw_idx];
+            if (quantile_sum != 0.) index_weighted_mean_importance = std::round(weighted_mean_importance_in_bucket / quantile_sum);
+        }
+        lut_encode[raw_idx] = static_cast<unsigned char>(comp_idx);
+        importanceIntegral += importance[raw_idx];
+    }
+    lut_decode[comp_idx] = static_cast<uint16_t>(index_weighted_mean_importance);
+}
+
+void frame_shuffle_order(const float* sums, size_t Z, size_t per_frame, uint64_t* decode_map)
+{
+    std::vector<float> metric(Z);
+    for (size_t z = 0; z < Z; ++z) metric[z] = sums[z] / per_frame;          // float / size_t
+    std::vector<float> sorted_metric = metric;
+    std::sort(sorted_metric.begin(), sorted_metric.end());
+    for (size_t i = 0; i < Z; ++i) {
+        const auto it = std::find(metric.begin(), metric.end(), sorted_metric[i]);
+        decode_map[i] = (uint64_t)std::distance(metric.begin(), it);
+    }
+}
+
 // ---- base64 (base64.hpp:135-162: standard alphabet, '=' padded) ----
 std::string base64_encode(const unsigned char* src, size_t n)
 {

@@ -86,6 +86,14 @@ struct HeaderInfo {
 };
 HeaderInfo header_unpack(const char* begin, const char* end);
 
+// quantiser LUTs from a 65536-bin histogram, weighting "none" (encoders/quantiser_utils.hpp:386-418, :227-306):
+// lut_encode[65536] bytes, lut_decode[256] raw values.  IEEE binary32/64 in the reference's statement order.
+void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode);
+
+// frame_shuffle ordering from the per-frame float sums (encoders/frame_shuffle_utils.hpp:126-166):
+// metric = sum / per_frame, sorted ascending, slot i <- first frame whose metric equals sorted[i]
+void frame_shuffle_order(const float* sums, size_t Z, size_t per_frame, uint64_t* decode_map);
+
 std::string base64_encode(const unsigned char* src, size_t n);
 std::vector<unsigned char> base64_decode(const std::string& s);
 std::string to_verbatim(const void* data, size_t bytes);

@@ -69,3 +69,65 @@ def test_diff_bitswap_lz4_u16(sqy, oracle):
         rc, blob = sqy.encode("diff3x3x1->bitswap1->lz4", vol, nthreads=2)
         assert rc == 0
         assert blob == oracle.pipeline_encode("diff3x3x1->bitswap1->lz4", vol), shape
+
+
+def _cases_u8():
+    rng = np.random.default_rng(9)
+    yield "synth_u8", synth.stack((48, 64, 96), np.uint8)
+    yield "random_u8", rng.integers(0, 256, (16, 128, 128), dtype=np.uint8)
+    yield "ragged_u8", rng.integers(0, 40, (5, 7, 9), dtype=np.uint8)            # len % 8 != 0
+    yield "zeros_u8", np.zeros((4, 512, 512), np.uint8)
+
+
+@pytest.mark.parametrize("pipeline", ["bitswap1->lz4", "bitswap1", "lz4"])
+@pytest.mark.parametrize("name,vol", list(_cases_u8()), ids=[c[0] for c in _cases_u8()])
+def test_u8_pipelines(sqy, oracle, pipeline, name, vol):
+    rc, blob = sqy.encode(pipeline, vol, nthreads=2)
+    assert rc == 0
+    assert blob == oracle.pipeline_encode(pipeline, vol)
+
+
+def test_diff_u8_small(sqy, oracle):
+    vol = synth.stack((20, 30, 40), np.uint8)
+    rc, blob = sqy.encode("diff3x3x1->lz4", vol, nthreads=2)
+    assert rc == 0
+    assert blob == oracle.pipeline_encode("diff3x3x1->lz4", vol)
+    # extents > 127 overflow the reference's char coordinates: refused
+    rc, blob = sqy.encode("diff3x3x1->lz4", synth.stack((4, 200, 8), np.uint8), nthreads=2)
+    assert rc == 1
+
+
+@pytest.mark.parametrize("pipeline", ["frame_shuffle->lz4", "frame_shuffle", "frame_shuffle->bitswap1->lz4"])
+def test_frame_shuffle(sqy, oracle, pipeline):
+    vols = [synth.stack((64, 96, 128), np.uint8), synth.stack((40, 64, 64), np.uint16)]
+    # frames with equal metrics (std::find maps them to the same source frame) and a >2^24 sum (rounding order matters)
+    v = synth.stack((12, 512, 1024), np.uint8)
+    v[5] = v[2]
+    v[7] = v[2]
+    vols.append(v)
+    vols.append(np.full((6, 4200, 4096), 3, np.uint8))
+    for vol in vols:
+        # the reorder_map grows the header beyond what SQY_Pipeline_Max_Compressed_Length promises for stacks of many
+        # small frames (the reference overflows there): give the explicit-capacity entry point room for it
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2, extra_capacity=16 * vol.shape[0] + 256)
+        assert rc == 0
+        want = oracle.pipeline_encode(pipeline, vol)
+        assert blob == want, (pipeline, vol.shape, vol.dtype)
+    # reference protocol on a stack of many tiny frames: refused (error 1) instead of writing past dst
+    # (header + 8-byte-per-frame map + raw payload cannot fit 2*header + raw)
+    rc, blob = sqy.encode("frame_shuffle", np.random.default_rng(5).integers(0, 256, (40000, 4, 4), dtype=np.uint8), nthreads=2)
+    assert rc == 1
+
+
+@pytest.mark.parametrize("pipeline", ["quantiser->bitswap1->lz4", "quantiser", "quantiser->lz4"])
+def test_quantiser(sqy, oracle, pipeline):
+    rng = np.random.default_rng(3)
+    vols = [synth.stack((32, 128, 128), np.uint16),                       # > 256 levels: adaptive_lloyd_com
+            rng.integers(0, 200, (8, 64, 64), dtype=np.uint16),           # <= 256 levels: linear mapping
+            rng.integers(0, 65536, (16, 128, 128), dtype=np.uint16),      # whole range, every window of the histogram
+            (rng.integers(0, 1000, (4, 33, 35)) * 60).astype(np.uint16)]  # ragged length, spread values
+    for vol in vols:
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2)
+        assert rc == 0
+        want = oracle.pipeline_encode(pipeline, vol)
+        assert blob == want, (pipeline, vol.shape)
