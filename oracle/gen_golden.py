@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/: golden vectors that pin the oracle (and through it the HIP path) to the REAL thing.
+
+Run in the build container (needs /root/reference -> oracle/_ref/libsqy_ref.so and the image's liblz4 1.9.3):
+    python oracle/gen_golden.py
+
+Sources of truth
+  * LZ4 bytes      liblz4.so.1.9.3 driven with sqeazy's call sequence (oracle/ref_driver.cpp cites
+                   encoders/lz4.hpp:103-113, lz4_utils.hpp:99-274)
+  * bitswap1 u16   the reference's own SSE gather, sqeazy::detail::simd_segment_broadcast
+                   (encoders/sse_utils.hpp:1365-1433), compiled in place from /root/reference
+  * everything the reference cannot produce here (needs Boost: scalar bitswap, diff3x3x1, quantiser, frame_shuffle,
+    header) is NOT in this file's "reference" section; those stages are pinned by the reference's own KATs restated in
+    tests/test_oracle_reference_kats.py and carry "oracle" hashes here only as regression anchors.
+
+Output
+  tests/golden/golden.json     {case: {input: generator spec, stage: {sha256, bytes, source}}}
+  tests/golden/*.bin           a few small raw input/expected pairs (data only)
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref, sqy_oracle as o   # noqa: E402
+from sqeazy_amd import synth             # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def gen_bytes(kind, n, seed):
+    """byte streams; the same function is imported by the tests"""
+    rng = np.random.default_rng(seed)
+    if kind == "zeros":
+        return np.zeros(n, np.uint8)
+    if kind == "ff":
+        return np.full(n, 255, np.uint8)
+    if kind == "random":
+        return rng.integers(0, 256, n, dtype=np.uint8)
+    if kind == "2level":
+        return rng.integers(0, 2, n, dtype=np.uint8)
+    if kind == "8level":
+        return rng.integers(0, 8, n, dtype=np.uint8)
+    if kind == "ramp":
+        return (np.arange(n) % 251).astype(np.uint8)
+    if kind == "slowramp":
+        return ((np.arange(n) // 7) % 256).astype(np.uint8)
+    if kind == "sparse":
+        s = np.zeros(n, np.uint8)
+        k = n // 50
+        if k:
+            s[rng.integers(0, n, k)] = rng.integers(1, 255, k)
+        return s
+    if kind == "words":
+        words = rng.integers(0, 256, (50, 12), dtype=np.uint8)
+        return words[rng.integers(0, 50, n // 12 + 1)].reshape(-1)[:n]
+    if kind == "period7":
+        return np.tile(np.arange(7, dtype=np.uint8), n // 7 + 1)[:n]
+    raise KeyError(kind)
+
+
+def main():
+    assert ref.available(), "oracle/_ref/libsqy_ref.so missing: run `make -C oracle` where /root/reference exists"
+    assert ref.lz4_version() == 10903, "golden vectors are pinned to liblz4 1.9.3"
+    os.makedirs(GOLD, exist_ok=True)
+    G = {"_meta": {"liblz4": "1.9.3 (LZ4_versionNumber 10903)", "reference_pieces": "encoders/sse_utils.hpp simd_segment_broadcast",
+                   "generator": "oracle/gen_golden.py"}, "lz4_block": [], "lz4_frames": [], "bitswap1_u16": [], "pipelines": []}
+
+    # ---- LZ4 block level: LZ4_compress_fast_continue(fresh stream, cap n-1) ----
+    kinds = ["zeros", "ff", "random", "2level", "8level", "ramp", "slowramp", "sparse", "words", "period7"]
+    for kind in kinds:
+        for n in (1, 12, 13, 14, 100, 1000, 10000, 65536, 70000, 262144):
+            d = gen_bytes(kind, n, 1000 + n)
+            r = ref.lz4_block(d)
+            mine = o.lz4_block_compress(d)
+            assert r == mine, ("oracle differs from liblz4", kind, n)
+            G["lz4_block"].append({"kind": kind, "n": n, "seed": 1000 + n, "csize": 0 if r is None else len(r),
+                                   "sha256": None if r is None else sha(r), "source": "liblz4-1.9.3"})
+
+    # ---- frames, chunked layout: encode_parallel ----
+    for kind in kinds:
+        for n in (0, 5, 10000, 262144, 262145, 600000, 2 * 262144 + 10000):
+            d = gen_bytes(kind, n, 2000 + n)
+            if n == 0:
+                continue
+            r = ref.lz4_encode_parallel(d, nthreads=2)
+            r4 = ref.lz4_encode_parallel(d, nthreads=4)
+            assert np.array_equal(r, r4), "chunked layout must not depend on the thread count (>= 2)"
+            mine = o.lz4_encode_chunked(d)
+            assert np.array_equal(r, mine), ("oracle frames differ from liblz4", kind, n)
+            G["lz4_frames"].append({"kind": kind, "n": n, "seed": 2000 + n, "bytes": int(r.size), "sha256": sha(r.tobytes()),
+                                    "source": "liblz4-1.9.3 via sqeazy's encode_parallel call sequence"})
+    # other block sizes (BD / HC bytes)
+    for kb, bid in ((64, 4), (1024, 6)):
+        d = gen_bytes("8level", 3 * (kb << 10) + 777, 77)
+        r = ref.lz4_encode_parallel(d, chunk=kb << 10, block_id=bid, nthreads=2)
+        cfg = o.Lz4Config("blocksize_kb=%d,framestep_kb=%d" % (kb, kb))
+        mine = o.lz4_encode_chunked(d, cfg)
+        assert np.array_equal(r, mine), kb
+        G["lz4_frames"].append({"kind": "8level", "n": int(d.size), "seed": 77, "config": "blocksize_kb=%d,framestep_kb=%d" % (kb, kb), "bytes": int(r.size),
+                                "sha256": sha(r.tobytes()), "source": "liblz4-1.9.3"})
+    # LZ4F constants the reference's tests pin (tests/test_lz4_sandbox.cpp:387-430)
+    G["_meta"]["LZ4F_compressBound_256k"] = int(ref.lz4f_compress_bound(262144))
+    G["_meta"]["LZ4F_HEADER_SIZE_MAX"] = int(ref.lib().ref_lz4f_header_size_max())
+
+    # ---- bitswap1 u16 through the reference's SSE kernel ----
+    for name, arr in (("ramp128", np.arange(128, dtype=np.uint16)),
+                      ("random_64k", np.random.default_rng(5).integers(0, 65536, 1 << 16, dtype=np.uint16)),
+                      ("synth_16x64x64", synth.stack((16, 64, 64)).reshape(-1)),
+                      ("lowbits_4096", np.random.default_rng(6).integers(0, 16, 4096, dtype=np.uint16))):
+        r = ref.bitswap1_encode_u16(arr, nthreads=2)
+        assert np.array_equal(r, o.bitswap1_encode(arr)), name
+        G["bitswap1_u16"].append({"name": name, "len": int(arr.size), "sha256": sha(r.tobytes()), "source": "reference sse_utils.hpp"})
+
+    # ---- whole pipelines: payload from liblz4 where the stage chain is reference-backed, oracle otherwise ----
+    vols = {"synth_u16_32x64x64": synth.stack((32, 64, 64)), "synth_u16_24x100x52": synth.stack((24, 100, 52)),
+            "synth_u8_48x64x96": synth.stack((48, 64, 96), np.uint8)}
+    for vname, vol in vols.items():
+        for pipe in ("bitswap1->lz4", "lz4", "diff3x3x1->bitswap1->lz4", "frame_shuffle->lz4", "quantiser->bitswap1->lz4"):
+            if vol.dtype == np.uint8 and pipe.startswith(("quantiser", "diff")):
+                continue
+            blob = o.pipeline_encode(pipe, vol)
+            entry = {"volume": vname, "pipeline": pipe, "bytes": len(blob), "sha256": sha(blob), "source": "oracle"}
+            if pipe in ("bitswap1->lz4", "lz4") and vol.dtype == np.uint16 and vol.size % 128 == 0:
+                # fully reference-backed payload: reference SSE bitswap + liblz4 frames
+                stream = ref.bitswap1_encode_u16(vol, 2).view(np.uint8) if pipe.startswith("bitswap1") else vol.reshape(-1).view(np.uint8)
+                payload = ref.lz4_encode_parallel(stream, nthreads=2).tobytes()
+                h = o.header_unpack(blob)
+                assert blob[h["size"]:] == payload
+                entry["payload_sha256"] = sha(payload)
+                entry["source"] = "payload: reference SSE bitswap + liblz4 1.9.3; header: oracle"
+            G["pipelines"].append(entry)
+
+    # ---- small raw fixtures (data only) ----
+    d = gen_bytes("sparse", 10000, 42)
+    d.tofile(os.path.join(GOLD, "sparse_10000.in.bin"))
+    ref.lz4_encode_parallel(d, nthreads=2).tofile(os.path.join(GOLD, "sparse_10000.lz4frames.bin"))
+    v = synth.stack((4, 16, 32))
+    v.tofile(os.path.join(GOLD, "synth_u16_4x16x32.in.bin"))
+    ref.bitswap1_encode_u16(v, 1).tofile(os.path.join(GOLD, "synth_u16_4x16x32.bitswap1.bin"))
+    ref.lz4_encode_parallel(ref.bitswap1_encode_u16(v, 1).view(np.uint8), nthreads=2).tofile(
+        os.path.join(GOLD, "synth_u16_4x16x32.bitswap1_lz4_payload.bin"))
+
+    with open(os.path.join(GOLD, "golden.json"), "w") as f:
+        json.dump(G, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(GOLD, "golden.json"), "with", sum(len(v) for k, v in G.items() if k != "_meta"), "vectors")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,127 @@
+"""CPU: the reference's own known-answer tests for the hot path, restated against the oracle.
+Each test cites the reference test it follows (paths relative to /root/reference/src/cpp/tests)."""
+import numpy as np
+import pytest
+
+
+def test_bitswap1_kat_incrementing_array(oracle):
+    """test_bitswap_scheme_impl.cpp:296-312: input 0..15 -> out[12..15] = ff, f0f, 3333, 5555, rest 0"""
+    out = oracle.bitswap1_encode(np.arange(16, dtype=np.uint16))
+    want = np.zeros(16, np.uint16)
+    want[12:] = [0x00ff, 0x0f0f, 0x3333, 0x5555]
+    assert np.array_equal(out, want)
+
+
+def test_bitswap1_u8_roundtrip_7x9x11(oracle):
+    """test_bitswap_scheme_impl.cpp:410-443: 8-bit volume whose length is not a multiple of 8 round-trips"""
+    v = (np.arange(7 * 9 * 11) % 251).astype(np.uint8).reshape(7, 9, 11)
+    enc = oracle.bitswap1_encode(v)
+    assert np.array_equal(enc.reshape(-1)[-(v.size % 8):], v.reshape(-1)[-(v.size % 8):])   # tail copied (bitswap_scheme_impl.hpp:99-103)
+    assert np.array_equal(oracle.bitswap1_decode(enc), v)
+
+
+@pytest.mark.parametrize("n", [8, 16])
+def test_diff_halo_geometry_cube(oracle, n):
+    """test_diff_scheme_impl.cpp:50-87 (offset_exact_last_plane): (n-1)*(n-2) row offsets, first/second/last values"""
+    offs, hx = oracle.diff3x3x1_offsets((n, n, n))
+    assert len(offs) == (n - 1) * (n - 2)
+    assert offs[0] == n * n + n + 1
+    assert offs[1] == n * n + 2 * n + 1
+    assert offs[-1] == (n - 1) * n * n + (n - 2) * n + 1
+    assert hx == n - 2
+
+
+def test_diff_changed_voxel_counts(oracle):
+    """number of rewritten voxels = (min(X,Z)-1)*(Y-2)*(Z-2) as observed with the reference's diff_scheme"""
+    for shape, want in (((8, 8, 8), 252), ((4, 6, 10), 24), ((6, 8, 16), 120)):
+        offs, hx = oracle.diff3x3x1_offsets(shape)
+        assert len(offs) * hx == want
+
+
+def test_diff_roundtrip_and_wraparound(oracle):
+    rng = np.random.default_rng(2)
+    v = rng.integers(0, 65536, (9, 10, 12), dtype=np.uint16)      # sums wrap mod 2^16 (values > 7281)
+    e = oracle.diff3x3x1_encode(v)
+    assert not np.array_equal(e, v)
+    assert np.array_equal(e[0], v[0])                              # first plane is never rewritten
+    assert np.array_equal(oracle.diff3x3x1_decode(e), v)
+    z, y, x = 3, 4, 5
+    s = int(v[z - 1, y - 1:y + 2, x - 1:x + 2].astype(np.uint64).sum()) & 0xffff
+    assert e[z, y, x] == (int(v[z, y, x]) - s // 9) & 0xffff
+
+
+def test_lz4_parameter_logic(oracle):
+    """test_lz4_scheme_impl.cpp:15-57"""
+    C = oracle.Lz4Config
+    assert (C().blocksize_kb, C().framestep_kb) == (256, 256)
+    assert C("framestep_kb=64").framestep_kb == 256
+    assert C("framestep_kb=64,blocksize_kb=64").framestep_kb == 64
+    assert C("blocksize_kb=64,framestep_kb=128").framestep_kb == 128
+    assert C("framestep_kb=513").framestep_kb == 512
+    assert C("framestep_kb=511").framestep_kb == 512
+    assert C("framestep_kb=512").framestep_kb == 512
+    assert C().config() == "accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0"
+
+
+def test_closest_blocksize(oracle):
+    """test_lz4_utils_impl.cpp:147-181"""
+    f = oracle.closest_blocksize_kb
+    assert f(32) == 64 and f(0) == 64
+    assert f(16 << 10) == 4096 and f(0xffffffff) == 4096
+    assert (f(64), f(256), f(1024), f(4096)) == (64, 256, 1024, 4096)
+    assert f(65) == 64 and f(255) == 256 and f(257) == 256
+
+
+def test_lz4_max_encoded_size(oracle):
+    """test_lz4_scheme_impl.cpp:63-216 relations + constants of test_lz4_sandbox.cpp:387-430"""
+    c = oracle.Lz4Config()
+    assert c.max_encoded_size(1 << 20, 1) == 4 * (262152 + 19)
+    assert c.max_encoded_size(1 << 20, 3) == 2 * 3 * (262152 + 19)          # over-estimate per thread, on purpose
+    assert c.max_encoded_size(1000, 1) > 1000
+
+
+def test_pipeline_validity(oracle):
+    """test_pipeline_interface.cpp:28-61, test_dynamic_pipeline_impl.cpp:679-709"""
+    ok = oracle.can_be_built_from
+    assert ok("bitswap1->lz4") and ok("lz4") and ok("quantiser->bitswap1->lz4") and ok("diff3x3x1->bitswap1->lz4")
+    assert ok("bitswap1(num_bits_per_plane=1)->lz4(accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0)")
+    assert not ok("") and not ok("bswap1_lz4") and not ok("bitswap1->") and not ok("diff->bitswap1->lz4")
+
+
+def test_frame_shuffle_label_stacks(oracle):
+    """test_frame_shuffle_scheme_impl.cpp:191-260: frames labelled 0..7 stay put, reversed labels come out ascending"""
+    ident = np.repeat(np.arange(8, dtype=np.uint16), 64).reshape(8, 8, 8)
+    out, dmap = oracle.frame_shuffle_encode(ident)
+    assert np.array_equal(out, ident) and list(dmap) == list(range(8))
+    rev = ident[::-1].copy()
+    out, dmap = oracle.frame_shuffle_encode(rev)
+    assert np.array_equal(out, ident) and list(dmap) == list(range(7, -1, -1))
+    # equal metrics: std::find returns the FIRST such frame for every slot (frame_shuffle_utils.hpp:156-160)
+    eq = np.stack([np.full((4, 4), v, np.uint8) for v in (5, 3, 5, 1)])
+    out, dmap = oracle.frame_shuffle_encode(eq)
+    assert list(dmap) == [3, 1, 0, 0]
+
+
+def test_quantiser_ramp_histogram_and_exact_lut(oracle):
+    """test_quantiser_impl.cpp:862-876 (ramp histogram is all ones); test_sqeazy_pipelines_impl.cpp:347-398
+    (<= 256 levels quantise without loss)"""
+    ramp = np.arange(1 << 12, dtype=np.uint16)
+    h = oracle.histogram(ramp)
+    assert np.all(h[:1 << 12] == 1) and h[1 << 12:].sum() == 0
+    few = (np.random.default_rng(0).integers(0, 200, 5000) * 7).astype(np.uint16)
+    q, dec = oracle.quantiser_encode(few)
+    assert np.array_equal(dec[q], few)
+
+
+def test_header_alignment_and_delimiter(oracle):
+    """test_sqeazy_header_impl.cpp:100-124: header length is a multiple of sizeof(T); ends with the delimiter"""
+    for dt in (np.uint8, np.uint16):
+        for shape in ((3, 5, 7), (10, 100, 1000), (1,)):
+            h = oracle.header_pack(dt, shape, "bitswap1(num_bits_per_plane=1)->lz4", 12345)
+            assert len(h) % np.dtype(dt).itemsize == 0 and h.endswith(b"|01307#!")
+            u = oracle.header_unpack(h + b"payload")
+            assert u["shape"] == shape and u["bytes"] == 12345 and u["size"] == len(h)
+    # verbatim blocks (base64 with '/') survive the JSON escaping
+    name = "quantiser(decode_lut_string=<verbatim>ab/cd+ef==</verbatim>)->lz4"
+    h = oracle.header_pack(np.uint16, (2, 2, 2), name, 1)
+    assert oracle.header_unpack(h)["pipename"] == name
