@@ -178,7 +178,8 @@ size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, siz
     size_t* offs = (size_t*)malloc((noff ? noff : 1) * sizeof(size_t));                                  \
     if (!offs) return 1;                                                                                 \
     sqo_diff3x3x1_offsets(shape, offs, noff, &hx);                                                       \
-    for (size_t o = 0; o < noff; ++o) {                                                                  \
+    _Pragma("omp parallel for schedule(static) if(SQO_DIFF_PARALLEL)")                                   \
+    for (long o = 0; o < (long)noff; ++o) {                                                              \
         for (size_t k = 0; k < hx; ++k) {                                                                \
             const size_t idx = offs[o] + k;                                                              \
             T sum = 0;                                                                                   \
@@ -194,6 +195,7 @@ size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, siz
 
 int sqo_diff3x3x1_encode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3])
 {
+#define SQO_DIFF_PARALLEL 1   /* encode reads only the raw input: rows are independent */
     const uint16_t* src = in;
 #define BODY_STORE out[idx] = (uint16_t)(int16_t)(in[idx] - local_sum / 9u);
     SQO_DIFF_BODY(uint16_t, int16_t, unsigned int)
@@ -214,6 +216,8 @@ int sqo_diff3x3x1_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[
 
 /* diff_scheme_impl.hpp:143-194: decode walks the same offsets in order and reads the ALREADY
  * DECODED output (plane z-1 is complete before plane z only in serial order; restated serially). */
+#undef SQO_DIFF_PARALLEL
+#define SQO_DIFF_PARALLEL 0   /* decode reads its own output of plane z-1: serial, as the restated reference order */
 int sqo_diff3x3x1_decode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3])
 {
     const uint16_t* src = out;
