@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Condenses the rocprofv3 output of a GPU run (gpurun_out/prof/...) into profiles/ (tracked).
+
+  rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof/trace     -- python3 bench.py ...
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_fetch -- python3 bench.py ...
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/prof/pmc_write -- python3 bench.py ...
+
+HBM traffic per launch = (2 * FETCH_SIZE + WRITE_SIZE) KiB: on gfx950 FETCH_SIZE reports half of the bytes of wide
+coalesced streaming reads (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact for 16-byte-per-lane stores.
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+src = os.path.join(ROOT, "gpurun_out", "prof")
+dst = os.path.join(ROOT, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+SHORT = {"sqy::lz4_chunks_kernel": "lz4_chunks", "sqy::bitswap1_u16_tiles": "bitswap1_u16", "sqy::lz4_frame_gather_kernel": "lz4_frame_gather",
+         "sqy::lz4_frame_scan_kernel": "lz4_frame_scan", "sqy::bitswap1_u16_generic": "bitswap1_u16_generic"}
+
+
+def short(name):
+    base = name.split("(")[0]
+    return SHORT.get(base, base)
+
+
+rows = []
+for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+    for r in csv.DictReader(open(f)):
+        if r["Name"].startswith("sqy::"):
+            rows.append(r)
+with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 10 --warmup 2 --no-cpu-baseline   (sqy:: kernels only)\n")
+    w = csv.writer(f)
+    w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
+    for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+        w.writerow([r["Name"], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["MinNs"], r["MaxNs"], r["StdDev"]])
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+for name in ("pmc_fetch", "pmc_write"):
+    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if r["Kernel_Name"].startswith("sqy::"):
+                pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
+traffic = {}
+with open(os.path.join(dst, "%s_pmc_hbm.csv" % tag), "w") as f:
+    f.write("# separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes over bench.py; KiB per launch, mean over launches\n")
+    f.write("# hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024   (gfx950: FETCH_SIZE counts 128-B requests at 64 B)\n")
+    w = csv.writer(f)
+    w.writerow(["kernel", "launches", "FETCH_SIZE_KiB", "WRITE_SIZE_KiB", "hbm_bytes_per_launch"])
+    for k, c in sorted(pmc.items()):
+        fe = sum(c["FETCH_SIZE"]) / max(len(c["FETCH_SIZE"]), 1)
+        wr = sum(c["WRITE_SIZE"]) / max(len(c["WRITE_SIZE"]), 1)
+        hbm = int((2 * fe + wr) * 1024)
+        traffic[k] = hbm
+        w.writerow([k, len(c["FETCH_SIZE"]), "%.1f" % fe, "%.1f" % wr, hbm])
+json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
+for n in ("bench_plain.log", "bench_trace.log"):
+    p = os.path.join(src, n)
+    if os.path.exists(p):
+        lines = [l for l in open(p) if l.startswith("{")]
+        if lines:
+            open(os.path.join(dst, "%s_%s" % (tag, n.replace(".log", ".json"))), "w").write(lines[-1])
+print(open(os.path.join(dst, "%s_kernel_stats.csv" % tag)).read())
+print(open(os.path.join(dst, "%s_pmc_hbm.csv" % tag)).read())
