@@ -307,6 +307,17 @@ __device__ __forceinline__ uint32_t lz4_hash5(uint64_t seq)
     return (uint32_t)(((seq << 24) * 889523592379ULL) >> 52);
 }
 
+// the same hash from the low dword and the 5th byte without 64-bit multiplies:
+// ((seq << 24) * P) >> 52 = bits 28..39 of (seq40 * P) mod 2^40, P = 0xCF1BBCDCBB
+__device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
+{
+    const uint32_t plo = 0x1BBCDCBBu;
+    const uint32_t l = lo * plo;
+    uint32_t h = __umulhi(lo, plo);
+    h += (lo & 0xffu) * 0xCFu + (byte4 & 0xffu) * 0xBBu;      // only bits 0..7 of this sum reach the result
+    return ((h << 4) | (l >> 28)) & 0xfffu;
+}
+
 // Sliding window of the chunk's source bytes in LDS (ring of WIN bytes + a 16-byte mirror of its head so
 // that unaligned 16-byte reads never have to split at the wrap, filled FB bytes at a time).
 // The parse only ever needs bytes around ip (probe sequences, catch-up, match extension, literals) and
@@ -533,10 +544,115 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
             uint32_t f = 64, fcand = 0;      // first matching probe of the batch and its candidate
             uint32_t ipf = 0;                // its position
-            uint32_t fwl = 0xffffffffu;      // bytes known equal beyond MINMATCH for the winner (0..11 exact), ~0 = unknown
+            uint32_t fwl = 0;                // forward bytes beyond MINMATCH for the winner: exact when fw_exact, else "at least"
+            bool fw_exact = false;
             uint32_t bkl = 0xffffffffu;      // bytes known equal in front of (ip, match) for the winner (0..3 exact), ~0 = unknown
             bool batch_done = false;         // fast path handled table commit
             uint32_t nvalid = 64, next_P = 0;
+            bool lean_handover = false;      // lean path found the winner but leaves the rest to the generic tail
+
+            // ---------------------------------------------------------------------------------------
+            // lean path: the batch right after a match (anchor == P, put2 == P-2), winner among the first 15
+            // probes with a resident candidate, fewer than 15 literals, match settled by the speculative compare or
+            // one wide round.  Straight-line, ring reads unconditional (ring offsets are always in bounds; the
+            // values only count where the masks say so), no global memory traffic.  Anything else falls through.
+            // ---------------------------------------------------------------------------------------
+            if (U == 0 && P >= w.wlo + 4u && P + 1200u <= w.hi_valid() && P + 1200u <= matchlimit) {
+                const uint32_t pos = P + (uint32_t)lane;
+                const uint32_t wlo4 = w.wlo + 4u;
+                const uint4 s16 = w.lds128(pos);
+                const uint32_t b4 = w.lds32(pos - 4u);
+                const uint32_t h = lz4_hash5_32(s16.x, s16.y);
+                {   // LZ4_putPosition(P - 2): its five bytes are the top half of b4 and the low three of s16.x (lane 0)
+                    const uint32_t x2 = __builtin_amdgcn_alignbit(s16.x, b4, 16);
+                    const uint32_t h2 = lz4_hash5_32(x2, s16.x >> 16);
+                    if (lane == 0) table[h2] = P - 2u;
+                    put2 = 0xffffffffu;
+                }
+                const uint32_t old = table[h];
+                const uint32_t dist = pos - old;
+                const bool near = dist <= LZ4_MAXD;
+                const bool cin = near && old >= wlo4;
+                const uint4 c16 = w.lds128(old);
+                const uint32_t cb4 = w.lds32(old - 4u);
+                const uint64_t mm = ballot(cin && c16.x == s16.x);
+                const uint64_t fm = ballot(near && old < wlo4);
+                const uint32_t f0 = mm ? ctz64(mm) : 64u;
+                bool ok = f0 <= 14u && (fm & ((1ull << f0) - 1ull)) == 0;
+                if (ok && f0 != 0) {
+                    if (f0 <= 4) {
+                        const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
+                        ok = ballot(((h == h1) | (h == h2s) | (h == h3) | (h == h4)) && (uint32_t)lane <= f0) == 0;
+                    } else {
+                        for (uint32_t c = 1; c <= f0; ++c)
+                            if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { ok = false; break; }
+                    }
+                }
+                if (ok) {
+                    const uint32_t mt0 = lane_read(old, f0);
+                    const uint32_t ip0 = P + f0;
+                    // forward: bytes 4..15 of the winner's 16-byte compare
+                    const uint32_t dy = lane_read(s16.y ^ c16.y, f0), dz = lane_read(s16.z ^ c16.z, f0), dw = lane_read(s16.w ^ c16.w, f0);
+                    uint32_t ml;
+                    bool settled = true;
+                    if (dy) ml = (uint32_t)__builtin_ctz(dy) >> 3;
+                    else if (dz) ml = 4u + ((uint32_t)__builtin_ctz(dz) >> 3);
+                    else if (dw) ml = 8u + ((uint32_t)__builtin_ctz(dw) >> 3);
+                    else {
+                        // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (both resident, clear of matchlimit)
+                        const uint32_t d = (uint32_t)lane * 16u;
+                        const uint32_t g = first_diff16(w.lds128(ip0 + 16u + d), w.lds128(mt0 + 16u + d));
+                        const uint64_t nf = ballot(g != 16u);
+                        if (nf) {
+                            const uint32_t l = ctz64(nf);
+                            ml = 12u + l * 16u + lane_read(g, l);
+                        } else {
+                            ml = 12u + 1024u;
+                            settled = false;
+                        }
+                    }
+                    // backward catch-up, bounded by the literals (ip0 - anchor = f0) and the candidate position
+                    const uint32_t xb = lane_read(b4 ^ cb4, f0);
+                    const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;
+                    const uint32_t lim = f0 < mt0 ? f0 : mt0;
+                    // commit probes 0..f0 (positions only grow)
+                    if ((uint32_t)lane <= f0) atomicMax(&table[h], pos);
+                    if (settled && (bk < 4u || lim <= 4u)) {
+                        const uint32_t back = bk < lim ? bk : lim;
+                        const uint32_t lit = f0 - back;                               // < 15
+                        const uint32_t matchCode = ml + back;
+                        const uint32_t offset = ip0 - mt0;
+                        const uint32_t ml_ext = matchCode >= 15u ? (matchCode - 15u) / 255u + 1u : 0u;
+                        const uint32_t seq_bytes = 1u + lit + 2u + ml_ext;            // <= 1 + 14 + 2 + 5
+                        // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
+                        if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
+                            op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; break; }
+                        o.reserve(op, seq_bytes);
+                        const uint32_t k = (uint32_t)lane;
+                        const uint32_t litbyte = w.lds8(P + k - 1u);                    // literal k-1 sits at anchor + k - 1 = P + k - 1
+                        uint32_t v = ((lit << 4) | (matchCode < 15u ? matchCode : 15u));
+                        v = (k >= 1u && k <= lit) ? litbyte : v;
+                        v = (k == lit + 1u) ? (offset & 0xffu) : v;
+                        v = (k == lit + 2u) ? (offset >> 8) : v;
+                        const uint32_t j = k - (lit + 3u);
+                        v = (k > lit + 2u) ? ((j + 1u < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1u) * 255u)) : v;
+                        if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
+                        op += seq_bytes;
+                        const uint32_t ipn = ip0 + 4u + ml;
+                        anchor = ipn;
+                        if (ipn >= mflimitPlusOne) break;
+                        put2 = ipn - 2u;
+                        P = ipn;
+                        SQY_STAMP(1);
+                        continue;                                                     // U stays 0
+                    }
+                    // winner known, but the match runs past the wide round or the catch-up past 4 bytes: generic tail
+                    f = f0; fcand = mt0; ipf = ip0; fwl = ml; fw_exact = settled; bkl = bk < 4u ? bk : 0xffffffffu;
+                    batch_done = true;
+                    lean_handover = true;
+                }
+                SQY_STAMP(2);
+            }
 
             // ---------------------------------------------------------------------------------------
             // fast path: 64 probes at consecutive positions, everything they touch resident in the ring
@@ -544,7 +660,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const bool step1 = (U + 64u <= 66u);                                  // all 64 advances are 1
             const bool interior = step1 && P >= w.wlo + 4u && P + 64u + 16u <= w.hi_valid() && P + 64u <= mflimitPlusOne - 1u &&
                                   P + 64u + 16u + 12u <= matchlimit;
-            if (interior) {
+            if (interior && !lean_handover) {
                 const uint32_t pos = P + (uint32_t)lane;
                 const uint4 s16 = w.lds128(pos);
                 const uint32_t b4 = w.lds32(pos - 4u);
@@ -553,10 +669,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     if (lane == 0) table[h2] = put2;
                     put2 = 0xffffffffu;
                 }
-                SQY_STAMP(1);
                 const uint32_t h = lz4_hash5(((uint64_t)s16.y << 32) | s16.x);
                 const uint32_t old = table[h];
-                SQY_STAMP(2);
                 const bool near = (old + LZ4_MAXD >= pos);
                 const bool cin = near && old >= w.wlo + 4u;                        // old + 16 <= pos + 16 <= hi_valid
                 uint32_t fw = 0xffffffffu, bk = 0xffffffffu;
@@ -596,7 +710,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     ipf = P + f;
                     fwl = lane_read(fw, f);
                     bkl = lane_read(bk, f);
-                    if (fwl >= 12u) fwl = (fwl == 12u) ? 12u : 0xffffffffu;
+                    fw_exact = fwl < 12u;
+                    if (fwl > 12u) fwl = 0u;                                        // far candidate: nothing known
                     if ((uint32_t)lane <= f) atomicMax(&table[h], pos);             // commit probes 0..f (positions grow)
                     batch_done = true;
                 }
@@ -689,10 +804,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
             // forward extension: bytes equal beyond MINMATCH (upstream's LZ4_count from ip+4), up to matchlimit
             uint32_t ml;
-            if (fwl < 12u) {
-                ml = fwl;                                                 // settled by the speculative 16-byte compare
+            if (fw_exact) {
+                ml = fwl;                                                 // settled by the speculative compares
             } else {
-                ml = (fwl == 12u) ? 12u : 0u;
+                ml = fwl;                                                 // bytes already known equal; continue from there
                 for (;;) {
                     uint32_t got[4];
                     // uniform test: both operands of the whole 4 KiB round resident in the ring and clear of matchlimit

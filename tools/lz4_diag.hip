@@ -26,7 +26,7 @@ int main(int argc, char** argv)
     std::vector<unsigned long long> dg(nch * 16); std::vector<uint32_t> cs(nch);
     hipMemcpy(dg.data(), ddg, nch * 16 * 8, hipMemcpyDeviceToHost);
     hipMemcpy(cs.data(), dcs, nch * 4, hipMemcpyDeviceToHost);
-    const char* names[8] = {"ensure", "seq+put2 read", "hash+table", "cand+hazard+commit", "ext0+catchup", "literals+offset", "mlcount+emit", "loop-top"};
+    const char* names[8] = {"ensure", "LEAN iteration (done)", "lean attempt, fell through", "generic batch", "generic ext+catchup", "generic emit", "generic tail", "loop-top"};
     for (uint64_t k = 0; k < nch; ++k) {
         unsigned long long tot = 0;
         for (int i = 0; i < 8; ++i) tot += dg[k * 16 + i];
