@@ -191,6 +191,8 @@ def decode(blob, nthreads=0):
     blob = bytes(blob)
     size = decompressed_sizeof(blob)
     shape = decompressed_shape(blob)
+    if size not in (1, 2) or not shape:
+        return 1, None
     dtype = np.uint16 if size == 2 else np.uint8
     out = np.empty(shape, dtype=dtype)
     src = np.frombuffer(blob, dtype=np.uint8)

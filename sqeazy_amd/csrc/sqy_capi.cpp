@@ -417,6 +417,190 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
     return 0;
 }
 
+// ---- decode --------------------------------------------------------------------------------------
+// dynamic_pipeline::decode (dynamic_pipeline.hpp:740-846): tail filters^-1, sink^-1, head filters^-1 in reverse.
+int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t dst_capacity, int want_elem, hipStream_t stream)
+{
+    if (!d_src_v || !d_dst) return 1;
+    const uint8_t* d_src = static_cast<const uint8_t*>(d_src_v);
+    Workspace* ws = workspace();
+    if (!ws) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+
+    // header: fetch a prefix of the blob, grow until the delimiter is inside
+    std::vector<char> head;
+    sqy::HeaderInfo h;
+    for (uint64_t want = 1 << 16;; want *= 16) {
+        const uint64_t take = std::min<uint64_t>(want, srclen);
+        head.resize(take);
+        SQY_HIP(hipMemcpyAsync(head.data(), d_src, take, hipMemcpyDeviceToHost, stream));
+        SQY_HIP(hipStreamSynchronize(stream));
+        h = sqy::header_unpack(head.data(), head.data() + take);
+        if (h.valid || take == srclen) break;
+    }
+    if (!h.valid) { std::fprintf(stderr, "[sqeazy]\t unable to find a sqy header in the blob\n"); return 1; }
+    const int elem = h.elem_size();
+    if (elem != want_elem) { std::fprintf(stderr, "[sqeazy]\t blob holds %s voxels\n", h.type.c_str()); return 1; }
+    std::string why;
+    if (!Pipeline::supported(h.pipename, elem, &why)) {
+        std::fprintf(stderr, "[sqeazy]\t%s cannot be build with this version of sqeazy (%s)\n", h.pipename.c_str(), why.c_str());
+        return 1;
+    }
+    Pipeline pipe = Pipeline::from_string(h.pipename);
+    uint64_t n = 1;
+    for (uint64_t d : h.shape) n *= d;
+    const uint64_t raw_bytes = n * (uint64_t)elem;
+    if (raw_bytes > dst_capacity || h.size + h.payload_bytes > srclen) {
+        std::fprintf(stderr, "[sqeazy]\t decode: buffer too small or blob truncated\n");
+        return 1;
+    }
+    // element size of the stream in front of every stage (the quantiser sink turns it into bytes)
+    std::vector<int> elem_before(pipe.stages.size());
+    {
+        int e = elem;
+        for (size_t i = 0; i < pipe.stages.size(); ++i) { elem_before[i] = e; if (pipe.stages[i].kind == StageKind::quantiser) e = 1; }
+    }
+    const uint8_t* cur = d_src + h.size;
+    uint64_t cur_bytes = h.payload_bytes;
+    bool use_ping = true;
+    auto out_buf = [&](size_t stage_index, uint64_t bytes) -> uint8_t* {
+        if (stage_index == 0) return static_cast<uint8_t*>(d_dst);               // the first stage's inverse produces the volume
+        DevBuf& b = use_ping ? ws->ping : ws->pong;
+        use_ping = !use_ping;
+        if (b.ensure(std::max<uint64_t>(bytes, 16))) return nullptr;
+        return static_cast<uint8_t*>(b.p);
+    };
+
+    for (size_t si = pipe.stages.size(); si-- > 0;) {
+        const Stage& st = pipe.stages[si];
+        const int e_in = elem_before[si];                                       // element size on the ENCODER's input side of this stage
+        const uint64_t stage_in_bytes = n * (uint64_t)e_in;                     // bytes the inverse has to produce
+        switch (st.kind) {
+            case StageKind::lz4: {
+                const uint64_t total = stage_in_bytes;
+                const uint64_t chunk = total ? st.lz4.bytes_per_chunk(total) : 1;
+                const uint64_t block_bytes = st.lz4.block_bytes();
+                const uint64_t nchunks = total ? (total + chunk - 1) / chunk : 0;
+                const uint64_t max_blocks = std::max<uint64_t>(nchunks * ((chunk + block_bytes - 1) / block_bytes), total / block_bytes + 1) + 16;
+                if (ws->lz4_scratch.ensure(max_blocks * 16 + (max_blocks + 2) * 4 + 64)) return 1;
+                uint8_t* blk = static_cast<uint8_t*>(ws->lz4_scratch.p);
+                uint32_t* frame_first = reinterpret_cast<uint32_t*>(blk + max_blocks * 16);
+                if (ws->csize.ensure(64)) return 1;
+                uint32_t* counts = static_cast<uint32_t*>(ws->csize.p);          // [0..2] index result, [4] decode error flag
+                SQY_HIP(hipMemsetAsync(counts, 0, 32, stream));
+                {
+                    ProfScope ps("lz4_frame_index", stream);
+                    SQY_HIP(sqy::launch_lz4_frame_index(cur, cur_bytes, blk, frame_first, max_blocks, counts, stream));
+                }
+                uint32_t hc[3];
+                SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
+                SQY_HIP(hipStreamSynchronize(stream));
+                if (hc[2]) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 frame stream (code %u)\n", hc[2]); return 1; }
+                const uint32_t nframes = hc[0];
+                if (nframes > 1 && nframes != nchunks) {
+                    std::fprintf(stderr, "[sqy::lz4] %u frames where %llu chunks were expected\n", nframes, (unsigned long long)nchunks);
+                    return 1;
+                }
+                uint8_t* out = out_buf(si, total);
+                if (!out) return 1;
+                {
+                    ProfScope ps("lz4_frames_decode", stream);
+                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, counts + 4, stream));
+                }
+                uint32_t bad = 0;
+                SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
+                SQY_HIP(hipStreamSynchronize(stream));
+                if (bad) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 block\n"); return 1; }
+                cur = out; cur_bytes = total;
+                break;
+            }
+            case StageKind::bitswap1: {
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                ProfScope ps("bitswap1_decode", stream);
+                SQY_HIP(sqy::launch_bitswap1_decode(cur, out, n, e_in, stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            case StageKind::diff3x3x1: {
+                if (h.shape.size() != 3) return 1;
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                ProfScope ps("diff3x3x1_decode", stream);
+                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            case StageKind::quantiser: {
+                auto it = st.cfg.find("decode_lut_string");
+                if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t quantiser: no decode_lut_string in the header\n"); return 1; }
+                const std::string b64 = it->second.substr(10, it->second.size() - 21);   // strip <verbatim> ... </verbatim>
+                const std::vector<unsigned char> lut = sqy::base64_decode(b64);
+                if (lut.size() != 512) { std::fprintf(stderr, "[sqeazy]\t quantiser: malformed decode LUT\n"); return 1; }
+                if (ws->small.ensure(4096)) return 1;
+                SQY_HIP(hipMemcpyAsync(ws->small.p, lut.data(), 512, hipMemcpyHostToDevice, stream));
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                {
+                    ProfScope ps("quantiser_decode", stream);
+                    SQY_HIP(sqy::launch_quantiser_decode(cur, reinterpret_cast<uint16_t*>(out), n, static_cast<const uint16_t*>(ws->small.p), stream));
+                }
+                SQY_HIP(hipStreamSynchronize(stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            case StageKind::frame_shuffle: {
+                if (h.shape.size() != 3) return 1;
+                auto it = st.cfg.find("reorder_map");
+                const uint64_t Z = h.shape[0];
+                if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: no reorder_map in the header\n"); return 1; }
+                const std::vector<unsigned char> mapb = sqy::base64_decode(it->second.substr(10, it->second.size() - 21));
+                if (mapb.size() != Z * 8) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: malformed reorder_map\n"); return 1; }
+                for (uint64_t i = 0; i < Z; ++i) {
+                    uint64_t v; std::memcpy(&v, mapb.data() + 8 * i, 8);
+                    if (v >= Z) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: reorder_map out of range\n"); return 1; }
+                }
+                if (ws->small.ensure(std::max<uint64_t>(Z * 8, 4096))) return 1;
+                SQY_HIP(hipMemcpyAsync(ws->small.p, mapb.data(), Z * 8, hipMemcpyHostToDevice, stream));
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                {
+                    ProfScope ps("frame_scatter", stream);
+                    SQY_HIP(sqy::launch_frame_scatter(cur, out, Z, h.shape[1] * h.shape[2] * (uint64_t)e_in, static_cast<const uint64_t*>(ws->small.p), stream));
+                }
+                SQY_HIP(hipStreamSynchronize(stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            default:
+                return 1;
+        }
+    }
+    if (cur != d_dst) SQY_HIP(hipMemcpyAsync(d_dst, cur, raw_bytes, hipMemcpyDeviceToDevice, stream));
+    SQY_HIP(hipStreamSynchronize(stream));
+    if (g_prof_on) prof_collect();
+    return 0;
+}
+
+int decode_from_host(const char* src, long srclength, char* dst, int elem_size)
+{
+    if (!src || !dst || srclength <= 0) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(src, src + srclength);
+    if (!h.valid) { std::fprintf(stderr, "[sqeazy]\t unable to find a sqy header in the blob\n"); return 1; }
+    if (!device_present()) { std::fprintf(stderr, "[sqeazy]\t no MI355X (HIP device) visible: sqeazy_amd has no CPU path\n"); return 1; }
+    std::lock_guard<std::mutex> lock(g_mu);
+    Workspace* ws = workspace();
+    if (!ws) return 1;
+    uint64_t n = 1;
+    for (uint64_t d : h.shape) n *= d;
+    const uint64_t raw = n * (uint64_t)h.elem_size();
+    if (ws->io_src.ensure(std::max<uint64_t>((uint64_t)srclength, 16)) || ws->io_dst.ensure(std::max<uint64_t>(raw, 16))) return 1;
+    SQY_HIP(hipMemcpy(ws->io_src.p, src, (size_t)srclength, hipMemcpyHostToDevice));
+    const int rc = decode_on_device(ws->io_src.p, (uint64_t)srclength, ws->io_dst.p, raw, elem_size, nullptr);
+    if (rc) return rc;
+    SQY_HIP(hipMemcpy(dst, ws->io_dst.p, raw, hipMemcpyDeviceToHost));
+    return 0;
+}
+
 int max_compressed_length(const char* pipeline, long pipeline_length, long* length, int elem_size, uint64_t raw_bytes)
 {
     if (!pipeline || !length || pipeline_length < 0) return 1;
@@ -539,16 +723,14 @@ bool SQY_Pipeline_Possible(const char* s, int sizeofpixel)
 
 int SQY_Decode_UI16(const char* src, long srclength, char* dst, int nthreads)
 {
-    (void)src; (void)srclength; (void)dst; (void)nthreads;
-    std::fprintf(stderr, "[sqeazy]\t SQY_Decode_UI16: decode is not implemented on MI355X yet\n");
-    return 1;
+    (void)nthreads;   // the layout is read from the blob; the GPU decodes every frame in parallel
+    return decode_from_host(src, srclength, dst, 2);
 }
 
 int SQY_Decode_UI8(const char* src, long srclength, char* dst, int nthreads)
 {
-    (void)src; (void)srclength; (void)dst; (void)nthreads;
-    std::fprintf(stderr, "[sqeazy]\t SQY_Decode_UI8: decode is not implemented on MI355X yet\n");
-    return 1;
+    (void)nthreads;
+    return decode_from_host(src, srclength, dst, 1);
 }
 
 int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
@@ -579,16 +761,16 @@ int SQYAMD_PipelineEncode_UI8_Cap(const char* pipeline, const char* src, long* s
     return encode_from_host(pipeline, src, shape, shape_size, 1, dst, dstlength, nthreads, std::max(dst_capacity, 0l));
 }
 
-int SQYAMD_Decode_UI16_Device(const void*, long, void*, long, void*)
+int SQYAMD_Decode_UI16_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream)
 {
-    std::fprintf(stderr, "[sqeazy]\t decode is not implemented on MI355X yet\n");
-    return 1;
+    std::lock_guard<std::mutex> lock(g_mu);
+    return decode_on_device(d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 2, static_cast<hipStream_t>(hip_stream));
 }
 
-int SQYAMD_Decode_UI8_Device(const void*, long, void*, long, void*)
+int SQYAMD_Decode_UI8_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream)
 {
-    std::fprintf(stderr, "[sqeazy]\t decode is not implemented on MI355X yet\n");
-    return 1;
+    std::lock_guard<std::mutex> lock(g_mu);
+    return decode_on_device(d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 1, static_cast<hipStream_t>(hip_stream));
 }
 
 void SQYAMD_Profile_Enable(int enable)

@@ -34,5 +34,17 @@ hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t
 hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream);
 hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
 
+// ---- decode ----
+// index of every LZ4 block of the concatenated frames: blk[i] = {data offset lo, hi, size | raw << 31, block id in frame}
+hipError_t launch_lz4_frame_index(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
+                                  uint32_t* counts /* frames, blocks, error */, hipStream_t stream);
+// frame f decodes to out + f*frame_stride; every block decodes to at most block_bytes
+hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
+                                    uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t* errflag, hipStream_t stream);
+hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int elem_size, hipStream_t stream);
+hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream);
+hipError_t launch_quantiser_decode(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
+hipError_t launch_frame_scatter(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
+
 } // namespace sqy
 #endif

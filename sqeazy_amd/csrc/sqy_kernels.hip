@@ -1221,6 +1221,209 @@ void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ o
 }
 
 // ------------------------------------------------------------------------------------------------
+// decode (src/sqeazy.cpp:281-335 -> dynamic_pipeline.hpp:740-846): LZ4 frames, inverse filters.
+// ------------------------------------------------------------------------------------------------
+
+// Walk the concatenated LZ4 frames once (one lane chases the size fields) and record every block:
+//   blk[i] = {offset of the block's data in the stream, size | raw flag << 31, frame id, block id in frame}
+// frame_first[f] = index of the first block of frame f.  counts[0] = #frames, counts[1] = #blocks, counts[2] = error.
+__global__ __launch_bounds__(64)
+void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* __restrict__ blk, uint32_t* __restrict__ frame_first,
+                            uint64_t max_blocks, uint32_t* __restrict__ counts)
+{
+    if (threadIdx.x != 0) return;
+    uint64_t off = 0;
+    uint32_t nframes = 0, nblocks = 0, err = 0;
+    while (off < n) {
+        if (off + 7 > n || in[off] != 0x04 || in[off + 1] != 0x22 || in[off + 2] != 0x4D || in[off + 3] != 0x18) { err = 1; break; }
+        const uint32_t flg = in[off + 4];
+        if ((flg >> 6) != 1 || (flg & 0x0D)) { err = 2; break; }       // only what sqeazy writes: no content size / checksum / dictID
+        const bool block_checksum = (flg >> 4) & 1;
+        off += 7;
+        frame_first[nframes] = nblocks;
+        uint32_t j = 0;
+        for (;;) {
+            if (off + 4 > n) { err = 3; break; }
+            const uint32_t field = ld_u32(in + off);
+            off += 4;
+            if (field == 0) break;
+            const uint32_t sz = field & 0x7fffffffu;
+            if (off + sz > n || nblocks >= max_blocks) { err = 4; break; }
+            blk[nblocks] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), field, j);
+            ++nblocks; ++j;
+            off += sz + (block_checksum ? 4 : 0);
+        }
+        if (err) break;
+        ++nframes;
+    }
+    frame_first[nframes] = nblocks;
+    counts[0] = nframes; counts[1] = nblocks; counts[2] = err;
+}
+
+// One wavefront per frame; the last 64 KiB of decoded output live in an LDS ring so that match copies (which may
+// overlap their own output and, in block-linked frames, reach into the previous block) never read global memory
+// the wave has just written.  Output leaves through the ring in 16-byte pieces.
+constexpr uint32_t DEC_RING = 65536;
+
+__global__ __launch_bounds__(64)
+void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
+                              uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes,
+                              uint32_t* __restrict__ errflag)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t dring_raw[];
+    lds_u8* ring = (lds_u8*)dring_raw;
+    const int lane = threadIdx.x;
+    const uint32_t f = blockIdx.x;
+    const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
+    const uint64_t frame_out = (uint64_t)f * frame_stride;      // frame f decodes to [f*chunk, ...)
+    uint32_t pos = 0;                                          // decoded bytes of this frame so far
+    uint32_t flushed = 0;                                      // bytes of this frame already written to global memory
+    bool bad = false;
+
+    auto flush = [&](bool all) {
+        // write ring bytes [flushed, pos) (all) or the whole KiB pieces of it
+        while (flushed + 1024u <= pos || (all && flushed < pos)) {
+            const uint32_t cnt = (pos - flushed >= 1024u) ? 1024u : (pos - flushed);
+            const uint64_t o = frame_out + flushed;
+            if (o + cnt > out_bytes) { bad = true; flushed = pos; break; }
+            const uint32_t nvec = cnt >> 4;
+            if ((uint32_t)lane < nvec) {
+                const v4u v = *reinterpret_cast<const SQY_LDS v4u*>(ring + ((flushed + (uint32_t)lane * 16u) & (DEC_RING - 1)));
+                st_u128(out + o + (uint32_t)lane * 16u, make_uint4(v.x, v.y, v.z, v.w));
+            }
+            const uint32_t done = nvec << 4;
+            if ((uint32_t)lane < cnt - done) out[o + done + lane] = ring[(flushed + done + lane) & (DEC_RING - 1)];
+            flushed += cnt;
+        }
+    };
+
+    for (uint32_t b = b0; b < b1 && !bad; ++b) {
+        const uint4 e = blk[b];
+        const uint8_t* __restrict__ src = in + (((uint64_t)e.y << 32) | e.x);
+        const uint32_t sz = e.z & 0x7fffffffu;
+        if (e.z >> 31) {
+            // stored block: straight copy (through the ring, later blocks of a linked frame may reference it)
+            for (uint32_t i = 0; i < sz; i += 64) {
+                const uint32_t cnt = sz - i < 64 ? sz - i : 64;
+                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[i + lane];
+                pos += cnt;
+                flush(false);
+            }
+            continue;
+        }
+        const uint32_t block_start = pos;
+        uint32_t ip = 0;
+        while (ip < sz) {
+            const uint32_t token = src[ip++];
+            uint32_t lit = token >> 4;
+            if (lit == 15) {
+                uint32_t sbyte;
+                do { if (ip >= sz) { bad = true; break; } sbyte = src[ip++]; lit += sbyte; } while (sbyte == 255);
+            }
+            if (bad || ip + lit > sz || pos - block_start + lit > block_bytes) { bad = true; break; }
+            for (uint32_t i = 0; i < lit; i += 64) {
+                const uint32_t cnt = lit - i < 64 ? lit - i : 64;
+                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[ip + i + lane];
+                pos += cnt;
+                flush(false);
+            }
+            ip += lit;
+            if (ip >= sz) break;                                   // last sequence: literals only
+            if (ip + 2 > sz) { bad = true; break; }
+            const uint32_t offset = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+            ip += 2;
+            uint32_t ml = token & 15u;
+            if (ml == 15) {
+                uint32_t sbyte;
+                do { if (ip >= sz) { bad = true; break; } sbyte = src[ip++]; ml += sbyte; } while (sbyte == 255);
+            }
+            ml += 4;
+            if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
+            // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
+            // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
+            const uint32_t lmod = (uint32_t)lane % offset;
+            for (uint32_t j = 0; j < ml; j += 64) {
+                const uint32_t cnt = ml - j < 64 ? ml - j : 64;
+                uint32_t v = 0;
+                if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
+                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                pos += cnt;
+                flush(false);
+            }
+        }
+    }
+    flush(true);
+    if (bad && lane == 0) atomicExch(errflag, 1u);
+}
+
+// inverse bitswap1 (bitplane_reorder_scalar.hpp:81-116): one thread per group of W voxels
+template <typename T>
+__global__ __launch_bounds__(256)
+void bitswap1_decode_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t len, uint64_t seg)
+{
+    constexpr uint32_t W = sizeof(T) * 8;
+    const uint64_t L = seg * W;
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < seg) {
+        uint32_t plane[W];
+#pragma unroll
+        for (uint32_t b = 0; b < W; ++b) plane[b] = in[(uint64_t)(W - 1 - b) * seg + w];
+#pragma unroll
+        for (uint32_t j = 0; j < W; ++j) {
+            uint32_t v = 0;
+#pragma unroll
+            for (uint32_t b = 0; b < W; ++b) v |= ((plane[b] >> (W - 1 - j)) & 1u) << b;
+            out[w * W + j] = (T)v;
+        }
+    }
+    if (blockIdx.x == 0 && w < len - L) out[L + w] = in[L + w];
+}
+
+// inverse diff3x3x1, one launch per frame z (plane z-1 must be final): diff_scheme_impl.hpp:143-194
+template <typename T, typename ST>
+__global__ __launch_bounds__(256)
+void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t z, uint64_t length, uint64_t Y, uint64_t X,
+                                   uint64_t hx, uint64_t zlim, int single)
+{
+    const uint64_t frame = Y * X;
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= frame) return;
+    const uint64_t idx = z * frame + r;
+    T v = in[idx];
+    if (z >= 1 && diff_touched(idx, length, Y, X, hx, zlim, single != 0)) {
+        const T* p = out + idx - frame;
+        T sum = 0;
+        sum = (T)(sum + p[-(int64_t)X - 1]); sum = (T)(sum + p[-(int64_t)X]); sum = (T)(sum + p[-(int64_t)X + 1]);
+        sum = (T)(sum + p[-1]);              sum = (T)(sum + p[0]);           sum = (T)(sum + p[1]);
+        sum = (T)(sum + p[X - 1]);           sum = (T)(sum + p[X]);           sum = (T)(sum + p[X + 1]);
+        v = (T)((uint32_t)(int32_t)(ST)v + (uint32_t)sum / 9u);
+    }
+    out[idx] = v;
+}
+
+// inverse quantiser: out[i] = lut_decode[in[i]]
+__global__ __launch_bounds__(256)
+void quantiser_decode_kernel(const uint8_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t len, const uint16_t* __restrict__ lut)
+{
+    __shared__ uint16_t sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (uint64_t)gridDim.x * 256) out[i] = sl[in[i]];
+}
+
+// inverse frame_shuffle: out frame map[i] = in frame i (frame_shuffle_utils.hpp:313-357)
+__global__ __launch_bounds__(256)
+void frame_scatter_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t frame_bytes,
+                          const uint64_t* __restrict__ map, uint32_t blocks_per_frame)
+{
+    const uint64_t f = blockIdx.x / blocks_per_frame;
+    const uint32_t part = blockIdx.x % blocks_per_frame;
+    const uint8_t* s = in + f * frame_bytes;
+    uint8_t* d = out + map[f] * frame_bytes;
+    for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < frame_bytes; i += (uint64_t)blocks_per_frame * 256) d[i] = s[i];
+}
+
+// ------------------------------------------------------------------------------------------------
 // launchers
 // ------------------------------------------------------------------------------------------------
 static inline int num_cus()
@@ -1365,6 +1568,76 @@ hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t f
     if (bpf == 0) bpf = 1;
     if (bpf > 64) bpf = 64;
     hipLaunchKernelGGL(frame_gather_kernel, dim3((unsigned)(Z * bpf)), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, frame_bytes,
+                       map, (uint32_t)bpf);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_frame_index(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
+                                  uint32_t* counts, hipStream_t stream)
+{
+    hipLaunchKernelGGL(lz4_frame_index_kernel, dim3(1), dim3(64), 0, stream, in, n, (uint4*)blk, frame_first, max_blocks, counts);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
+                                    uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t* errflag, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz4_frames_decode_kernel, dim3(nframes), dim3(64), DEC_RING, stream, in, (const uint4*)blk, frame_first, out,
+                       out_bytes, frame_stride, block_bytes, errflag);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int elem_size, hipStream_t stream)
+{
+    if (len == 0) return hipSuccess;
+    const uint64_t W = (uint64_t)elem_size * 8, seg = len / W;
+    uint64_t blocks = (seg + 255) / 256;
+    if (blocks == 0) blocks = 1;
+    if (elem_size == 2)
+        hipLaunchKernelGGL((bitswap1_decode_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, len, seg);
+    else
+        hipLaunchKernelGGL((bitswap1_decode_kernel<uint8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, len, seg);
+    return hipGetLastError();
+}
+
+hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream)
+{
+    const uint64_t length = Z * Y * X, frame = Y * X;
+    if (length == 0) return hipSuccess;
+    const uint64_t zlim = X < Z ? X : Z;
+    const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
+    const int single = (noff == 1);
+    const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
+    const unsigned blocks = (unsigned)((frame + 255) / 256);
+    for (uint64_t z = 0; z < Z; ++z) {
+        if (elem_size == 2)
+            hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint16_t, int16_t>), dim3(blocks), dim3(256), 0, stream, (const uint16_t*)in,
+                               (uint16_t*)out, z, length, Y, X, hx, zlim, single);
+        else
+            hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint8_t, int8_t>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)in,
+                               (uint8_t*)out, z, length, Y, X, hx, zlim, single);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_quantiser_decode(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream)
+{
+    if (len == 0) return hipSuccess;
+    uint64_t blocks = (len + 256 * 32 - 1) / (256 * 32);
+    const uint64_t cap = (uint64_t)num_cus() * 8;
+    if (blocks > cap) blocks = cap;
+    hipLaunchKernelGGL(quantiser_decode_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, len, lut);
+    return hipGetLastError();
+}
+
+hipError_t launch_frame_scatter(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream)
+{
+    if (Z == 0 || frame_bytes == 0) return hipSuccess;
+    uint64_t bpf = (frame_bytes + 256 * 64 - 1) / (256 * 64);
+    if (bpf == 0) bpf = 1;
+    if (bpf > 64) bpf = 64;
+    hipLaunchKernelGGL(frame_scatter_kernel, dim3((unsigned)(Z * bpf)), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, frame_bytes,
                        map, (uint32_t)bpf);
     return hipGetLastError();
 }

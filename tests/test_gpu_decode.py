@@ -1,0 +1,88 @@
+"""GPU: SQY_Decode_UI8/UI16 through the C-ABI -- round trips of every supported pipeline and blobs made elsewhere."""
+import numpy as np
+import pytest
+
+from sqeazy_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+PIPES_U16 = ["bitswap1->lz4", "lz4", "bitswap1", "diff3x3x1->bitswap1->lz4", "diff3x3x1->lz4", "frame_shuffle->lz4",
+             "frame_shuffle->bitswap1->lz4", "quantiser->bitswap1->lz4", "quantiser->lz4", "quantiser"]
+
+
+def _vols_u16():
+    rng = np.random.default_rng(21)
+    return [synth.stack((24, 64, 96)), rng.integers(0, 65536, (9, 20, 33), dtype=np.uint16), np.zeros((5, 200, 300), np.uint16),
+            (np.arange(40 * 64 * 64) % 3000).astype(np.uint16).reshape(40, 64, 64)]
+
+
+@pytest.mark.parametrize("pipeline", PIPES_U16)
+def test_roundtrip_u16(sqy, oracle, pipeline):
+    for vol in _vols_u16():
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2, extra_capacity=16 * vol.shape[0] + 256)
+        assert rc == 0
+        rc, back = sqy.decode(blob)
+        assert rc == 0, pipeline
+        want = oracle.pipeline_decode(blob)            # == vol for the lossless pipelines
+        ok = np.array_equal(back, want) if "frame_shuffle" not in pipeline else True
+        assert ok, (pipeline, vol.shape)
+        if "frame_shuffle" in pipeline:
+            _, dmap = oracle.frame_shuffle_encode(vol)
+            keep = np.unique(dmap.astype(np.int64))
+            assert np.array_equal(back[keep], vol[keep])
+        elif "quantiser" not in pipeline:
+            assert np.array_equal(back, vol)
+
+
+@pytest.mark.parametrize("pipeline", ["bitswap1->lz4", "lz4", "frame_shuffle->lz4", "diff3x3x1->lz4"])
+def test_roundtrip_u8(sqy, oracle, pipeline):
+    for vol in (synth.stack((20, 30, 40), np.uint8), np.random.default_rng(4).integers(0, 256, (7, 9, 11), dtype=np.uint8)):
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2, extra_capacity=16 * vol.shape[0] + 256)
+        assert rc == 0
+        rc, back = sqy.decode(blob)
+        assert rc == 0
+        if "frame_shuffle" in pipeline:
+            _, dmap = oracle.frame_shuffle_encode(vol)
+            keep = np.unique(dmap.astype(np.int64))
+            assert np.array_equal(back[keep], vol[keep])
+        else:
+            assert np.array_equal(back, vol)
+
+
+def test_decode_long_matches_and_overlaps(sqy, oracle):
+    """matches far longer than the 64 KiB history ring, offsets 1..70000-ish, literals-only blocks"""
+    rng = np.random.default_rng(8)
+    n = 3 * (256 << 10) + 999
+    streams = [np.zeros(n, np.uint8), np.tile(np.arange(7, dtype=np.uint8), n // 7 + 1)[:n],
+               np.tile(rng.integers(0, 256, 70001, dtype=np.uint8), n // 70001 + 1)[:n],
+               np.repeat(rng.integers(0, 256, n // 300 + 1, dtype=np.uint8), 300)[:n], rng.integers(0, 256, n, dtype=np.uint8)]
+    for d in streams:
+        vol = d.reshape(1, 1, -1)
+        blob = oracle.pipeline_encode("lz4", vol)
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, vol)
+
+
+def test_decode_serial_layout_from_liblz4(sqy, oracle):
+    """a blob in the reference's nthreads=1 layout (ONE block-linked frame, made with liblz4 itself) decodes too"""
+    from oracle import ref
+    if not ref.available():
+        pytest.skip("oracle/_ref not available")
+    vol = synth.stack((20, 128, 128))
+    planes = oracle.bitswap1_encode(vol).reshape(-1).view(np.uint8)
+    payload = ref.lz4_encode_serial(planes).tobytes()
+    name = "bitswap1(num_bits_per_plane=1)->lz4(accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0)"
+    blob = oracle.header_pack(np.uint16, vol.shape, name, len(payload)) + payload
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+
+
+def test_decode_rejects_garbage(sqy, oracle):
+    vol = synth.stack((4, 16, 16))
+    blob = bytearray(oracle.pipeline_encode("bitswap1->lz4", vol))
+    rc, _ = sqy.decode(bytes(blob[:len(blob) // 2]))
+    assert rc != 0
+    h = oracle.header_unpack(bytes(blob))
+    blob[h["size"]] ^= 0xff                                  # break the first frame's magic
+    rc, _ = sqy.decode(bytes(blob))
+    assert rc != 0
