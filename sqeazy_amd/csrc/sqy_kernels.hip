@@ -490,11 +490,13 @@ struct Lz4Out {
 // SQY_LZ4_DIAG (tools/lz4_diag.hip only): per-phase cycle accounting with s_memtime; never set in the product build
 #ifdef SQY_LZ4_DIAG
 #define SQY_DIAG_ARG , unsigned long long* __restrict__ diag
+#define SQY_REASON(i) do { dreason[i] += 1; } while (0)
 #define SQY_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
                           __builtin_amdgcn_s_waitcnt(0xC07F); dacc[i] += t_ - tprev; tprev = t_; dcnt[i] += 1; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SQY_DIAG_ARG
 #define SQY_STAMP(i) do { } while (0)
+#define SQY_REASON(i) do { } while (0)
 #endif
 
 __global__ __launch_bounds__(64)
@@ -502,7 +504,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
-    unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dreason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long tprev = __builtin_amdgcn_s_memtime();
 #endif
     __shared__ uint32_t table[4096];
@@ -520,10 +522,19 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     w.issue();
     Lz4Out o;
     o.dst = (SQY_GLB uint8_t*)dst; o.ob = (lds_u8*)stage; o.base = 0; o.lane = lane;
+    // Table entry = position << tsh | tag, tag = tsh-bit hash of the 4 bytes at that position.  Positions stay in the
+    // high bits, so entries order like positions (ds_max commit, flag bit 31 free) and a tag mismatch proves that the
+    // candidate's first 4 bytes differ -- no read of a far candidate just to reject it.  An empty bucket means
+    // "position 0" in liblz4, so the table starts out as entry(0).
+    const uint32_t pos_bits = n > 1 ? 32u - (uint32_t)__builtin_clz(n - 1) : 1u;
+    const uint32_t tsh = 31u - pos_bits;                       // >= 9 for chunks up to 4 MiB
+    const uint32_t tmask = (1u << tsh) - 1u;
+    auto tag_of = [&](uint32_t seq32) -> uint32_t { return (seq32 * 2654435761u) >> (32u - tsh); };
     {
+        const uint32_t e0 = n >= 4 ? tag_of(glb_ld_u32((glb_u8*)src)) : 0u;
         uint4* t4 = reinterpret_cast<uint4*>(table);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) t4[i * 64 + lane] = make_uint4(0, 0, 0, 0);
+        for (int i = 0; i < 16; ++i) t4[i * 64 + lane] = make_uint4(e0, e0, e0, e0);
     }
     __syncthreads();
 
@@ -549,7 +560,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             uint32_t bkl = 0xffffffffu;      // bytes known equal in front of (ip, match) for the winner (0..3 exact), ~0 = unknown
             bool batch_done = false;         // fast path handled table commit
             uint32_t nvalid = 64, next_P = 0;
-            bool lean_handover = false;      // lean path found the winner but leaves the rest to the generic tail
 
             // ---------------------------------------------------------------------------------------
             // lean path: the batch right after a match (anchor == P, put2 == P-2), winner among the first 15
@@ -566,42 +576,56 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 {   // LZ4_putPosition(P - 2): its five bytes are the top half of b4 and the low three of s16.x (lane 0)
                     const uint32_t x2 = __builtin_amdgcn_alignbit(s16.x, b4, 16);
                     const uint32_t h2 = lz4_hash5_32(x2, s16.x >> 16);
-                    if (lane == 0) table[h2] = P - 2u;
+                    if (lane == 0) table[h2] = ((P - 2u) << tsh) | tag_of(x2);
                     put2 = 0xffffffffu;
                 }
-                const uint32_t old = table[h];
-                const uint32_t dist = pos - old;
-                const bool near = dist <= LZ4_MAXD;
+                const uint32_t mytag = tag_of(s16.x);
+                SQY_STAMP(1);
+                const uint32_t oe = table[h];
+                const uint32_t old = oe >> tsh;
+                const bool near = (pos - old) <= LZ4_MAXD && (oe & tmask) == mytag;    // tag differs: cannot match, skip it
                 const bool cin = near && old >= wlo4;
+                SQY_STAMP(2);
                 const uint4 c16 = w.lds128(old);
                 const uint32_t cb4 = w.lds32(old - 4u);
-                const uint64_t mm = ballot(cin && c16.x == s16.x);
-                const uint64_t fm = ballot(near && old < wlo4);
+                // every lane evaluates itself as the winner: forward bytes, catch-up, flags -- one packed word
+                const uint32_t d = first_diff16(s16, c16);                            // 0..16
+                const bool hit = cin && d >= 4u;
+                const uint32_t xb = b4 ^ cb4;
+                const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;       // equal bytes in front, 4 = maybe more
+                const uint32_t lim = (uint32_t)lane < old ? (uint32_t)lane : old;      // ip - anchor = lane, match > 0
+                const uint32_t back = bk < lim ? bk : lim;
+                const uint32_t slow_back = (bk == 4u && lim > 4u) ? 1u : 0u;
+                const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
+                // "spoils the prefix": a far candidate (needs a global read) or an earlier probe in the same bucket
+                const bool spoil = (near && !cin) | (h == h1) | (h == h2s) | (h == h3) | (h == h4);
+                const uint32_t packed = (d - 4u) | (back << 8) | (slow_back << 16);
+                const uint64_t mm = ballot(hit);
+                const uint64_t sp = ballot(spoil);
                 const uint32_t f0 = mm ? ctz64(mm) : 64u;
-                bool ok = f0 <= 14u && (fm & ((1ull << f0) - 1ull)) == 0;
-                if (ok && f0 != 0) {
-                    if (f0 <= 4) {
-                        const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
-                        ok = ballot(((h == h1) | (h == h2s) | (h == h3) | (h == h4)) && (uint32_t)lane <= f0) == 0;
-                    } else {
-                        for (uint32_t c = 1; c <= f0; ++c)
-                            if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { ok = false; break; }
-                    }
+                // lanes <= 4 are fully covered by the four DPP compares; beyond that fall back to the readlane loop
+                bool ok = f0 <= 14u && (sp & ((2ull << f0) - 1ull)) == 0;
+#ifdef SQY_LZ4_DIAG
+                if (mm == 0) SQY_REASON(0);
+                else if (f0 > 14u) SQY_REASON(1);
+                else if (ballot(near && !cin) & ((2ull << f0) - 1ull)) SQY_REASON(2);
+                else if (!ok) SQY_REASON(3);
+#endif
+                if (ok && f0 > 4u) {
+                    for (uint32_t c = 5; c <= f0; ++c)
+                        if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { ok = false; break; }
                 }
+                SQY_STAMP(3);
                 if (ok) {
                     const uint32_t mt0 = lane_read(old, f0);
+                    const uint32_t pk = lane_read(packed, f0);
                     const uint32_t ip0 = P + f0;
-                    // forward: bytes 4..15 of the winner's 16-byte compare
-                    const uint32_t dy = lane_read(s16.y ^ c16.y, f0), dz = lane_read(s16.z ^ c16.z, f0), dw = lane_read(s16.w ^ c16.w, f0);
-                    uint32_t ml;
+                    uint32_t ml = pk & 0xffu;                                           // 0..12
                     bool settled = true;
-                    if (dy) ml = (uint32_t)__builtin_ctz(dy) >> 3;
-                    else if (dz) ml = 4u + ((uint32_t)__builtin_ctz(dz) >> 3);
-                    else if (dw) ml = 8u + ((uint32_t)__builtin_ctz(dw) >> 3);
-                    else {
+                    if (ml == 12u) {
                         // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (both resident, clear of matchlimit)
-                        const uint32_t d = (uint32_t)lane * 16u;
-                        const uint32_t g = first_diff16(w.lds128(ip0 + 16u + d), w.lds128(mt0 + 16u + d));
+                        const uint32_t dd = (uint32_t)lane * 16u;
+                        const uint32_t g = first_diff16(w.lds128(ip0 + 16u + dd), w.lds128(mt0 + 16u + dd));
                         const uint64_t nf = ballot(g != 16u);
                         if (nf) {
                             const uint32_t l = ctz64(nf);
@@ -611,19 +635,15 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                             settled = false;
                         }
                     }
-                    // backward catch-up, bounded by the literals (ip0 - anchor = f0) and the candidate position
-                    const uint32_t xb = lane_read(b4 ^ cb4, f0);
-                    const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;
-                    const uint32_t lim = f0 < mt0 ? f0 : mt0;
-                    // commit probes 0..f0 (positions only grow)
-                    if ((uint32_t)lane <= f0) atomicMax(&table[h], pos);
-                    if (settled && (bk < 4u || lim <= 4u)) {
-                        const uint32_t back = bk < lim ? bk : lim;
-                        const uint32_t lit = f0 - back;                               // < 15
-                        const uint32_t matchCode = ml + back;
+                    SQY_STAMP(4);
+                    if ((uint32_t)lane <= f0) atomicMax(&table[h], (pos << tsh) | mytag);   // commit probes 0..f0 (positions only grow)
+                    if (settled && (pk >> 16) == 0u) {
+                        const uint32_t bck = (pk >> 8) & 0xffu;
+                        const uint32_t lit = f0 - bck;                                  // < 15
+                        const uint32_t matchCode = ml + bck;
                         const uint32_t offset = ip0 - mt0;
                         const uint32_t ml_ext = matchCode >= 15u ? (matchCode - 15u) / 255u + 1u : 0u;
-                        const uint32_t seq_bytes = 1u + lit + 2u + ml_ext;            // <= 1 + 14 + 2 + 5
+                        const uint32_t seq_bytes = 1u + lit + 2u + ml_ext;              // <= 1 + 14 + 2 + 5
                         // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
                         if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
                             op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; break; }
@@ -643,85 +663,23 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         if (ipn >= mflimitPlusOne) break;
                         put2 = ipn - 2u;
                         P = ipn;
-                        SQY_STAMP(1);
-                        continue;                                                     // U stays 0
+                        SQY_STAMP(5);
+                        continue;                                                       // U stays 0
                     }
                     // winner known, but the match runs past the wide round or the catch-up past 4 bytes: generic tail
-                    f = f0; fcand = mt0; ipf = ip0; fwl = ml; fw_exact = settled; bkl = bk < 4u ? bk : 0xffffffffu;
-                    batch_done = true;
-                    lean_handover = true;
-                }
-                SQY_STAMP(2);
-            }
-
-            // ---------------------------------------------------------------------------------------
-            // fast path: 64 probes at consecutive positions, everything they touch resident in the ring
-            // ---------------------------------------------------------------------------------------
-            const bool step1 = (U + 64u <= 66u);                                  // all 64 advances are 1
-            const bool interior = step1 && P >= w.wlo + 4u && P + 64u + 16u <= w.hi_valid() && P + 64u <= mflimitPlusOne - 1u &&
-                                  P + 64u + 16u + 12u <= matchlimit;
-            if (interior && !lean_handover) {
-                const uint32_t pos = P + (uint32_t)lane;
-                const uint4 s16 = w.lds128(pos);
-                const uint32_t b4 = w.lds32(pos - 4u);
-                if (put2 != 0xffffffffu) {
-                    const uint32_t h2 = lz4_hash5(w.rd64(put2));
-                    if (lane == 0) table[h2] = put2;
-                    put2 = 0xffffffffu;
-                }
-                const uint32_t h = lz4_hash5(((uint64_t)s16.y << 32) | s16.x);
-                const uint32_t old = table[h];
-                const bool near = (old + LZ4_MAXD >= pos);
-                const bool cin = near && old >= w.wlo + 4u;                        // old + 16 <= pos + 16 <= hi_valid
-                uint32_t fw = 0xffffffffu, bk = 0xffffffffu;
-                bool hit = false;
-                if (cin) {
-                    const uint4 c16 = w.lds128(old);
-                    const uint32_t cb4 = w.lds32(old - 4u);
-                    const uint32_t d = first_diff16(s16, c16);
-                    hit = d >= 4u;
-                    fw = d - 4u;                                                   // 0..12 (12 = all 16 equal: continue wide)
-                    const uint32_t x = b4 ^ cb4;
-                    bk = x ? ((uint32_t)__builtin_clz(x) >> 3) : 4u;               // equal bytes counted backwards, 4 = maybe more
-                } else if (near) {
-                    hit = w.rd32(old) == s16.x;                                    // far candidate: global read, lengths unknown
-                }
-                const uint64_t mm = ballot(hit);
-                const uint32_t f0 = mm ? ctz64(mm) : 64u;
-                bool clean = false;
-                if (f0 == 0) {
-                    clean = true;
-                } else if (f0 <= 4) {
-                    // any probe <= f0 sharing a hash bucket with an earlier probe of this batch?
-                    // DPP reads need their SOURCE lane active: fetch the four neighbours with every lane enabled,
-                    // combine afterwards (a short-circuit && would mask the low lanes off and hide the hazard)
-                    const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
-                    const bool hz = (h == h1) | (h == h2s) | (h == h3) | (h == h4);   // lanes < d read ~0, never a hash
-                    clean = (ballot(hz && (uint32_t)lane <= f0) == 0);
-                } else if (f0 <= 24) {
-                    clean = true;
-                    for (uint32_t c = 1; c <= f0; ++c) {
-                        if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { clean = false; break; }
-                    }
-                }
-                if (clean) {
-                    f = f0;
-                    fcand = lane_read(old, f);
-                    ipf = P + f;
-                    fwl = lane_read(fw, f);
-                    bkl = lane_read(bk, f);
-                    fw_exact = fwl < 12u;
-                    if (fwl > 12u) fwl = 0u;                                        // far candidate: nothing known
-                    if ((uint32_t)lane <= f) atomicMax(&table[h], pos);             // commit probes 0..f (positions grow)
+                    if (!settled) SQY_REASON(4); else SQY_REASON(5);
+                    f = f0; fcand = mt0; ipf = ip0; fwl = ml; fw_exact = settled;
+                    bkl = (pk >> 16) ? 0xffffffffu : ((pk >> 8) & 0xffu);
                     batch_done = true;
                 }
-                SQY_STAMP(3);
+                
             }
 
             // ---------------------------------------------------------------------------------------
             // generic path: any step schedule, chunk borders, hazards -- exact but slower
             // ---------------------------------------------------------------------------------------
             if (!batch_done) {
+                if (U != 0) SQY_REASON(6); else SQY_REASON(7);
                 const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
                 const uint32_t ustar = 64 * (s_first + 1) - 62;          // first unified index with step s_first+1
                 const uint32_t u = U + lane;
@@ -737,23 +695,26 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 if (valid) seq = w.rd64(pos);
                 if (put2 != 0xffffffffu) {
                     // LZ4_putPosition(ip - 2) of the previous match, fetched together with this batch's sequences
-                    const uint32_t h2 = lz4_hash5(w.rd64(put2));
-                    if (lane == 0) table[h2] = put2;
+                    const uint64_t s2 = w.rd64(put2);
+                    const uint32_t h2 = lz4_hash5(s2);
+                    if (lane == 0) table[h2] = (put2 << tsh) | tag_of((uint32_t)s2);
                     put2 = 0xffffffffu;
                 }
-                uint32_t h = 0, old = 0, fl = 0;
+                uint32_t h = 0, oe = 0, fl = 0;
                 if (valid) {
                     h = lz4_hash5(seq);
-                    old = table[h];
+                    oe = table[h];
                     atomicMax(&table[h], 0x80000000u | (uint32_t)(63 - lane));
                     fl = table[h];
                 }
                 const uint32_t seq32 = (uint32_t)seq;
+                const uint32_t mytag = tag_of(seq32);
+                const uint32_t old = oe >> tsh;
                 const bool hazard = valid && ((63u - (fl & 63u)) != (uint32_t)lane);
                 const uint64_t hz = ballot(hazard);
 
-                // non-hazard lanes: candidate is the pre-batch table entry
-                const bool near = valid && !hazard && (old + LZ4_MAXD >= pos);
+                // non-hazard lanes: candidate is the pre-batch table entry; a differing tag rules it out without a read
+                const bool near = valid && !hazard && (old + LZ4_MAXD >= pos) && (oe & tmask) == mytag;
                 uint32_t m32 = ~seq32;
                 if (near) m32 = w.rd32(old);
                 const uint64_t mm = ballot(near && m32 == seq32);
@@ -779,11 +740,11 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
                 // table: restore, then insert the committed prefix (lanes <= f, or every valid lane)
                 const uint32_t ncommit = (f < 64) ? f + 1 : nvalid;
-                if (valid) table[h] = old;
-                if ((uint32_t)lane < ncommit) atomicMax(&table[h], pos);
+                if (valid) table[h] = oe;
+                if ((uint32_t)lane < ncommit) atomicMax(&table[h], (pos << tsh) | mytag);
                 if (f < 64) ipf = lane_read(pos, f);
                 next_P = lane_read(nxt, 63);
-                SQY_STAMP(3);
+                
             } else {
                 next_P = P + 64u;
             }
@@ -883,7 +844,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     back = ip0 - ip;
                 }
             }
-            SQY_STAMP(4);
+            
 
             const uint32_t ip = ip0 - back;                           // start of the match after catch-up
             const uint32_t lit = ip - anchor;
@@ -939,11 +900,11 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 }
                 o.base = op;
             }
-            SQY_STAMP(5);
+            
 
             const uint32_t ipn = q + ml;                              // = original ip + 4 + forward count
             anchor = ipn;
-            SQY_STAMP(6);
+            
             if (ipn >= mflimitPlusOne) break;
 
             // LZ4_putPosition(ip - 2) happens at the top of the next batch; the unified batch then starts with
@@ -951,6 +912,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             put2 = ipn - 2;
             P = ipn;
             U = 0;
+            SQY_STAMP(6);
         }
     }
 
@@ -977,7 +939,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     }
     if (lane == 0) csize[blk] = failed ? 0u : op;
 #ifdef SQY_LZ4_DIAG
-    if (lane == 0) for (int i = 0; i < 8; ++i) { diag[blk * 16 + i] = dacc[i]; diag[blk * 16 + 8 + i] = dcnt[i]; }
+    if (lane == 0) for (int i = 0; i < 8; ++i) { diag[blk * 24 + i] = dacc[i]; diag[blk * 24 + 8 + i] = dcnt[i]; diag[blk * 24 + 16 + i] = dreason[i]; }
 #endif
 }
 
