@@ -12,6 +12,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -36,26 +39,20 @@ using sqy::StageKind;
 
 // ---- per-kernel timing -------------------------------------------------------------------------
 struct ProfEntry { std::string name; double ms = 0; long launches = 0; };
-struct PendingEvent { int entry; hipEvent_t a, b; };
-bool g_prof_on = false;
+struct PendingEvent { const char* name; hipEvent_t a, b; };
+std::atomic<bool> g_prof_on{false};
+std::mutex g_prof_mu;
 std::vector<ProfEntry> g_prof;
-std::vector<PendingEvent> g_pending;
-
-int prof_index(const char* name)
-{
-    for (size_t i = 0; i < g_prof.size(); ++i) if (g_prof[i].name == name) return (int)i;
-    g_prof.push_back(ProfEntry{name, 0, 0});
-    return (int)g_prof.size() - 1;
-}
 
 struct ProfScope {
     hipStream_t s;
     PendingEvent ev{};
+    std::vector<PendingEvent>* sink;
     bool on;
-    ProfScope(const char* name, hipStream_t stream) : s(stream), on(g_prof_on)
+    ProfScope(const char* name, hipStream_t stream, std::vector<PendingEvent>* pending) : s(stream), sink(pending), on(g_prof_on.load())
     {
         if (!on) return;
-        ev.entry = prof_index(name);
+        ev.name = name;
         if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
         hipEventRecord(ev.a, s);
     }
@@ -63,25 +60,29 @@ struct ProfScope {
     {
         if (!on) return;
         hipEventRecord(ev.b, s);
-        g_pending.push_back(ev);
+        sink->push_back(ev);
     }
 };
 
-void prof_collect()
+void prof_collect(std::vector<PendingEvent>& pending)
 {
-    for (PendingEvent& p : g_pending) {
+    for (PendingEvent& p : pending) {
         float ms = 0;
         if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
-            g_prof[p.entry].ms += ms;
-            g_prof[p.entry].launches += 1;
+            std::lock_guard<std::mutex> lock(g_prof_mu);
+            size_t i = 0;
+            for (; i < g_prof.size(); ++i) if (g_prof[i].name == p.name) break;
+            if (i == g_prof.size()) g_prof.push_back(ProfEntry{p.name, 0, 0});
+            g_prof[i].ms += ms;
+            g_prof[i].launches += 1;
         }
         hipEventDestroy(p.a);
         hipEventDestroy(p.b);
     }
-    g_pending.clear();
+    pending.clear();
 }
 
-// ---- HBM workspace (grow-only, one per device, guarded by g_mu) ----------------------------------
+// ---- HBM workspace (grow-only; one per leased context) ------------------------------------------
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -104,26 +105,63 @@ struct DevBuf {
 struct Workspace {
     DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small;
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
-    void release()
+    void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
         io_src.release(); io_dst.release(); small.release();
-        if (pinned) { hipHostFree(pinned); pinned = nullptr; }
     }
 };
 
-constexpr int kMaxDev = 16;
-std::mutex g_mu;
-Workspace g_ws[kMaxDev];
+// A context = one HBM workspace + one private stream.  Concurrent C-ABI calls (the reference is re-entrant:
+// every call builds its own pipeline object, src/sqeazy.cpp:123) each lease their own context, so two host
+// threads encoding different volumes overlap on the GPU instead of queueing behind a lock.
+struct Context {
+    Workspace ws;
+    hipStream_t stream = nullptr;       // used when the caller brings no stream (host-pointer entry points)
+    std::vector<PendingEvent> pending;
+    bool busy = false;
+};
 
-Workspace* workspace()
-{
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
-    Workspace* w = &g_ws[dev];
-    if (!w->pinned && hipHostMalloc(&w->pinned, 4096, hipHostMallocDefault) != hipSuccess) return nullptr;
-    return w;
-}
+constexpr int kMaxDev = 16;
+constexpr size_t kMaxCtxPerDev = 8;
+std::mutex g_pool_mu;
+std::condition_variable g_pool_cv;
+std::vector<std::unique_ptr<Context>> g_pool[kMaxDev];
+
+struct ContextLease {
+    Context* ctx = nullptr;
+    ContextLease()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return;
+        std::unique_lock<std::mutex> lock(g_pool_mu);
+        for (;;) {
+            for (auto& c : g_pool[dev]) if (!c->busy) { ctx = c.get(); break; }
+            if (ctx) break;
+            if (g_pool[dev].size() < kMaxCtxPerDev) {
+                std::unique_ptr<Context> c(new Context());
+                if (hipHostMalloc(&c->ws.pinned, 4096, hipHostMallocDefault) != hipSuccess) return;
+                if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return;
+                ctx = c.get();
+                g_pool[dev].push_back(std::move(c));
+                break;
+            }
+            g_pool_cv.wait(lock);
+        }
+        ctx->busy = true;
+    }
+    ~ContextLease()
+    {
+        if (!ctx) return;
+        {
+            std::lock_guard<std::mutex> lock(g_pool_mu);
+            ctx->busy = false;
+        }
+        g_pool_cv.notify_one();
+    }
+    ContextLease(const ContextLease&) = delete;
+    ContextLease& operator=(const ContextLease&) = delete;
+};
 
 bool device_present()
 {
@@ -133,7 +171,7 @@ bool device_present()
 
 // ---- encode --------------------------------------------------------------------------------------
 // The body of dynamic_pipeline::encode (dynamic_pipeline.hpp:560-616) on device buffers.
-int encode_on_device(const char* pipeline_c, const void* d_src, const long* shape, unsigned rank, int elem_size,
+int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, const long* shape, unsigned rank, int elem_size,
                      void* d_dst, uint64_t dst_capacity, long* dstlength, int nthreads, hipStream_t stream)
 {
     if (!pipeline_c || !d_src || !shape || !d_dst || !dstlength) return 1;
@@ -165,8 +203,8 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
     }
     const uint64_t raw_bytes = len * (uint64_t)elem_size;
 
-    Workspace* ws = workspace();
-    if (!ws) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    Workspace* ws = &cx.ws;
+    std::vector<PendingEvent>* pend = &cx.pending;
 
     // ---- walk the stages ----
     const uint8_t* cur = static_cast<const uint8_t*>(d_src);
@@ -191,7 +229,7 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
             case StageKind::bitswap1: {
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
-                ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream);
+                ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
                 if (cur_elem == 2)
                     SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream));
                 else
@@ -218,7 +256,7 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 }
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
-                ProfScope ps("diff3x3x1", stream);
+                ProfScope ps("diff3x3x1", stream, pend);
                 SQY_HIP(sqy::launch_diff3x3x1(cur, out, Z, Y, X, cur_elem, stream));
                 cur = out;
                 break;
@@ -233,7 +271,7 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 float* d_sums = static_cast<float*>(ws->small.p);
                 uint64_t* d_map = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(ws->small.p) + ((Z * 4 + 15) & ~(uint64_t)15));
                 {
-                    ProfScope ps("frame_metric", stream);
+                    ProfScope ps("frame_metric", stream, pend);
                     SQY_HIP(sqy::launch_frame_metric(cur, Z, per_frame, cur_elem, d_sums, stream));
                 }
                 std::vector<float> sums(Z);
@@ -245,7 +283,7 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
                 {
-                    ProfScope ps("frame_gather", stream);
+                    ProfScope ps("frame_gather", stream, pend);
                     SQY_HIP(sqy::launch_frame_gather(cur, out, Z, per_frame * (uint64_t)cur_elem, d_map, stream));
                 }
                 SQY_HIP(hipStreamSynchronize(stream));                     // `map` (host) is read by the async copy above
@@ -260,7 +298,7 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 uint32_t* d_histo = static_cast<uint32_t*>(ws->small.p);
                 uint8_t* d_lut = static_cast<uint8_t*>(ws->small.p) + 65536 * sizeof(uint32_t);
                 {
-                    ProfScope ps("histogram_u16", stream);
+                    ProfScope ps("histogram_u16", stream, pend);
                     SQY_HIP(sqy::launch_histogram_u16(reinterpret_cast<const uint16_t*>(cur), cur_len, d_histo, stream));
                 }
                 std::vector<uint32_t> histo(65536);
@@ -273,7 +311,7 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 uint8_t* out = next_buf(cur_len);
                 if (!out) return 1;
                 {
-                    ProfScope ps("quantiser_apply", stream);
+                    ProfScope ps("quantiser_apply", stream, pend);
                     SQY_HIP(sqy::launch_quantiser_apply_u16(reinterpret_cast<const uint16_t*>(cur), out, cur_len, d_lut, stream));
                 }
                 SQY_HIP(hipStreamSynchronize(stream));                     // lut_encode (host) is read by the async copy above
@@ -302,12 +340,12 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
                 if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
                 if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
                 {
-                    ProfScope ps("lz4_chunks", stream);
+                    ProfScope ps("lz4_chunks", stream, pend);
                     SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                    static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream));
                 }
                 {
-                    ProfScope ps("lz4_frame_scan", stream);
+                    ProfScope ps("lz4_frame_scan", stream, pend);
                     SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
                                                        static_cast<uint64_t*>(ws->frame_off.p), stream));
                 }
@@ -357,17 +395,17 @@ int encode_on_device(const char* pipeline_c, const void* d_src, const long* shap
             const unsigned char empty[11] = {0x04, 0x22, 0x4D, 0x18, fd[0], fd[1], (unsigned char)hc, 0, 0, 0, 0};
             SQY_HIP(hipMemcpyAsync(out + hdr.size(), empty, sizeof(empty), hipMemcpyHostToDevice, stream));
         } else {
-            ProfScope ps("lz4_frame_gather", stream);
+            ProfScope ps("lz4_frame_gather", stream, pend);
             SQY_HIP(sqy::launch_lz4_frame_gather(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                  static_cast<uint32_t*>(ws->csize.p), static_cast<uint64_t*>(ws->frame_off.p),
                                                  out + hdr.size(), fd[1], hc, lz4_nchunks, stream));
         }
     } else {
-        ProfScope ps("payload_copy", stream);
+        ProfScope ps("payload_copy", stream, pend);
         SQY_HIP(hipMemcpyAsync(out + hdr.size(), cur, payload_bytes, hipMemcpyDeviceToDevice, stream));
     }
     SQY_HIP(hipStreamSynchronize(stream));
-    if (g_prof_on) prof_collect();
+    if (g_prof_on.load()) prof_collect(cx.pending);
     *dstlength = (long)blob_bytes;
     (void)raw_bytes;
     return 0;
@@ -386,9 +424,10 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
         }
     }
     if (!device_present()) { std::fprintf(stderr, "[sqeazy]\t no MI355X (HIP device) visible: sqeazy_amd has no CPU path\n"); return 1; }
-    std::lock_guard<std::mutex> lock(g_mu);
-    Workspace* ws = workspace();
-    if (!ws) return 1;
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    Workspace* ws = &lease.ctx->ws;
+    hipStream_t stream = lease.ctx->stream;
     uint64_t len = 1;
     for (unsigned i = 0; i < rank; ++i) {
         if (shape[i] <= 0) return 1;
@@ -408,23 +447,24 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
     // documented "error 1 - destination buffer is not large enough" (inc/sqeazy.h:105) is returned instead.
     const uint64_t bound = dst_capacity >= 0 ? (uint64_t)dst_capacity : Pipeline::from_string(pipeline).max_encoded_size(raw, elem_size);
     if (ws->io_src.ensure(std::max<uint64_t>(raw, 16)) || ws->io_dst.ensure(std::max<uint64_t>(bound, 16))) return 1;
-    SQY_HIP(hipMemcpy(ws->io_src.p, src, raw, hipMemcpyHostToDevice));
+    SQY_HIP(hipMemcpyAsync(ws->io_src.p, src, raw, hipMemcpyHostToDevice, stream));
     long out_len = 0;
-    const int rc = encode_on_device(pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, nullptr);
+    const int rc = encode_on_device(*lease.ctx, pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, stream);
     if (rc) return rc;
-    SQY_HIP(hipMemcpy(dst, ws->io_dst.p, (size_t)out_len, hipMemcpyDeviceToHost));
+    SQY_HIP(hipMemcpyAsync(dst, ws->io_dst.p, (size_t)out_len, hipMemcpyDeviceToHost, stream));
+    SQY_HIP(hipStreamSynchronize(stream));
     *dstlength = out_len;
     return 0;
 }
 
 // ---- decode --------------------------------------------------------------------------------------
 // dynamic_pipeline::decode (dynamic_pipeline.hpp:740-846): tail filters^-1, sink^-1, head filters^-1 in reverse.
-int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t dst_capacity, int want_elem, hipStream_t stream)
+int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t dst_capacity, int want_elem, hipStream_t stream)
 {
     if (!d_src_v || !d_dst) return 1;
     const uint8_t* d_src = static_cast<const uint8_t*>(d_src_v);
-    Workspace* ws = workspace();
-    if (!ws) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    Workspace* ws = &cx.ws;
+    std::vector<PendingEvent>* pend = &cx.pending;
 
     // header: fetch a prefix of the blob, grow until the delimiter is inside
     std::vector<char> head;
@@ -488,7 +528,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
                 uint32_t* counts = static_cast<uint32_t*>(ws->csize.p);          // [0..2] index result, [4] decode error flag
                 SQY_HIP(hipMemsetAsync(counts, 0, 32, stream));
                 {
-                    ProfScope ps("lz4_frame_index", stream);
+                    ProfScope ps("lz4_frame_index", stream, pend);
                     SQY_HIP(sqy::launch_lz4_frame_index(cur, cur_bytes, blk, frame_first, max_blocks, counts, stream));
                 }
                 uint32_t hc[3];
@@ -503,7 +543,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
                 uint8_t* out = out_buf(si, total);
                 if (!out) return 1;
                 {
-                    ProfScope ps("lz4_frames_decode", stream);
+                    ProfScope ps("lz4_frames_decode", stream, pend);
                     SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, counts + 4, stream));
                 }
                 uint32_t bad = 0;
@@ -516,7 +556,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
             case StageKind::bitswap1: {
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
-                ProfScope ps("bitswap1_decode", stream);
+                ProfScope ps("bitswap1_decode", stream, pend);
                 SQY_HIP(sqy::launch_bitswap1_decode(cur, out, n, e_in, stream));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
@@ -525,7 +565,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
                 if (h.shape.size() != 3) return 1;
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
-                ProfScope ps("diff3x3x1_decode", stream);
+                ProfScope ps("diff3x3x1_decode", stream, pend);
                 SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, stream));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
@@ -541,7 +581,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 {
-                    ProfScope ps("quantiser_decode", stream);
+                    ProfScope ps("quantiser_decode", stream, pend);
                     SQY_HIP(sqy::launch_quantiser_decode(cur, reinterpret_cast<uint16_t*>(out), n, static_cast<const uint16_t*>(ws->small.p), stream));
                 }
                 SQY_HIP(hipStreamSynchronize(stream));
@@ -564,7 +604,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 {
-                    ProfScope ps("frame_scatter", stream);
+                    ProfScope ps("frame_scatter", stream, pend);
                     SQY_HIP(sqy::launch_frame_scatter(cur, out, Z, h.shape[1] * h.shape[2] * (uint64_t)e_in, static_cast<const uint64_t*>(ws->small.p), stream));
                 }
                 SQY_HIP(hipStreamSynchronize(stream));
@@ -577,7 +617,7 @@ int decode_on_device(const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t
     }
     if (cur != d_dst) SQY_HIP(hipMemcpyAsync(d_dst, cur, raw_bytes, hipMemcpyDeviceToDevice, stream));
     SQY_HIP(hipStreamSynchronize(stream));
-    if (g_prof_on) prof_collect();
+    if (g_prof_on.load()) prof_collect(cx.pending);
     return 0;
 }
 
@@ -587,17 +627,19 @@ int decode_from_host(const char* src, long srclength, char* dst, int elem_size)
     const sqy::HeaderInfo h = sqy::header_unpack(src, src + srclength);
     if (!h.valid) { std::fprintf(stderr, "[sqeazy]\t unable to find a sqy header in the blob\n"); return 1; }
     if (!device_present()) { std::fprintf(stderr, "[sqeazy]\t no MI355X (HIP device) visible: sqeazy_amd has no CPU path\n"); return 1; }
-    std::lock_guard<std::mutex> lock(g_mu);
-    Workspace* ws = workspace();
-    if (!ws) return 1;
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    Workspace* ws = &lease.ctx->ws;
+    hipStream_t stream = lease.ctx->stream;
     uint64_t n = 1;
     for (uint64_t d : h.shape) n *= d;
     const uint64_t raw = n * (uint64_t)h.elem_size();
     if (ws->io_src.ensure(std::max<uint64_t>((uint64_t)srclength, 16)) || ws->io_dst.ensure(std::max<uint64_t>(raw, 16))) return 1;
-    SQY_HIP(hipMemcpy(ws->io_src.p, src, (size_t)srclength, hipMemcpyHostToDevice));
-    const int rc = decode_on_device(ws->io_src.p, (uint64_t)srclength, ws->io_dst.p, raw, elem_size, nullptr);
+    SQY_HIP(hipMemcpyAsync(ws->io_src.p, src, (size_t)srclength, hipMemcpyHostToDevice, stream));
+    const int rc = decode_on_device(*lease.ctx, ws->io_src.p, (uint64_t)srclength, ws->io_dst.p, raw, elem_size, stream);
     if (rc) return rc;
-    SQY_HIP(hipMemcpy(dst, ws->io_dst.p, raw, hipMemcpyDeviceToHost));
+    SQY_HIP(hipMemcpyAsync(dst, ws->io_dst.p, raw, hipMemcpyDeviceToHost, stream));
+    SQY_HIP(hipStreamSynchronize(stream));
     return 0;
 }
 
@@ -736,16 +778,18 @@ int SQY_Decode_UI8(const char* src, long srclength, char* dst, int nthreads)
 int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
                                       long dst_capacity, long* dstlength, int nthreads, void* hip_stream)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
-    return encode_on_device(pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream));
 }
 
 int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
                                      long dst_capacity, long* dstlength, int nthreads, void* hip_stream)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
-    return encode_on_device(pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream));
 }
 
@@ -763,31 +807,32 @@ int SQYAMD_PipelineEncode_UI8_Cap(const char* pipeline, const char* src, long* s
 
 int SQYAMD_Decode_UI16_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
-    return decode_on_device(d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 2, static_cast<hipStream_t>(hip_stream));
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    return decode_on_device(*lease.ctx, d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 2, static_cast<hipStream_t>(hip_stream));
 }
 
 int SQYAMD_Decode_UI8_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
-    return decode_on_device(d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 1, static_cast<hipStream_t>(hip_stream));
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    return decode_on_device(*lease.ctx, d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 1, static_cast<hipStream_t>(hip_stream));
 }
 
 void SQYAMD_Profile_Enable(int enable)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
-    g_prof_on = enable != 0;
+    g_prof_on.store(enable != 0);
 }
 
 void SQYAMD_Profile_Reset(void)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     g_prof.clear();
 }
 
 const char* SQYAMD_Profile_Get(int i, double* total_ms, long* launches)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
+    std::lock_guard<std::mutex> lock(g_prof_mu);
     if (i < 0 || (size_t)i >= g_prof.size()) return nullptr;
     if (total_ms) *total_ms = g_prof[i].ms;
     if (launches) *launches = g_prof[i].launches;
@@ -796,9 +841,10 @@ const char* SQYAMD_Profile_Get(int i, double* total_ms, long* launches)
 
 void SQYAMD_Release_Workspace(void)
 {
-    std::lock_guard<std::mutex> lock(g_mu);
     int dev = 0;
-    if (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < kMaxDev) g_ws[dev].release();
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return;
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    for (auto& c : g_pool[dev]) if (!c->busy) c->ws.release_buffers();
 }
 
 const char* SQYAMD_Version(void) { return "sqeazy_amd 0.1.0 (gfx950, sqy header 0.5.2)"; }
