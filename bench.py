@@ -101,6 +101,7 @@ def main():
     gather_buf = torch.empty(world * cap, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
     import queue
     import threading
+    sys.setswitchinterval(1e-4)      # caller threads hand the GIL over promptly (default 5 ms would show up as whole milliseconds per step)
     inflight = max(1, args.inflight)
     # every caller thread owns a stream and two output buffers (the gather of step s may still read one while s+inflight encodes)
     streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
@@ -135,6 +136,7 @@ def main():
         for th in threads:
             th.start()
         pending, nxt, last_n = {}, 0, 0
+        t_start = time.perf_counter()
         while nxt < k:
             s_, t, b, n = done_q.get()
             if s_ < 0:
@@ -148,6 +150,8 @@ def main():
                 free_q[t2].put(b2)
                 last_n = n2
                 nxt += 1
+                if os.environ.get("SQY_BENCH_TRACE"):
+                    print("step %d done at %.2f ms (thread %d)" % (nxt - 1, (time.perf_counter() - t_start) * 1e3, t2), file=sys.stderr)
         for th in threads:
             th.join()
         if errors:
