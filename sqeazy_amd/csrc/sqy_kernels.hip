@@ -285,6 +285,72 @@ void diff3x3x1_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t Z,
     }
 }
 
+// 16-bit fast path for the common geometry (every row's reach 1 + hx stays inside its row, i.e. Z-2 <= X-1):
+// thread = 8 consecutive voxels of one row (one 16-byte load per source row), grid = (row pieces, Y, Z), so no
+// coordinate is ever recovered by division.  Rewritten voxels: 1 <= z < zlim, 1 <= y <= Y-2, 1 <= x < 1 + hx.
+__global__ __launch_bounds__(256)
+void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint32_t Y, uint32_t X,
+                               uint32_t hx, uint32_t zlim)
+{
+    const uint32_t z = blockIdx.z, y = blockIdx.y;
+    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 8u;
+    if (x0 >= X) return;
+    const uint64_t frame = (uint64_t)Y * X;
+    const uint64_t row = (uint64_t)z * frame + (uint64_t)y * X;
+    const uint16_t* __restrict__ cur = in + row;
+    uint16_t* __restrict__ dst = out + row;
+    const bool full = x0 + 8u <= X;
+    uint32_t v[8];
+    if (full && (((uintptr_t)(cur + x0)) & 15) == 0) {
+        const uint4 c = *reinterpret_cast<const uint4*>(cur + x0);
+        v[0] = c.x & 0xffffu; v[1] = c.x >> 16; v[2] = c.y & 0xffffu; v[3] = c.y >> 16;
+        v[4] = c.z & 0xffffu; v[5] = c.z >> 16; v[6] = c.w & 0xffffu; v[7] = c.w >> 16;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (x0 + j < X) ? cur[x0 + j] : 0u;
+    }
+    const bool row_touched = z >= 1u && z < zlim && y >= 1u && y + 2u <= Y && hx > 0u && x0 < 1u + hx && x0 + 8u > 1u;
+    if (row_touched) {
+        // column sums over the three rows of plane z-1 for columns x0-1 .. x0+8 (wrapping 16-bit arithmetic)
+        uint32_t colsum[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) colsum[j] = 0;
+        const uint16_t* __restrict__ up = in + row - frame;
+#pragma unroll
+        for (int dy = -1; dy <= 1; ++dy) {
+            const uint16_t* __restrict__ r = up + (int64_t)dy * X;
+            uint32_t e[10];
+            e[0] = (x0 > 0u) ? r[x0 - 1] : 0u;                       // only used for x = x0 >= 1
+            if (full && (((uintptr_t)(r + x0)) & 15) == 0) {
+                const uint4 c = *reinterpret_cast<const uint4*>(r + x0);
+                e[1] = c.x & 0xffffu; e[2] = c.x >> 16; e[3] = c.y & 0xffffu; e[4] = c.y >> 16;
+                e[5] = c.z & 0xffffu; e[6] = c.z >> 16; e[7] = c.w & 0xffffu; e[8] = c.w >> 16;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) e[1 + j] = (x0 + j < X) ? r[x0 + j] : 0u;
+            }
+            e[9] = (x0 + 8u < X) ? r[x0 + 8] : 0u;
+#pragma unroll
+            for (int j = 0; j < 10; ++j) colsum[j] += e[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t x = x0 + j;
+            if (x >= 1u && x < 1u + hx && x < X) {
+                const uint32_t sum = (colsum[j] + colsum[j + 1] + colsum[j + 2]) & 0xffffu;   // T sum wraps mod 2^16
+                const uint32_t mean = (sum * 58255u) >> 19;                                    // sum / 9 for sum < 65536
+                v[j] = (v[j] - mean) & 0xffffu;
+            }
+        }
+    }
+    if (full && (((uintptr_t)(dst + x0)) & 15) == 0) {
+        *reinterpret_cast<uint4*>(dst + x0) = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (x0 + j < X) dst[x0 + j] = (uint16_t)v[j];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LZ4 block compressor: one wavefront per chunk, hash table (4096 x u32) in LDS.
 //
@@ -1136,11 +1202,41 @@ void frame_metric_kernel(const T* __restrict__ in, uint64_t Z, uint64_t per_fram
     const T* p = in + z * per_frame;
     float sum = 0.f;
     uint64_t i = 0;
-    const uint32_t per_vec = 16 / sizeof(T);
+    constexpr uint32_t per_vec = 16 / sizeof(T);
     if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
         const uint4* pv = reinterpret_cast<const uint4*>(p);
         const uint64_t nv = per_frame / per_vec;
-        for (uint64_t v = 0; v < nv; ++v) {
+        uint64_t v = 0;
+        // one cache line (8 x 16 B) per step, two steps ahead in registers: the loads of steps k+1 and k+2 travel while
+        // step k is added -- strictly in index order, the additions are the reference's rounding sequence
+        if (nv >= 24) {
+            uint4 a[8], b[8], c[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { a[k] = pv[k]; b[k] = pv[8 + k]; }
+            for (; v + 24 <= nv; v += 8) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) c[k] = pv[v + 16 + k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const uint32_t w[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (sizeof(T) == 2) {
+                            sum = sum + (float)(w[j] & 0xffffu);
+                            sum = sum + (float)(w[j] >> 16);
+                        } else {
+                            sum = sum + (float)(w[j] & 0xffu);
+                            sum = sum + (float)((w[j] >> 8) & 0xffu);
+                            sum = sum + (float)((w[j] >> 16) & 0xffu);
+                            sum = sum + (float)(w[j] >> 24);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 8; ++k) { a[k] = b[k]; b[k] = c[k]; }
+            }
+        }
+        for (; v < nv; ++v) {
             const uint4 x = pv[v];
             const uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
@@ -1160,6 +1256,109 @@ void frame_metric_kernel(const T* __restrict__ in, uint64_t Z, uint64_t per_fram
     }
     for (; i < per_frame; ++i) sum = sum + (float)p[i];
     metric[z] = sum;                           // the division by Y*X happens on the host (sqy::frame_shuffle_order)
+}
+
+// Block-parallel EXACT evaluation of the same sequential binary32 sum.
+// While the running sum S (an integer) stays inside one binade [2^e, 2^(e+1)) with ulp u = 2^(e-23) >= 2, adding an
+// integer v rounds S+v to a multiple of u (ties to the even multiple).  With r = v mod u, d = v div u and p = parity of
+// S/u:  r < u/2 rounds down (delta -r), r > u/2 rounds up (delta u-r), r == u/2 is a tie: down when p^(d&1) == 0, else up,
+// and the parity after a tie is always 0.  So apart from ties every element is "parity ^= c, delta += const": a wave
+// splits a 4 KiB block over its 64 lanes, each lane walks its 64 bytes once (tracking what happens before its first tie
+// symbolically), and the 64 lane results are chained in lane order.  Blocks that may cross into the next binade (at most
+// a dozen per frame) are added by the lanes one after the other with real v_add_f32.  Below 2^24 everything is exact.
+// Checked against numpy's sequential float32 cumsum (tests) and, end to end, against the oracle's C loop.
+template <typename T>
+__global__ __launch_bounds__(64)
+void frame_metric_scan_kernel(const T* __restrict__ in, uint64_t per_frame, float* __restrict__ metric)
+{
+    constexpr uint32_t EPL = 64 / sizeof(T);              // elements per lane and block (64 bytes)
+    constexpr uint32_t BLK = 64 * EPL;
+    const int lane = threadIdx.x;
+    const T* __restrict__ p = in + (uint64_t)blockIdx.x * per_frame;
+    const uint64_t nblk = (per_frame + BLK - 1) / BLK;
+    uint64_t S = 0;                                        // the float sum, held exactly (it is an integer < 2^40)
+
+    for (uint64_t b = 0; b < nblk; ++b) {
+        // this lane's 64 bytes (zero padded past the frame: adding 0 never changes the sum)
+        uint32_t x[EPL];
+        const uint64_t e0 = b * BLK + (uint64_t)lane * EPL;
+        if (e0 + EPL <= per_frame) {
+            const uint4* q = reinterpret_cast<const uint4*>(p + e0);
+            uint32_t w[16];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const uint4 t = q[j]; w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w; }
+#pragma unroll
+            for (uint32_t i = 0; i < EPL; ++i)
+                x[i] = sizeof(T) == 1 ? (w[i >> 2] >> (8 * (i & 3))) & 0xffu : (w[i >> 1] >> (16 * (i & 1))) & 0xffffu;
+        } else {
+#pragma unroll
+            for (uint32_t i = 0; i < EPL; ++i) x[i] = (e0 + i < per_frame) ? (uint32_t)p[e0 + i] : 0u;
+        }
+        uint32_t lsum = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < EPL; ++i) lsum += x[i];
+        uint32_t tot = lsum;                               // <= 4096 * 255 or 2048 * 65535 < 2^28
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
+        tot = sgpr(tot);
+
+        if (S + tot < (1ull << 24)) { S += tot; continue; }            // exact regime
+        uint32_t k = 0;
+        bool safe = false;
+        if (S >= (1ull << 24)) {
+            const uint32_t e = 63u - (uint32_t)__builtin_clzll(S);
+            k = e - 23u;
+            safe = S + tot + (uint64_t)BLK * ((1ull << k) >> 1) < (1ull << (e + 1));
+        }
+        if (!safe) {
+            // the block may change binade: lanes add their elements one after the other with the hardware's float add
+            float sf = (float)S;                                       // S is representable: it IS the float sum
+            for (int L = 0; L < 64; ++L) {
+                if (lane == L) {
+#pragma unroll
+                    for (uint32_t i = 0; i < EPL; ++i) sf = sf + (float)x[i];
+                }
+                sf = __builtin_bit_cast(float, lane_read(__builtin_bit_cast(uint32_t, sf), L));
+            }
+            S = (uint64_t)sf;
+            continue;
+        }
+        const uint32_t u = 1u << k, half = u >> 1, um = u - 1u;
+        uint32_t seen = 0, C0 = 0, pcur = 0;
+        int32_t D0 = 0, Df = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < EPL; ++i) {
+            const uint32_t r = x[i] & um, dbit = (x[i] >> k) & 1u;
+            const bool tie = r == half, up = r > half;
+            const int32_t dl_nt = up ? (int32_t)(u - r) : -(int32_t)r;  // delta of a non-tie
+            if (!seen) {
+                if (tie) { seen = 1; C0 ^= dbit; pcur = 0; }             // its own delta is settled when the lanes are chained
+                else { C0 ^= dbit ^ (up ? 1u : 0u); D0 += dl_nt; }
+            } else {
+                const uint32_t base = pcur ^ dbit;
+                if (tie) { Df += base ? (int32_t)half : -(int32_t)half; pcur = 0; }
+                else { Df += dl_nt; pcur = base ^ (up ? 1u : 0u); }
+            }
+        }
+        // chain the 64 lane results in order
+        uint32_t par = (uint32_t)(S >> k) & 1u;
+        int64_t delta = 0;
+        const uint32_t flags = seen | (C0 << 1) | (pcur << 2);
+        for (int L = 0; L < 64; ++L) {
+            const uint32_t fl = lane_read(flags, L);
+            const int32_t d0 = (int32_t)lane_read((uint32_t)D0, L);
+            if (fl & 1u) {
+                const uint32_t base = par ^ ((fl >> 1) & 1u);
+                delta += d0 + (base ? (int32_t)half : -(int32_t)half) + (int32_t)lane_read((uint32_t)Df, L);
+                par = (fl >> 2) & 1u;
+            } else {
+                delta += d0;
+                par ^= (fl >> 1) & 1u;
+            }
+        }
+        S = (uint64_t)((int64_t)(S + tot) + delta);
+    }
+    if (lane == 0) metric[blockIdx.x] = (float)S;          // exact: S is the float sum
 }
 
 // out frame i = in frame map[i]
@@ -1446,6 +1645,12 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
     const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
     const int single = (noff == 1);
     const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
+    if (elem_size == 2 && !single && hx + 2 <= X && Y <= 65535 && Z <= 65535 && X <= 0xffffffffull) {   // reach stays inside the row, x+1 too
+        const unsigned bx = (unsigned)((X + 2047) / 2048);
+        hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel, dim3(bx, (unsigned)Y, (unsigned)Z), dim3(256), 0, stream, (const uint16_t*)in,
+                           (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim);
+        return hipGetLastError();
+    }
     uint64_t blocks = (length + 255) / 256;
     const uint64_t cap = (uint64_t)num_cus() * 16;
     if (blocks > cap) blocks = cap;
@@ -1515,6 +1720,15 @@ hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t
 hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream)
 {
     if (Z == 0) return hipSuccess;
+    if ((per_frame * (uint64_t)elem_size) % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && Z <= 0x7fffffffull &&
+        per_frame * (elem_size == 2 ? 65535ull : 255ull) < (1ull << 39)) {
+        // one wavefront per frame, block-parallel exact emulation of the sequential float sum
+        if (elem_size == 2)
+            hipLaunchKernelGGL((frame_metric_scan_kernel<uint16_t>), dim3((unsigned)Z), dim3(64), 0, stream, (const uint16_t*)in, per_frame, metric);
+        else
+            hipLaunchKernelGGL((frame_metric_scan_kernel<uint8_t>), dim3((unsigned)Z), dim3(64), 0, stream, (const uint8_t*)in, per_frame, metric);
+        return hipGetLastError();
+    }
     const unsigned blocks = (unsigned)((Z + 63) / 64);
     if (elem_size == 2)
         hipLaunchKernelGGL((frame_metric_kernel<uint16_t>), dim3(blocks), dim3(64), 0, stream, (const uint16_t*)in, Z, per_frame, metric);

@@ -64,7 +64,8 @@ def test_lz4_structured_bytes(sqy, oracle):
 
 
 def test_diff_bitswap_lz4_u16(sqy, oracle):
-    for shape in ((16, 32, 48), (8, 8, 8), (40, 12, 20), (6, 8, 16)):
+    for shape in ((16, 32, 48), (8, 8, 8), (40, 12, 20), (6, 8, 16), (9, 10, 8), (10, 10, 8), (12, 33, 2100), (5, 3, 3), (2, 9, 17),
+                  (1, 4, 4), (30, 7, 5)):
         vol = synth.stack(shape)
         rc, blob = sqy.encode("diff3x3x1->bitswap1->lz4", vol, nthreads=2)
         assert rc == 0
@@ -117,6 +118,23 @@ def test_frame_shuffle(sqy, oracle, pipeline):
     # (header + 8-byte-per-frame map + raw payload cannot fit 2*header + raw)
     rc, blob = sqy.encode("frame_shuffle", np.random.default_rng(5).integers(0, 256, (40000, 4, 4), dtype=np.uint8), nthreads=2)
     assert rc == 1
+
+
+@pytest.mark.parametrize("dtype,frame,hi", [(np.uint16, (512, 512), 65536), (np.uint16, (300, 1000), 65536), (np.uint16, (333, 1001), 4096),
+                                            (np.uint8, (1024, 1024), 256), (np.uint8, (1000, 1008), 256), (np.uint8, (999, 1001), 256),
+                                            (np.uint16, (2048, 2048), 65536)])
+def test_frame_shuffle_rounding_order(sqy, oracle, dtype, frame, hi):
+    """Every frame is a permutation of the same voxels: the integer sums are equal, so the frame order is decided by
+    nothing but the rounding sequence of the reference's sequential binary32 sum (frame_shuffle.hpp's std::accumulate
+    into a float).  Any deviation of the device's block-parallel evaluation from that sequence reorders the frames."""
+    rng = np.random.default_rng(11)
+    base = rng.integers(0, hi, frame[0] * frame[1], dtype=np.int64).astype(dtype)
+    vol = np.stack([rng.permutation(base).reshape(frame) for _ in range(24)])
+    vol[3] = np.sort(base).reshape(frame)             # sorted ascending / descending: the extreme rounding paths
+    vol[4] = np.sort(base)[::-1].reshape(frame)
+    rc, blob = sqy.encode("frame_shuffle", vol, nthreads=2, extra_capacity=4096)
+    assert rc == 0
+    assert blob == oracle.pipeline_encode("frame_shuffle", vol)
 
 
 @pytest.mark.parametrize("pipeline", ["quantiser->bitswap1->lz4", "quantiser", "quantiser->lz4"])
