@@ -37,6 +37,7 @@ def build(force=False, verbose=False):
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
     common = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
+    common += os.environ.get("SQY_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments (tools/), never set by the product build
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=" + ARCH] + common + ["-c", os.path.join(CSRC, src), "-o", obj]

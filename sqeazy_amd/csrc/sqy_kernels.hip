@@ -52,10 +52,13 @@ typedef SQY_GLB const uint8_t glb_u8;
 __device__ __forceinline__ uint32_t lds_ld_u8(const lds_u8* p) { return *p; }
 __device__ __forceinline__ uint32_t lds_ld_u32(const lds_u8* p) { return reinterpret_cast<const SQY_LDS pk_u32*>(p)->v; }
 __device__ __forceinline__ uint64_t lds_ld_u64(const lds_u8* p) { return reinterpret_cast<const SQY_LDS pk_u64*>(p)->v; }
+typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));
+// ONE 16-byte load: four field loads get split by the optimiser into a b64 now and a conditional b64 later when only
+// the low half decides a branch -- a second dependent LDS round trip on the parse's critical path
 __device__ __forceinline__ uint4 lds_ld_u128(const lds_u8* p)
 {
-    const SQY_LDS pk_u128* q = reinterpret_cast<const SQY_LDS pk_u128*>(p);
-    return make_uint4(q->x, q->y, q->z, q->w);
+    const v4u_any t = *reinterpret_cast<const SQY_LDS v4u_any*>(p);
+    return make_uint4(t.x, t.y, t.z, t.w);
 }
 __device__ __forceinline__ uint32_t glb_ld_u8(glb_u8* p) { return *p; }
 __device__ __forceinline__ uint32_t glb_ld_u32(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u32*>(p)->v; }
@@ -652,19 +655,34 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 const bool near = (pos - old) <= LZ4_MAXD && (oe & tmask) == mytag;    // tag differs: cannot match, skip it
                 const bool cin = near && old >= wlo4;
                 SQY_STAMP(2);
-                const uint4 c16 = w.lds128(old);
-                const uint32_t cb4 = w.lds32(old - 4u);
+                uint4 c16 = w.lds128(old);
+                uint32_t cb4 = w.lds32(old - 4u);
                 // every lane evaluates itself as the winner: forward bytes, catch-up, flags -- one packed word
-                const uint32_t d = first_diff16(s16, c16);                            // 0..16
-                const bool hit = cin && d >= 4u;
+                uint32_t d = first_diff16(s16, c16);                                  // 0..16
+                // candidates behind the ring (older than ~6 KiB, tag equal so very likely real matches) that sit in front
+                // of the first ring hit decide the batch: fetch just those from global memory and stay on this path
+                const bool far = near && !cin && lane < 15;
+                {
+                    const uint64_t ml_ = ballot(cin && d >= 4u);
+                    const uint64_t upto = ml_ ? ((2ull << ctz64(ml_)) - 1ull) : ~0ull;
+                    if (ballot(far) & upto) {
+                        if (far) {
+                            c16 = glb_ld_u128(w.src + old);                            // old + 16 <= pos + 15 < matchlimit
+                            cb4 = old >= 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src) << (8u * (4u - old)));
+                            d = first_diff16(s16, c16);
+                        }
+                        SQY_REASON(2);
+                    }
+                }
+                const bool hit = (cin || far) && d >= 4u;
                 const uint32_t xb = b4 ^ cb4;
                 const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;       // equal bytes in front, 4 = maybe more
                 const uint32_t lim = (uint32_t)lane < old ? (uint32_t)lane : old;      // ip - anchor = lane, match > 0
                 const uint32_t back = bk < lim ? bk : lim;
                 const uint32_t slow_back = (bk == 4u && lim > 4u) ? 1u : 0u;
                 const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
-                // "spoils the prefix": a far candidate (needs a global read) or an earlier probe in the same bucket
-                const bool spoil = (near && !cin) | (h == h1) | (h == h2s) | (h == h3) | (h == h4);
+                // "spoils the prefix": an earlier probe in the same bucket
+                const bool spoil = (h == h1) | (h == h2s) | (h == h3) | (h == h4);
                 const uint32_t packed = (d - 4u) | (back << 8) | (slow_back << 16);
                 const uint64_t mm = ballot(hit);
                 const uint64_t sp = ballot(spoil);
@@ -674,7 +692,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 #ifdef SQY_LZ4_DIAG
                 if (mm == 0) SQY_REASON(0);
                 else if (f0 > 14u) SQY_REASON(1);
-                else if (ballot(near && !cin) & ((2ull << f0) - 1ull)) SQY_REASON(2);
                 else if (!ok) SQY_REASON(3);
 #endif
                 if (ok && f0 > 4u) {
@@ -691,7 +708,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     if (ml == 12u) {
                         // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (both resident, clear of matchlimit)
                         const uint32_t dd = (uint32_t)lane * 16u;
-                        const uint32_t g = first_diff16(w.lds128(ip0 + 16u + dd), w.lds128(mt0 + 16u + dd));
+                        uint4 mside;                                                    // uniform: candidate side resident?
+                        if (mt0 >= w.wlo) mside = w.lds128(mt0 + 16u + dd); else mside = glb_ld_u128(w.src + mt0 + 16u + dd);
+                        const uint32_t g = first_diff16(w.lds128(ip0 + 16u + dd), mside);
                         const uint64_t nf = ballot(g != 16u);
                         if (nf) {
                             const uint32_t l = ctz64(nf);
@@ -713,9 +732,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
                         if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
                             op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; break; }
+#ifndef SQY_LZ4_NOEMIT
                         o.reserve(op, seq_bytes);
                         const uint32_t k = (uint32_t)lane;
-                        const uint32_t litbyte = w.lds8(P + k - 1u);                    // literal k-1 sits at anchor + k - 1 = P + k - 1
+                        const uint32_t litbyte = b4 >> 24;                              // literal k-1 sits at anchor + k - 1 = P + k - 1 = pos - 1
                         uint32_t v = ((lit << 4) | (matchCode < 15u ? matchCode : 15u));
                         v = (k >= 1u && k <= lit) ? litbyte : v;
                         v = (k == lit + 1u) ? (offset & 0xffu) : v;
@@ -723,6 +743,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         const uint32_t j = k - (lit + 3u);
                         v = (k > lit + 2u) ? ((j + 1u < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1u) * 255u)) : v;
                         if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
+#endif
                         op += seq_bytes;
                         const uint32_t ipn = ip0 + 4u + ml;
                         anchor = ipn;
@@ -925,7 +946,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (matchCode < 15 ? matchCode : 15u);
             const uint32_t seq_bytes = 1 + lit_ext + lit + 2 + ml_ext;
 
+#ifdef SQY_LZ4_NOEMIT
+            op += seq_bytes;
+            if (false) {
+#else
             if (seq_bytes <= 64 && lit < 15) {
+#endif
                 // whole sequence at once into the LDS stage: lane k writes byte k
                 o.reserve(op, seq_bytes);
                 const uint32_t k = (uint32_t)lane;
@@ -942,7 +968,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 }
                 if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
                 op += seq_bytes;
-            } else {
+            }
+#ifdef SQY_LZ4_NOEMIT
+            else if (false) {
+#else
+            else {
+#endif
                 o.flush(op);
                 if (lane == 0) dst[op] = (uint8_t)token;
                 op += 1;
