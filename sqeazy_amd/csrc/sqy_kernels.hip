@@ -13,6 +13,7 @@
 // No CUDA compatibility layer, no dual paths: this file only targets gfx950.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "sqy_kernels.h"
 
@@ -179,6 +180,46 @@ void bitswap1_u16_tiles(const uint16_t* __restrict__ in, uint16_t* __restrict__ 
         __builtin_amdgcn_wave_barrier();
 
         // plane b lives in segment 15-b; this tile contributes 512 words (1 KiB) per segment
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
+            const v4u val = {pl[b][0], pl[b][1], pl[b][2], pl[b][3]};
+            __builtin_nontemporal_store(val, dst + lane);
+        }
+    }
+}
+
+// Same tile, no LDS: every lane loads its own 256 contiguous bytes (16 x 16 B at a lane stride of 256 B; the eight
+// loads that share a 128-byte line are issued back to back, so the line is fetched once and hit in L1 after that).
+// Needs no LDS allocation at all, which matters when the CUs' LDS is held by resident LZ4 chunk waves of other calls
+// in flight: this kernel then still finds room (wave slots and registers only).
+__global__ __launch_bounds__(256)
+void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
+    for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
+        const v4u* src = reinterpret_cast<const v4u*>(in + tile * BSW_TILE_VOX) + lane * 16;
+        v4u v[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v[j] = src[j];
+        uint32_t pl[16][4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const v4u a0 = v[4 * q], a1 = v[4 * q + 1], b0 = v[4 * q + 2], b1 = v[4 * q + 3];
+            const uint32_t ga[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t gb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+            uint32_t r[16];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                r[15 - 2 * k] = __builtin_amdgcn_perm(gb[k], ga[k], 0x05040100u);
+                r[14 - 2 * k] = __builtin_amdgcn_perm(gb[k], ga[k], 0x07060302u);
+            }
+            transpose16x16_pairs(r);
+#pragma unroll
+            for (int b = 0; b < 16; ++b) pl[b][q] = r[b];
+        }
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
             v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
@@ -499,9 +540,16 @@ __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const Lz4Wind
 // index of the first differing byte of two 16-byte values (16 when equal)
 __device__ __forceinline__ uint32_t first_diff16(uint4 x, uint4 y)
 {
-    const uint64_t lo = ((uint64_t)(x.y ^ y.y) << 32) | (uint64_t)(x.x ^ y.x);
-    const uint64_t hi = ((uint64_t)(x.w ^ y.w) << 32) | (uint64_t)(x.z ^ y.z);
-    return lo ? (ctz64(lo) >> 3) : (hi ? 8 + (ctz64(hi) >> 3) : 16);
+    // ffs(v) - 1 is v_ffbl_b32: the bit index, or ~0 for v == 0.  "| 32 k" adds the dword offset to a real index and
+    // leaves the "no difference in this dword" marker above every index.  Straight-line on purpose: the branchy form
+    // (low half first, high half only if equal) costs two exec-mask regions per call on the parse's critical path.
+    const uint32_t t0 = (uint32_t)(__builtin_ffs((int)(x.x ^ y.x)) - 1);
+    const uint32_t t1 = (uint32_t)(__builtin_ffs((int)(x.y ^ y.y)) - 1) | 32u;
+    const uint32_t t2 = (uint32_t)(__builtin_ffs((int)(x.z ^ y.z)) - 1) | 64u;
+    const uint32_t t3 = (uint32_t)(__builtin_ffs((int)(x.w ^ y.w)) - 1) | 96u;
+    const uint32_t a = t0 < t1 ? t0 : t1, b = t2 < t3 ? t2 : t3;
+    const uint32_t m = a < b ? a : b;
+    return (m < 128u ? m : 128u) >> 3;
 }
 
 // number of equal leading bytes of chunk[a..a+maxlen) and chunk[b..b+maxlen), maxlen <= 16, b < a
@@ -617,6 +665,33 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         uint32_t P = 1, U = 1;           // first probe of the block: search from ip = 1 (table[hash(0)] = 0 is a no-op)
         uint32_t put2 = 0xffffffffu;     // position whose hash has to enter the table before the next batch (ip - 2)
 
+        // A sequence found by the lean path is written out one iteration LATER, between the issue of the next batch's
+        // ring reads and their first use: its ~70 instructions then run in the shadow of that LDS round trip.
+        bool pend = false;
+        uint32_t pe_lit = 0, pe_mcode = 0, pe_off = 0;
+        uint32_t pe_litv = 0;            // per lane: literal byte k-1 for lane k
+        auto emit_pending = [&]() {
+            pend = false;
+            const uint32_t lit = pe_lit, matchCode = pe_mcode, offset = pe_off;
+            const uint32_t ml_ext = matchCode >= 15u ? (matchCode - 15u) / 255u + 1u : 0u;
+            const uint32_t seq_bytes = 1u + lit + 2u + ml_ext;                      // <= 1 + 14 + 2 + 5
+            // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
+            if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
+                op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; return; }
+#ifndef SQY_LZ4_NOEMIT
+            o.reserve(op, seq_bytes);
+            const uint32_t k = (uint32_t)lane;
+            uint32_t v = ((lit << 4) | (matchCode < 15u ? matchCode : 15u));
+            v = (k >= 1u && k <= lit) ? pe_litv : v;
+            v = (k == lit + 1u) ? (offset & 0xffu) : v;
+            v = (k == lit + 2u) ? (offset >> 8) : v;
+            const uint32_t j = k - (lit + 3u);
+            v = (k > lit + 2u) ? ((j + 1u < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1u) * 255u)) : v;
+            if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
+#endif
+            op += seq_bytes;
+        };
+
         for (;;) {
             SQY_STAMP(7);
             w.ensure(P);
@@ -641,6 +716,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 const uint32_t wlo4 = w.wlo + 4u;
                 const uint4 s16 = w.lds128(pos);
                 const uint32_t b4 = w.lds32(pos - 4u);
+                if (pend) { emit_pending(); if (failed) break; }
                 const uint32_t h = lz4_hash5_32(s16.x, s16.y);
                 {   // LZ4_putPosition(P - 2): its five bytes are the top half of b4 and the low three of s16.x (lane 0)
                     const uint32_t x2 = __builtin_amdgcn_alignbit(s16.x, b4, 16);
@@ -727,24 +803,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         const uint32_t lit = f0 - bck;                                  // < 15
                         const uint32_t matchCode = ml + bck;
                         const uint32_t offset = ip0 - mt0;
-                        const uint32_t ml_ext = matchCode >= 15u ? (matchCode - 15u) / 255u + 1u : 0u;
-                        const uint32_t seq_bytes = 1u + lit + 2u + ml_ext;              // <= 1 + 14 + 2 + 5
-                        // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
-                        if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
-                            op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; break; }
-#ifndef SQY_LZ4_NOEMIT
-                        o.reserve(op, seq_bytes);
-                        const uint32_t k = (uint32_t)lane;
-                        const uint32_t litbyte = b4 >> 24;                              // literal k-1 sits at anchor + k - 1 = P + k - 1 = pos - 1
-                        uint32_t v = ((lit << 4) | (matchCode < 15u ? matchCode : 15u));
-                        v = (k >= 1u && k <= lit) ? litbyte : v;
-                        v = (k == lit + 1u) ? (offset & 0xffu) : v;
-                        v = (k == lit + 2u) ? (offset >> 8) : v;
-                        const uint32_t j = k - (lit + 3u);
-                        v = (k > lit + 2u) ? ((j + 1u < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1u) * 255u)) : v;
-                        if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
-#endif
-                        op += seq_bytes;
+                        pend = true; pe_lit = lit; pe_mcode = matchCode; pe_off = offset;
+                        pe_litv = b4 >> 24;                                             // literal k-1 sits at anchor + k - 1 = pos - 1
                         const uint32_t ipn = ip0 + 4u + ml;
                         anchor = ipn;
                         if (ipn >= mflimitPlusOne) break;
@@ -765,6 +825,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // ---------------------------------------------------------------------------------------
             // generic path: any step schedule, chunk borders, hazards -- exact but slower
             // ---------------------------------------------------------------------------------------
+            if (pend) { emit_pending(); if (failed) break; }
             if (!batch_done) {
                 if (U != 0) SQY_REASON(6); else SQY_REASON(7);
                 const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
@@ -1011,6 +1072,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             U = 0;
             SQY_STAMP(6);
         }
+        if (pend && !failed) emit_pending();
     }
 
     if (!failed) {
@@ -1639,7 +1701,13 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
     const bool aligned = (seg_words % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (aligned) n_tiles = (seg_words * 16) / BSW_TILE_VOX;
-    if (n_tiles) {
+    static const int bsw_mode = std::getenv("SQY_BSW_MODE") ? std::atoi(std::getenv("SQY_BSW_MODE")) : 0;
+    if (n_tiles && bsw_mode >= 1) {
+        const uint64_t want = (n_tiles + 3) / 4;
+        const uint64_t cap = (uint64_t)num_cus() * (uint64_t)(bsw_mode >= 2 ? bsw_mode : 8);
+        const unsigned grid = (unsigned)(want < cap ? want : cap);
+        hipLaunchKernelGGL(bitswap1_u16_regs, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words);
+    } else if (n_tiles) {
         const uint64_t want = (n_tiles + BSW_WAVES - 1) / BSW_WAVES;
         const uint64_t cap = (uint64_t)num_cus() * 2 * 4;   // 2 workgroups resident per CU (LDS), a few rounds each
         const unsigned grid = (unsigned)(want < cap ? want : cap);
