@@ -70,6 +70,15 @@ __device__ __forceinline__ uint4 glb_ld_u128(glb_u8* p)
     return make_uint4(q->x, q->y, q->z, q->w);
 }
 
+// One lane's LDS write must be seen by another lane's later LDS read.  The hardware keeps a wave's LDS operations in
+// order; what this stops is the COMPILER treating lanes as independent threads (it may turn "if (lane == k) t[h] = x;
+// y = t[h];" into a diamond whose load side runs first).
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
@@ -463,6 +472,7 @@ struct Lz4Window {
             *reinterpret_cast<SQY_LDS v4u*>(win + o) = val;
             if (j == 0 && o == 0) *reinterpret_cast<SQY_LDS v4u*>(win + LZ4_WIN) = val;   // mirror of ring[0..16)
         }
+        wave_lds_sync();                                       // other lanes read these bytes
         whi += LZ4_FB;
         if (whi - wlo > LZ4_WIN) wlo = whi - LZ4_WIN;
     }
@@ -585,6 +595,7 @@ struct Lz4Out {
     // write everything staged; afterwards base == op
     __device__ __forceinline__ void flush(uint32_t op)
     {
+        wave_lds_sync();                                       // staged bytes were written by other lanes
         const uint32_t cnt = op - base;
         const uint32_t nvec = cnt >> 4;
         for (uint32_t i = lane; i < nvec; i += 64) {
@@ -604,12 +615,16 @@ struct Lz4Out {
     __device__ __forceinline__ lds_u8* at(uint32_t o) const { return ob + (o - base); }
 };
 
-// SQY_LZ4_DIAG (tools/lz4_diag.hip only): per-phase cycle accounting with s_memtime; never set in the product build
+// SQY_LZ4_DIAG (tools/lz4_diag.hip only, never set in the product build): cycles of ONE region of the parse loop per
+// build, between mark SQY_DIAG_A and mark SQY_DIAG_B (s_memtime; one region at a time keeps the probe's own register and
+// issue cost out of the number), plus event counters.
 #ifdef SQY_LZ4_DIAG
 #define SQY_DIAG_ARG , unsigned long long* __restrict__ diag
 #define SQY_REASON(i) do { dreason[i] += 1; } while (0)
-#define SQY_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long t_ = __builtin_amdgcn_s_memtime(); \
-                          __builtin_amdgcn_s_waitcnt(0xC07F); dacc[i] += t_ - tprev; tprev = t_; dcnt[i] += 1; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define SQY_STAMP(i) do { \
+        if ((i) == SQY_DIAG_A) { __builtin_amdgcn_sched_barrier(0); dt0 = __builtin_amdgcn_s_memtime(); darmed = true; __builtin_amdgcn_sched_barrier(0); } \
+        else if ((i) == SQY_DIAG_B) { __builtin_amdgcn_sched_barrier(0); if (darmed) { dacc += __builtin_amdgcn_s_memtime() - dt0; dcnt += 1; darmed = false; } __builtin_amdgcn_sched_barrier(0); } \
+    } while (0)
 #else
 #define SQY_DIAG_ARG
 #define SQY_STAMP(i) do { } while (0)
@@ -621,8 +636,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
-    unsigned long long dacc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dcnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}, dreason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    unsigned long long tprev = __builtin_amdgcn_s_memtime();
+    unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool darmed = false;
 #endif
     __shared__ uint32_t table[4096];
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
@@ -693,9 +708,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         };
 
         for (;;) {
-            SQY_STAMP(7);
-            w.ensure(P);
             SQY_STAMP(0);
+            w.ensure(P);
 
             uint32_t f = 64, fcand = 0;      // first matching probe of the batch and its candidate
             uint32_t ipf = 0;                // its position
@@ -706,83 +720,82 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             uint32_t nvalid = 64, next_P = 0;
 
             // ---------------------------------------------------------------------------------------
-            // lean path: the batch right after a match (anchor == P, put2 == P-2), winner among the first 15
-            // probes with a resident candidate, fewer than 15 literals, match settled by the speculative compare or
-            // one wide round.  Straight-line, ring reads unconditional (ring offsets are always in bounds; the
-            // values only count where the masks say so), no global memory traffic.  Anything else falls through.
+            // lean loop: batches right after a match (anchor == P, put2 == P-2) whose winner sits among the first 15
+            // probes, with fewer than 15 literals and a match settled by the speculative 16-byte compare or one wide
+            // round.  Straight-line; ring reads are unconditional (ring offsets are always in bounds, the values only
+            // count where the masks say so).  Lane 15 does not probe: it hashes position P-2 alongside the others and
+            // performs LZ4_putPosition(ip - 2) with the same instructions.  Anything unusual leaves the loop for the
+            // generic path below, which redoes the batch from P.
             // ---------------------------------------------------------------------------------------
-            if (U == 0 && P >= w.wlo + 4u && P + 1200u <= w.hi_valid() && P + 1200u <= matchlimit) {
-                const uint32_t pos = P + (uint32_t)lane;
-                const uint32_t wlo4 = w.wlo + 4u;
-                const uint4 s16 = w.lds128(pos);
-                const uint32_t b4 = w.lds32(pos - 4u);
-                if (pend) { emit_pending(); if (failed) break; }
-                const uint32_t h = lz4_hash5_32(s16.x, s16.y);
-                {   // LZ4_putPosition(P - 2): its five bytes are the top half of b4 and the low three of s16.x (lane 0)
-                    const uint32_t x2 = __builtin_amdgcn_alignbit(s16.x, b4, 16);
-                    const uint32_t h2 = lz4_hash5_32(x2, s16.x >> 16);
-                    if (lane == 0) table[h2] = ((P - 2u) << tsh) | tag_of(x2);
+            bool finished = false;
+            if (U == 0) {
+                for (;;) {
+                    if (!(P >= w.wlo + 4u && P + 1200u <= w.hi_valid() && P + 1200u <= matchlimit)) break;
+                    SQY_STAMP(1);
+                    const bool putlane = lane == 15;
+                    const uint32_t pos = putlane ? P - 2u : P + (uint32_t)lane;
+                    const uint32_t wlo4 = w.wlo + 4u;
+                    const uint4 s16 = w.lds128(pos);
+                    const uint32_t b4 = w.lds32(pos - 4u);
+                    if (pend) { emit_pending(); if (failed) break; }
+                    SQY_STAMP(2);
+                    const uint32_t h = lz4_hash5_32(s16.x, s16.y);
+                    const uint32_t mytag = tag_of(s16.x);
+                    const uint32_t mine = (pos << tsh) | mytag;
+                    if (putlane) table[h] = mine;                                       // LZ4_putPosition(P - 2), before anybody looks
+                    wave_lds_sync();
                     put2 = 0xffffffffu;
-                }
-                const uint32_t mytag = tag_of(s16.x);
-                SQY_STAMP(1);
-                const uint32_t oe = table[h];
-                const uint32_t old = oe >> tsh;
-                const bool near = (pos - old) <= LZ4_MAXD && (oe & tmask) == mytag;    // tag differs: cannot match, skip it
-                const bool cin = near && old >= wlo4;
-                SQY_STAMP(2);
-                uint4 c16 = w.lds128(old);
-                uint32_t cb4 = w.lds32(old - 4u);
-                // every lane evaluates itself as the winner: forward bytes, catch-up, flags -- one packed word
-                uint32_t d = first_diff16(s16, c16);                                  // 0..16
-                // candidates behind the ring (older than ~6 KiB, tag equal so very likely real matches) that sit in front
-                // of the first ring hit decide the batch: fetch just those from global memory and stay on this path
-                const bool far = near && !cin && lane < 15;
-                {
-                    const uint64_t ml_ = ballot(cin && d >= 4u);
-                    const uint64_t upto = ml_ ? ((2ull << ctz64(ml_)) - 1ull) : ~0ull;
-                    if (ballot(far) & upto) {
-                        if (far) {
-                            c16 = glb_ld_u128(w.src + old);                            // old + 16 <= pos + 15 < matchlimit
-                            cb4 = old >= 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src) << (8u * (4u - old)));
-                            d = first_diff16(s16, c16);
+                    SQY_STAMP(3);
+                    const uint32_t oe = table[h];
+                    const uint32_t old = oe >> tsh;
+                    // tag differs: the candidate's first four bytes differ, it cannot match
+                    const bool near = (uint32_t)lane < 15u && (pos - old) <= LZ4_MAXD && (oe & tmask) == mytag;
+                    const bool cin = near && old >= wlo4;
+                    SQY_STAMP(4);
+                    uint4 c16 = w.lds128(old);
+                    uint32_t cb4 = w.lds32(old - 4u);
+                    // every lane evaluates itself as the winner: forward bytes, catch-up, flags -- one packed word
+                    uint32_t d = first_diff16(s16, c16);                                // 0..16
+                    SQY_STAMP(5);
+                    // candidates behind the ring (older than ~6 KiB, tag equal so very likely real matches) that sit in
+                    // front of the first ring hit decide the batch: fetch just those from global memory and stay here
+                    const bool far = near && !cin;
+                    const uint64_t farm = ballot(far);
+                    if (farm) {
+                        const uint64_t ml_ = ballot(cin && d >= 4u);
+                        const uint64_t upto = ml_ ? ((2ull << ctz64(ml_)) - 1ull) : ~0ull;
+                        if (farm & upto) {
+                            if (far) {
+                                c16 = glb_ld_u128(w.src + old);                         // old + 16 <= pos + 15 < matchlimit
+                                cb4 = old >= 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src) << (8u * (4u - old)));
+                                d = first_diff16(s16, c16);
+                            }
+                            SQY_REASON(2);
                         }
-                        SQY_REASON(2);
                     }
-                }
-                const bool hit = (cin || far) && d >= 4u;
-                const uint32_t xb = b4 ^ cb4;
-                const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;       // equal bytes in front, 4 = maybe more
-                const uint32_t lim = (uint32_t)lane < old ? (uint32_t)lane : old;      // ip - anchor = lane, match > 0
-                const uint32_t back = bk < lim ? bk : lim;
-                const uint32_t slow_back = (bk == 4u && lim > 4u) ? 1u : 0u;
-                const uint32_t h1 = row_shr<1>(h), h2s = row_shr<2>(h), h3 = row_shr<3>(h), h4 = row_shr<4>(h);
-                // "spoils the prefix": an earlier probe in the same bucket
-                const bool spoil = (h == h1) | (h == h2s) | (h == h3) | (h == h4);
-                const uint32_t packed = (d - 4u) | (back << 8) | (slow_back << 16);
-                const uint64_t mm = ballot(hit);
-                const uint64_t sp = ballot(spoil);
-                const uint32_t f0 = mm ? ctz64(mm) : 64u;
-                // lanes <= 4 are fully covered by the four DPP compares; beyond that fall back to the readlane loop
-                bool ok = f0 <= 14u && (sp & ((2ull << f0) - 1ull)) == 0;
-#ifdef SQY_LZ4_DIAG
-                if (mm == 0) SQY_REASON(0);
-                else if (f0 > 14u) SQY_REASON(1);
-                else if (!ok) SQY_REASON(3);
-#endif
-                if (ok && f0 > 4u) {
-                    for (uint32_t c = 5; c <= f0; ++c)
+                    SQY_STAMP(6);
+                    const uint64_t mm = ballot(near && d >= 4u);
+                    if (mm == 0) { SQY_REASON(0); break; }
+                    const uint32_t f0 = ctz64(mm);                                      // <= 14
+                    // an earlier probe of this batch in the same bucket would be the true candidate: leave those to the
+                    // generic path (lane 15's put is already in the table, so it needs no check)
+                    bool ok = true;
+                    for (uint32_t c = 1; c <= f0; ++c)
                         if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { ok = false; break; }
-                }
-                SQY_STAMP(3);
-                if (ok) {
+                    if (!ok) { SQY_REASON(3); break; }
+                    SQY_STAMP(7);
                     const uint32_t mt0 = lane_read(old, f0);
-                    const uint32_t pk = lane_read(packed, f0);
                     const uint32_t ip0 = P + f0;
-                    uint32_t ml = pk & 0xffu;                                           // 0..12
+                    uint32_t ml = lane_read(d, f0) - 4u;                                // 0..12
+                    // catch-up of the winner: ip - anchor = f0 literals, match > 0
+                    const uint32_t xb = lane_read(b4 ^ cb4, f0);
+                    const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;   // equal bytes in front, 4 = maybe more
+                    const uint32_t lim = f0 < mt0 ? f0 : mt0;
+                    const uint32_t bck = bk < lim ? bk : lim;
+                    const bool slow_back = bk == 4u && lim > 4u;
                     bool settled = true;
                     if (ml == 12u) {
-                        // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (both resident, clear of matchlimit)
+                        // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (the ip side resident and clear of matchlimit)
                         const uint32_t dd = (uint32_t)lane * 16u;
                         uint4 mside;                                                    // uniform: candidate side resident?
                         if (mt0 >= w.wlo) mside = w.lds128(mt0 + 16u + dd); else mside = glb_ld_u128(w.src + mt0 + 16u + dd);
@@ -796,30 +809,28 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                             settled = false;
                         }
                     }
-                    SQY_STAMP(4);
-                    if ((uint32_t)lane <= f0) atomicMax(&table[h], (pos << tsh) | mytag);   // commit probes 0..f0 (positions only grow)
-                    if (settled && (pk >> 16) == 0u) {
-                        const uint32_t bck = (pk >> 8) & 0xffu;
-                        const uint32_t lit = f0 - bck;                                  // < 15
-                        const uint32_t matchCode = ml + bck;
-                        const uint32_t offset = ip0 - mt0;
-                        pend = true; pe_lit = lit; pe_mcode = matchCode; pe_off = offset;
-                        pe_litv = b4 >> 24;                                             // literal k-1 sits at anchor + k - 1 = pos - 1
-                        const uint32_t ipn = ip0 + 4u + ml;
-                        anchor = ipn;
-                        if (ipn >= mflimitPlusOne) break;
-                        put2 = ipn - 2u;
-                        P = ipn;
-                        SQY_STAMP(5);
-                        continue;                                                       // U stays 0
+                    SQY_STAMP(8);
+                    if ((uint32_t)lane <= f0) table[h] = mine;          // commit probes 0..f0: distinct buckets, newer than any entry
+                    wave_lds_sync();
+                    if (!settled || slow_back) {
+                        // winner known, but the match runs past the wide round or the catch-up past 4 bytes: generic tail
+                        if (!settled) SQY_REASON(4); else SQY_REASON(5);
+                        f = f0; fcand = mt0; ipf = ip0; fwl = ml; fw_exact = settled;
+                        bkl = slow_back ? 0xffffffffu : bck;
+                        batch_done = true;
+                        break;
                     }
-                    // winner known, but the match runs past the wide round or the catch-up past 4 bytes: generic tail
-                    if (!settled) SQY_REASON(4); else SQY_REASON(5);
-                    f = f0; fcand = mt0; ipf = ip0; fwl = ml; fw_exact = settled;
-                    bkl = (pk >> 16) ? 0xffffffffu : ((pk >> 8) & 0xffu);
-                    batch_done = true;
+                    pend = true; pe_lit = f0 - bck; pe_mcode = ml + bck; pe_off = ip0 - mt0;    // < 15 literals
+                    pe_litv = b4 >> 24;                                                 // literal k-1 sits at anchor + k - 1 = pos - 1
+                    const uint32_t ipn = ip0 + 4u + ml;
+                    anchor = ipn;
+                    if (ipn >= mflimitPlusOne) { finished = true; break; }
+                    put2 = ipn - 2u;
+                    P = ipn;
+                    SQY_STAMP(9);
+                    w.ensure(P);
                 }
-                
+                if (finished || failed) break;
             }
 
             // ---------------------------------------------------------------------------------------
@@ -846,6 +857,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     const uint64_t s2 = w.rd64(put2);
                     const uint32_t h2 = lz4_hash5(s2);
                     if (lane == 0) table[h2] = (put2 << tsh) | tag_of((uint32_t)s2);
+                    wave_lds_sync();
                     put2 = 0xffffffffu;
                 }
                 uint32_t h = 0, oe = 0, fl = 0;
@@ -890,6 +902,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 const uint32_t ncommit = (f < 64) ? f + 1 : nvalid;
                 if (valid) table[h] = oe;
                 if ((uint32_t)lane < ncommit) atomicMax(&table[h], (pos << tsh) | mytag);
+                wave_lds_sync();
                 if (f < 64) ipf = lane_read(pos, f);
                 next_P = lane_read(nxt, 63);
                 
@@ -1070,7 +1083,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             put2 = ipn - 2;
             P = ipn;
             U = 0;
-            SQY_STAMP(6);
+            SQY_STAMP(10);
         }
         if (pend && !failed) emit_pending();
     }
@@ -1098,7 +1111,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     }
     if (lane == 0) csize[blk] = failed ? 0u : op;
 #ifdef SQY_LZ4_DIAG
-    if (lane == 0) for (int i = 0; i < 8; ++i) { diag[blk * 24 + i] = dacc[i]; diag[blk * 24 + 8 + i] = dcnt[i]; diag[blk * 24 + 16 + i] = dreason[i]; }
+    if (lane == 0) { diag[blk * 16] = dacc; diag[blk * 16 + 1] = dcnt; for (int i = 0; i < 8; ++i) diag[blk * 16 + 8 + i] = dreason[i]; }
 #endif
 }
 
@@ -1560,6 +1573,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             for (uint32_t i = 0; i < sz; i += 64) {
                 const uint32_t cnt = sz - i < 64 ? sz - i : 64;
                 if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[i + lane];
+                wave_lds_sync();
                 pos += cnt;
                 flush(false);
             }
@@ -1578,6 +1592,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             for (uint32_t i = 0; i < lit; i += 64) {
                 const uint32_t cnt = lit - i < 64 ? lit - i : 64;
                 if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[ip + i + lane];
+                wave_lds_sync();
                 pos += cnt;
                 flush(false);
             }
@@ -1601,6 +1616,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                 uint32_t v = 0;
                 if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
                 if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                wave_lds_sync();
                 pos += cnt;
                 flush(false);
             }

@@ -4,9 +4,16 @@ import numpy as np
 import sqeazy_amd
 from sqeazy_amd import synth
 from oracle import sqy_oracle as o
-vol = synth.stack((64, 256, 256))
-rc, blob = sqeazy_amd.encode("lz4", vol, nthreads=2)
-want = o.pipeline_encode("lz4", vol)
+pipe = sys.argv[1] if len(sys.argv) > 1 else "lz4"
+shape = tuple(int(x) for x in sys.argv[2].split("x")) if len(sys.argv) > 2 else (64, 256, 256)
+vol = synth.stack(shape)
+rc, blob = sqeazy_amd.encode(pipe, vol, nthreads=2)
+want = o.pipeline_encode(pipe, vol)
+if pipe != "lz4":      # the bytes LZ4 sees: payload of the same pipeline without the sink
+    pre = o.pipeline_encode(pipe.rsplit("->", 1)[0], vol)
+    lzin = np.frombuffer(pre, np.uint8)[sqeazy_amd.header_size(pre):]
+else:
+    lzin = vol.view(np.uint8).reshape(-1)
 print(rc, len(blob), len(want))
 hs = sqeazy_amd.header_size(want)
 a = np.frombuffer(blob, np.uint8); b = np.frombuffer(want, np.uint8)
@@ -49,6 +56,11 @@ while off < len(want):
             sg = []; print("gpu parse error", e)
         for i,(x,y) in enumerate(zip(sw,sg)):
             if x!=y:
-                print("seq", i, "oracle", x, "gpu", y, "prev", sw[i-1] if i else None); break
+                print("seq", i, "oracle", x, "gpu", y, "prev", sw[i-2:i] if i else None)
+                base = k * 262144; q = x[0] + x[1]
+                print("bytes at oracle match pos", q, bytes(lzin[base+q-8:base+q+24]).hex())
+                if x[2]: print("oracle cand", q - x[2], bytes(lzin[base+q-x[2]-8:base+q-x[2]+24]).hex())
+                if y[2]: qg = y[0] + y[1]; print("gpu match pos", qg, "cand", qg - y[2], bytes(lzin[base+qg-y[2]-8:base+qg-y[2]+24]).hex())
+                break
         break
     off = end; k += 1

@@ -1,10 +1,12 @@
-// tools/lz4_diag.hip -- diagnostic build of the LZ4 chunk kernel with per-phase s_memtime accounting.
-// Not part of the product: reads chunks from a file, runs the kernel, prints cycle shares per phase.
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I sqeazy_amd/csrc tools/lz4_diag.hip -o tools/lz4_diag
+// tools/lz4_diag.hip -- diagnostic build of the LZ4 chunk kernel: cycles of one region of the parse loop.
+// Not part of the product.  Build one binary per region (marks A -> B, see SQY_STAMP in sqy_kernels.hip):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSQY_DIAG_A=0 -DSQY_DIAG_B=9 -I sqeazy_amd/csrc tools/lz4_diag.hip -o tools/lz4_diag_0_9
+// tools/lz4_diag_all.sh builds and runs the usual set.
 #define SQY_LZ4_DIAG 1
 #include "../sqeazy_amd/csrc/sqy_kernels.hip"
 #include <cstdio>
 #include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { std::printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 int main(int argc, char** argv)
 {
     if (argc < 2) { std::printf("usage: lz4_diag file [chunk]\n"); return 1; }
@@ -17,30 +19,24 @@ int main(int argc, char** argv)
     const uint32_t chunk = argc > 2 ? std::atoi(argv[2]) : 262144;
     const uint64_t nch = (n + chunk - 1) / chunk;
     uint8_t *din, *dscr; uint32_t* dcs; unsigned long long* ddg;
-    hipMalloc(&din, n + 64); hipMalloc(&dscr, nch * chunk); hipMalloc(&dcs, nch * 4); hipMalloc(&ddg, nch * 24 * 8);
-    hipMemcpy(din, h.data(), n, hipMemcpyHostToDevice);
-    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    CK(hipMalloc(&din, n + 64)); CK(hipMalloc(&dscr, nch * chunk)); CK(hipMalloc(&dcs, nch * 4)); CK(hipMalloc(&ddg, nch * 16 * 8));
+    CK(hipMemcpy(din, h.data(), n, hipMemcpyHostToDevice));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
-        hipEventRecord(e0, 0);
+        CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL(sqy::lz4_chunks_kernel, dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, ddg);
-        hipEventRecord(e1, 0);
-        hipDeviceSynchronize();
-        float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-        std::printf("launch %d: %.3f ms wall\n", rep, ms);
+        CK(hipEventRecord(e1, 0));
+        CK(hipDeviceSynchronize());
+        float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
+        if (ms < best) best = ms;
     }
-    std::vector<unsigned long long> dg(nch * 24); std::vector<uint32_t> cs(nch);
-    hipMemcpy(dg.data(), ddg, nch * 24 * 8, hipMemcpyDeviceToHost);
-    hipMemcpy(cs.data(), dcs, nch * 4, hipMemcpyDeviceToHost);
-    const char* names[8] = {"ensure", "lean: seq reads+hash+put2", "lean: table read", "lean: cand reads+eval+ballots", "lean: winner+wide round", "lean: commit+emit+advance", "generic iteration (whole)", "loop-top"};
-    for (uint64_t k = 0; k < nch; ++k) {
-        unsigned long long tot = 0;
-        for (int i = 0; i < 8; ++i) tot += dg[k * 24 + i];
-        std::printf("chunk %llu csize %u total %llu cycles, matches %llu, batches %llu\n", (unsigned long long)k, cs[k], tot, dg[k * 24 + 8 + 6], dg[k * 24 + 8 + 0]);
-        for (int i = 0; i < 8; ++i)
-            std::printf("   %-20s %10llu cyc  %5.1f%%  n=%llu  avg %.0f\n", names[i], dg[k * 24 + i], 100.0 * dg[k * 24 + i] / (tot ? tot : 1),
-                        dg[k * 24 + 8 + i], dg[k * 24 + 8 + i] ? (double)dg[k * 24 + i] / dg[k * 24 + 8 + i] : 0.0);
-        std::printf("   lean misses: no-hit-in-64 %llu, f0>14 %llu, far-candidate %llu, hazard %llu | handover long-match %llu, slow-back %llu | generic batches: U!=0 %llu, U==0 %llu\n",
-                    dg[k * 24 + 16], dg[k * 24 + 17], dg[k * 24 + 18], dg[k * 24 + 19], dg[k * 24 + 20], dg[k * 24 + 21], dg[k * 24 + 22], dg[k * 24 + 23]);
-    }
+    std::vector<unsigned long long> dg(nch * 16);
+    CK(hipMemcpy(dg.data(), ddg, nch * 16 * 8, hipMemcpyDeviceToHost));
+    unsigned long long acc = 0, cnt = 0, rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (uint64_t k = 0; k < nch; ++k) { acc += dg[k * 16]; cnt += dg[k * 16 + 1]; for (int i = 0; i < 8; ++i) rs[i] += dg[k * 16 + 8 + i]; }
+    std::printf("region %2d -> %2d: kernel %.3f ms, %llu passes/chunk, avg %.0f cycles, total %.0f cycles/chunk | events/chunk: no-hit %llu f0>14 %llu far-fetch %llu hazard %llu long %llu slow-back %llu genericU!=0 %llu genericU==0 %llu\n",
+                SQY_DIAG_A, SQY_DIAG_B, best, cnt / nch, cnt ? (double)acc / cnt : 0.0, (double)acc / nch,
+                rs[0] / nch, rs[1] / nch, rs[2] / nch, rs[3] / nch, rs[4] / nch, rs[5] / nch, rs[6] / nch, rs[7] / nch);
     return 0;
 }
