@@ -443,44 +443,49 @@ __device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
 // candidates a short distance back; everything resident is read with LDS latency instead of a dependent
 // HBM/L2 round trip.  Positions outside [wlo, whi) -- far candidates, skip-accelerated probes on
 // incompressible data, very long matches -- fall back to global loads.
-// The block [whi, whi+FB) is prefetched into registers one refill ahead (plain loads: the compiler counts
-// vmcnt for us) and committed to the ring when ip gets within AHEAD bytes of whi.
-constexpr uint32_t LZ4_WIN = 8192, LZ4_FB = 2048, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
+// The block [whi, whi+FB) is always on its way: one global_load_lds_dwordx4 (64 lanes x 16 B = 1 KiB straight
+// into the ring slot, no registers).  The instruction is issued through inline asm so that the compiler's
+// s_waitcnt bookkeeping does not see it -- otherwise every ring read in the parse loop waits for the block in
+// flight (vmcnt(0)) and the prefetch hides nothing.  commit() waits for it explicitly when ip gets within AHEAD
+// bytes of whi, one refill later.  (The compiler's own vmcnt(N) waits only become stricter by the extra
+// outstanding operation, never too weak: VMEM operations retire in order.)
+constexpr uint32_t LZ4_WIN = 8192, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 struct Lz4Window {
     glb_u8* src;           // chunk source (global)
     lds_u8* win;           // LDS ring (WIN + MIRROR bytes)
     uint32_t n;            // chunk bytes
-    uint32_t whi, wlo;     // resident range [wlo, whi), whi a multiple of FB
+    uint32_t whi, wlo;     // resident range [wlo, whi), whi a multiple of FB; [whi, whi + FB) is in flight into its slot
     uint32_t lane16;       // lane * 16
-    uint4 pf[LZ4_FB / 1024];   // block [whi, whi + FB)
 
     __device__ __forceinline__ void issue()
     {
-#pragma unroll
-        for (uint32_t j = 0; j < LZ4_FB / 1024; ++j) {
-            const uint32_t a = whi + j * 1024u + lane16;
-            pf[j] = (a + 16u <= n) ? glb_ld_u128(src + a) : make_uint4(0, 0, 0, 0);
+        // the slot of [whi, whi + FB) still holds [whi - WIN, whi - WIN + FB): give it up before the copy starts
+        if (whi + LZ4_FB - wlo > LZ4_WIN) wlo = whi + LZ4_FB - LZ4_WIN;
+        const uint32_t a = whi + lane16;
+        if (a + 16u <= n) {                                    // lanes past the chunk's last whole 16 bytes stay off
+            const uint32_t lds_dst = (uint32_t)(uintptr_t)win + (whi & (LZ4_WIN - 1));   // wave-uniform; the copy adds lane * 16
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src + a), "s"(lds_dst) : "memory");
         }
     }
     __device__ __forceinline__ void commit()
     {
-#pragma unroll
-        for (uint32_t j = 0; j < LZ4_FB / 1024; ++j) {
-            const uint32_t o = (whi + j * 1024u + lane16) & (LZ4_WIN - 1);
-            const v4u val = {pf[j].x, pf[j].y, pf[j].z, pf[j].w};
-            *reinterpret_cast<SQY_LDS v4u*>(win + o) = val;
-            if (j == 0 && o == 0) *reinterpret_cast<SQY_LDS v4u*>(win + LZ4_WIN) = val;   // mirror of ring[0..16)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the block in flight has landed
+        wave_lds_sync();
+        if ((whi & (LZ4_WIN - 1)) == 0) {                        // mirror of ring[0..16)
+            if (lane16 < 64u) *reinterpret_cast<SQY_LDS uint32_t*>(win + LZ4_WIN + (lane16 >> 2)) = *reinterpret_cast<const SQY_LDS uint32_t*>(win + (lane16 >> 2));
+            wave_lds_sync();
         }
-        wave_lds_sync();                                       // other lanes read these bytes
         whi += LZ4_FB;
-        if (whi - wlo > LZ4_WIN) wlo = whi - LZ4_WIN;
     }
     // make [ip - some history, ip + AHEAD) resident as far as the chunk goes (uniform control flow)
     __device__ __forceinline__ void ensure(uint32_t ip)
     {
         if (ip + LZ4_AHEAD <= whi || whi >= n) return;
         if (ip >= whi + (LZ4_WIN - LZ4_FB)) {                 // jumped past everything resident: restart the ring
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the copy in flight must not land on top of the new ones)
             uint32_t start = ip & ~(LZ4_FB - 1);
             if (start >= LZ4_FB) start -= LZ4_FB;              // keep one block of history
             whi = wlo = start;
@@ -729,6 +734,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // ---------------------------------------------------------------------------------------
             bool finished = false;
             if (U == 0) {
+                // Enter the loop with no load of the compiler's own in flight (results the generic path left unused
+                // count): otherwise its waitcnt pass puts a vmcnt(0) in front of the loop's first ring read, and that
+                // one would wait for the ring block in flight on EVERY iteration.
+                __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
                 for (;;) {
                     if (!(P >= w.wlo + 4u && P + 1200u <= w.hi_valid() && P + 1200u <= matchlimit)) break;
                     SQY_STAMP(1);
@@ -797,9 +806,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     if (ml == 12u) {
                         // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (the ip side resident and clear of matchlimit)
                         const uint32_t dd = (uint32_t)lane * 16u;
-                        uint4 mside;                                                    // uniform: candidate side resident?
-                        if (mt0 >= w.wlo) mside = w.lds128(mt0 + 16u + dd); else mside = glb_ld_u128(w.src + mt0 + 16u + dd);
-                        const uint32_t g = first_diff16(w.lds128(ip0 + 16u + dd), mside);
+                        // (two complete branches: a merged load would make the common, ring-only side wait on vmcnt too)
+                        uint32_t g;
+                        if (mt0 >= w.wlo) g = first_diff16(w.lds128(ip0 + 16u + dd), w.lds128(mt0 + 16u + dd));
+                        else { g = first_diff16(w.lds128(ip0 + 16u + dd), glb_ld_u128(w.src + mt0 + 16u + dd)); asm volatile("" : "+v"(g)); }  // (keeps the optimiser from re-merging the branches)
                         const uint64_t nf = ballot(g != 16u);
                         if (nf) {
                             const uint32_t l = ctz64(nf);
@@ -1109,6 +1119,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             op += lastRun;
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released
     if (lane == 0) csize[blk] = failed ? 0u : op;
 #ifdef SQY_LZ4_DIAG
     if (lane == 0) { diag[blk * 16] = dacc; diag[blk * 16 + 1] = dcnt; for (int i = 0; i < 8; ++i) diag[blk * 16 + 8 + i] = dreason[i]; }
