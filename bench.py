@@ -66,9 +66,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=SHAPE[0], help="z extent per GPU (default: the BASELINE config)")
-    ap.add_argument("--inflight", type=int, default=4,
+    ap.add_argument("--inflight", type=int, default=2,
                     help="C-ABI calls in flight per GPU (host threads, one stream + workspace each; the C-ABI is re-entrant like "
-                         "the reference's).  1 = strictly one call after the other")
+                         "the reference's).  1 = strictly one call after the other.  Two already keep the GPU busy (the LZ4 parse "
+                         "of one call overlaps the HBM-bound kernels of the other); more only stretch each kernel's duration")
     args = ap.parse_args()
 
     import torch

@@ -1728,7 +1728,10 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
     const bool aligned = (seg_words % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (aligned) n_tiles = (seg_words * 16) / BSW_TILE_VOX;
-    static const int bsw_mode = std::getenv("SQY_BSW_MODE") ? std::atoi(std::getenv("SQY_BSW_MODE")) : 0;
+    // default: the register-tile kernel, 16 blocks per CU.  It needs no LDS, so it runs next to the LZ4 chunk waves of
+    // other calls in flight (those hold nearly all of a CU's LDS); alone it is as fast as the LDS-tile kernel.
+    // SQY_BSW_MODE (tools/bsw_modes.sh): 0 = LDS tiles, n >= 2 = register tiles with n blocks per CU
+    static const int bsw_mode = std::getenv("SQY_BSW_MODE") ? std::atoi(std::getenv("SQY_BSW_MODE")) : 16;
     if (n_tiles && bsw_mode >= 1) {
         const uint64_t want = (n_tiles + 3) / 4;
         const uint64_t cap = (uint64_t)num_cus() * (uint64_t)(bsw_mode >= 2 ? bsw_mode : 8);
