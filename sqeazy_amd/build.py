@@ -14,6 +14,8 @@ LIB = os.path.join(LIBDIR, "libsqeazy_amd.so")
 SOURCES = ["sqy_kernels.hip", "sqy_pipeline.cpp", "sqy_capi.cpp"]
 HEADERS = ["sqy_kernels.h", "sqy_pipeline.hpp", os.path.join("..", "..", "include", "sqeazy_amd.h")]
 ARCH = "gfx950"
+BINDIR = os.path.join(HERE, "bin")
+CLI = os.path.join(BINDIR, "sqy")                 # command line front end over the C-ABI (csrc/sqy_cli.cpp)
 
 
 def _hipcc():
@@ -24,10 +26,10 @@ def _hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
+    t = min(os.path.getmtime(LIB), os.path.getmtime(CLI))
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + ["sqy_cli.cpp"]]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -49,6 +51,13 @@ def build(force=False, verbose=False):
         subprocess.check_call(cmd)
         objs.append(obj)
     cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    # the `sqy` tool: plain host C++ over the exported C symbols only, finds the library next to itself
+    os.makedirs(BINDIR, exist_ok=True)
+    cmd = ["g++", "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "sqy_cli.cpp"), "-o", CLI, "-L" + LIBDIR, "-lsqeazy_amd",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
