@@ -455,46 +455,52 @@ struct Lz4Window {
     glb_u8* src;           // chunk source (global)
     lds_u8* win;           // LDS ring (WIN + MIRROR bytes)
     uint32_t n;            // chunk bytes
-    uint32_t whi, wlo;     // resident range [wlo, whi), whi a multiple of FB; [whi, whi + FB) is in flight into its slot
+    uint32_t whi, wlo;     // resident range [wlo, whi), whi a multiple of FB
+    uint32_t nif;          // blocks [whi, whi + nif * FB) are in flight into their slots (1 in the steady state)
     uint32_t lane16;       // lane * 16
 
     __device__ __forceinline__ void issue()
     {
-        // the slot of [whi, whi + FB) still holds [whi - WIN, whi - WIN + FB): give it up before the copy starts
-        if (whi + LZ4_FB - wlo > LZ4_WIN) wlo = whi + LZ4_FB - LZ4_WIN;
-        const uint32_t a = whi + lane16;
+        const uint32_t b = whi + nif * LZ4_FB;                 // block to fetch
+        // its slot still holds [b - WIN, b - WIN + FB): give that up before the copy starts
+        if (b + LZ4_FB - wlo > LZ4_WIN) wlo = b + LZ4_FB - LZ4_WIN;
+        const uint32_t a = b + lane16;
         if (a + 16u <= n) {                                    // lanes past the chunk's last whole 16 bytes stay off
-            const uint32_t lds_dst = (uint32_t)(uintptr_t)win + (whi & (LZ4_WIN - 1));   // wave-uniform; the copy adds lane * 16
+            const uint32_t lds_dst = (uint32_t)(uintptr_t)win + (b & (LZ4_WIN - 1));   // wave-uniform; the copy adds lane * 16
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                          : "=&s"(keep) : "v"(src + a), "s"(lds_dst) : "memory");
         }
+        nif += 1;
     }
+    // everything in flight has landed and becomes readable
     __device__ __forceinline__ void commit()
     {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the block in flight has landed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_lds_sync();
-        if ((whi & (LZ4_WIN - 1)) == 0) {                        // mirror of ring[0..16)
+        const uint32_t end = whi + nif * LZ4_FB;
+        if (((end - 1u) & ~(LZ4_WIN - 1)) != ((whi - 1u) & ~(LZ4_WIN - 1)) || whi == 0) {   // a block with ring offset 0 among them
             if (lane16 < 64u) *reinterpret_cast<SQY_LDS uint32_t*>(win + LZ4_WIN + (lane16 >> 2)) = *reinterpret_cast<const SQY_LDS uint32_t*>(win + (lane16 >> 2));
             wave_lds_sync();
         }
-        whi += LZ4_FB;
+        whi = end;
+        nif = 0;
     }
     // make [ip - some history, ip + AHEAD) resident as far as the chunk goes (uniform control flow)
     __device__ __forceinline__ void ensure(uint32_t ip)
     {
         if (ip + LZ4_AHEAD <= whi || whi >= n) return;
         if (ip >= whi + (LZ4_WIN - LZ4_FB)) {                 // jumped past everything resident: restart the ring
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (the copy in flight must not land on top of the new ones)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (a copy in flight must not land on top of the new ones)
             uint32_t start = ip & ~(LZ4_FB - 1);
             if (start >= LZ4_FB) start -= LZ4_FB;              // keep one block of history
             whi = wlo = start;
-            issue();
+            nif = 0;
         }
-        do {
-            commit();
-            if (whi < n) issue();
-        } while (ip + LZ4_AHEAD > whi && whi < n);
+        // fetch what is missing in one go (one wait), then leave the next block in flight
+        while (whi + nif * LZ4_FB < ip + LZ4_AHEAD && whi + nif * LZ4_FB < n) issue();
+        commit();
+        if (whi < n) issue();
     }
     // end of the bytes that can be read from the ring: the last (n & 15) bytes are never filled
     __device__ __forceinline__ uint32_t hi_valid() const { return whi < (n & ~15u) ? whi : (n & ~15u); }
@@ -655,7 +661,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     uint8_t* __restrict__ dst = scratch + blk * stride;
 
     Lz4Window w;
-    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = n; w.whi = 0; w.wlo = 0; w.lane16 = (uint32_t)lane * 16u;
+    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = n; w.whi = 0; w.wlo = 0; w.nif = 0; w.lane16 = (uint32_t)lane * 16u;
     w.issue();
     Lz4Out o;
     o.dst = (SQY_GLB uint8_t*)dst; o.ob = (lds_u8*)stage; o.base = 0; o.lane = lane;

@@ -1,0 +1,15 @@
+#!/bin/bash
+# GPU box: plain bench + rocprofv3 kernel trace + the two HBM counter passes, all over the default bench command.
+# Outputs under gpurun_out/prof/; condense afterwards (here) with tools/summarize_profile.py <tag>.
+set -o pipefail
+cd "$(dirname "$0")/.."
+export TMPDIR=/tmp
+P=gpurun_out/prof
+rm -rf $P; mkdir -p $P
+B="bench.py --steps 10 --warmup 2"
+timeout -k 10 300 python3 $B > $P/bench_plain.log 2>&1 || exit 1
+tail -1 $P/bench_plain.log | cut -c1-400
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 $B --no-cpu-baseline > $P/bench_trace.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -- python3 $B --no-cpu-baseline > $P/bench_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -- python3 $B --no-cpu-baseline > $P/bench_write.log 2>&1 || exit 1
+echo profile passes done

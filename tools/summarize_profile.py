@@ -21,8 +21,9 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-SHORT = {"sqy::lz4_chunks_kernel": "lz4_chunks", "sqy::bitswap1_u16_tiles": "bitswap1_u16", "sqy::lz4_frame_gather_kernel": "lz4_frame_gather",
-         "sqy::lz4_frame_scan_kernel": "lz4_frame_scan", "sqy::bitswap1_u16_generic": "bitswap1_u16_generic"}
+SHORT = {"sqy::lz4_chunks_kernel": "lz4_chunks", "sqy::bitswap1_u16_tiles": "bitswap1_u16", "sqy::bitswap1_u16_regs": "bitswap1_u16",
+         "sqy::lz4_frame_gather_kernel": "lz4_frame_gather", "sqy::lz4_frame_scan_kernel": "lz4_frame_scan",
+         "sqy::bitswap1_u16_generic": "bitswap1_u16_generic"}
 
 
 def short(name):
