@@ -118,6 +118,17 @@ SQY_FUNCTION_PREFIX const char* SQYAMD_Profile_Get(int i, double* total_ms, long
 /* release the cached HBM workspace of the current device */
 SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
 
+/* Header helpers for callers that store blobs in containers of their own (the HDF5 filter's cd_values carry a header:
+ * inc/sqeazy_h5_filter.hpp:117-121, src/hdf5_utils.hpp:730-738).  The reference does this through its C++ header class
+ * (src/sqeazy_header.hpp); there is no C symbol for it there.
+ *   Header_Pipeline: copies the NUL-terminated "pipename" of the header at src into out.  *outlength in: capacity of out,
+ *                    out: bytes needed (out == NULL: size query).
+ *   Header_Build:    writes the header (with delimiter, without payload) the encoder would put in front of
+ *                    `encoded_bytes` of payload for this pipeline / voxel size / shape.  Same length protocol. */
+SQY_FUNCTION_PREFIX int SQYAMD_Header_Pipeline(const char* src, long srclength, char* out, long* outlength);
+SQY_FUNCTION_PREFIX int SQYAMD_Header_Build(const char* pipeline, int sizeof_voxel, const long* shape, unsigned shape_size,
+                                            long encoded_bytes, char* out, long* outlength);
+
 /* "sqeazy_amd <version> (gfx950)" */
 SQY_FUNCTION_PREFIX const char* SQYAMD_Version(void);
 

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = (
     "SQYAMD_PipelineEncode_UI16_Cap", "SQYAMD_PipelineEncode_UI8_Cap",
     "SQYAMD_Decode_UI16_Device", "SQYAMD_Decode_UI8_Device",
     "SQYAMD_Profile_Enable", "SQYAMD_Profile_Reset", "SQYAMD_Profile_Get",
-    "SQYAMD_Release_Workspace", "SQYAMD_Version",
+    "SQYAMD_Release_Workspace", "SQYAMD_Version", "SQYAMD_Header_Pipeline", "SQYAMD_Header_Build",
 )
 
 

@@ -29,7 +29,7 @@ def needs_build():
     if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
     t = min(os.path.getmtime(LIB), os.path.getmtime(CLI))
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + ["sqy_cli.cpp"]]
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + ["sqy_cli.cpp", "sqy_h5_filter.c"]]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -61,7 +61,43 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    build_h5_plugin(verbose)
     return LIB
+
+
+HDF5_ROOT = os.environ.get("SQY_HDF5_ROOT", "/opt/conda")       # this image ships HDF5 1.10.6 (C library + headers) there
+H5_PLUGIN = os.path.join(LIBDIR, "libh5sqy_amd.so")
+H5_TOOL = os.path.join(BINDIR, "h5_roundtrip")
+
+
+def build_h5_plugin(verbose=False):
+    """HDF5 filter plugin (csrc/sqy_h5_filter.c) and its test client, when an HDF5 C library is present.
+
+    libhdf5 is linked by file and found at run time through a symlink next to our library: adding its directory to a
+    search path would also put that directory's (older) libstdc++ in front of the system's."""
+    inc = os.path.join(HDF5_ROOT, "include")
+    so = None
+    for name in ("libhdf5.so.103", "libhdf5.so.200", "libhdf5.so"):
+        if os.path.exists(os.path.join(HDF5_ROOT, "lib", name)):
+            so = os.path.join(HDF5_ROOT, "lib", name)
+            break
+    if so is None or not os.path.exists(os.path.join(inc, "hdf5.h")):
+        return None
+    link = os.path.join(LIBDIR, os.path.basename(so))
+    if os.path.lexists(link):
+        os.remove(link)
+    os.symlink(so, link)
+    common = ["gcc", "-O2", "-Wall", "-I" + inc]
+    cmds = [common + ["-shared", "-fPIC", "-fvisibility=hidden", os.path.join(CSRC, "sqy_h5_filter.c"), "-o", H5_PLUGIN,
+                      "-L" + LIBDIR, "-lsqeazy_amd", so, "-Wl,-rpath,$ORIGIN",
+                      "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")],
+            common + [os.path.join(HERE, "..", "tools", "h5_roundtrip.c"), "-o", H5_TOOL, "-L" + LIBDIR, "-lsqeazy_amd", so,
+                      "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]]
+    for cmd in cmds:
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return H5_PLUGIN
 
 
 if __name__ == "__main__":

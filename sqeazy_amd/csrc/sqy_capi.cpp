@@ -847,6 +847,43 @@ void SQYAMD_Release_Workspace(void)
     for (auto& c : g_pool[dev]) if (!c->busy) c->ws.release_buffers();
 }
 
+int SQYAMD_Header_Pipeline(const char* src, long srclength, char* out, long* outlength)
+{
+    if (!src || !outlength || srclength <= 0) return 1;
+    const sqy::HeaderInfo h = sqy::header_unpack(src, src + srclength);
+    if (!h.valid) return 1;
+    const long need = (long)h.pipename.size() + 1;
+    const long have = out ? *outlength : 0;
+    *outlength = need;
+    if (!out) return 0;                          // size query
+    if (have < need) return 1;
+    std::memcpy(out, h.pipename.c_str(), (size_t)need);
+    return 0;
+}
+
+int SQYAMD_Header_Build(const char* pipeline, int sizeof_voxel, const long* shape, unsigned shape_size, long encoded_bytes,
+                        char* out, long* outlength)
+{
+    if (!pipeline || !shape || !outlength || shape_size == 0 || (sizeof_voxel != 1 && sizeof_voxel != 2) || encoded_bytes < 0) return 1;
+    try {
+        if (!sqy::Pipeline::supported(pipeline, sizeof_voxel)) return 1;
+        const sqy::Pipeline p = sqy::Pipeline::from_string(pipeline);
+        std::vector<uint64_t> shp(shape, shape + shape_size);
+        for (uint64_t v : shp) if ((long)v <= 0) return 1;
+        const std::string hdr = sqy::header_pack(sizeof_voxel, false, shp, p.name(), (uint64_t)encoded_bytes);
+        const long need = (long)hdr.size();
+        const long have = out ? *outlength : 0;
+        *outlength = need;
+        if (!out) return 0;                      // size query
+        if (have < need) return 1;
+        std::memcpy(out, hdr.data(), hdr.size());
+        return 0;
+    } catch (const std::exception& e) {
+        std::fprintf(stderr, "[sqeazy]\t %s\n", e.what());
+        return 1;
+    }
+}
+
 const char* SQYAMD_Version(void) { return "sqeazy_amd 0.1.0 (gfx950, sqy header 0.5.2)"; }
 
 } // extern "C"
