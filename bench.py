@@ -4,8 +4,9 @@
 Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run,
 one rank per GPU).  A "step" is one pass of the hot path over one z-slab: every rank encodes a
 1024x1024x512 uint16 synthetic stack (BASELINE.json configs[1]; 1 GiB, already resident in HBM) with ONE
-C-ABI call, then the compressed slabs are gathered to rank 0 over RCCL (N>1 only).  Weak scaling: per-GPU
-work is fixed.  value = (N * input bytes * K) / max-over-ranks wall time, GB = 1e9 bytes.
+C-ABI call; the slab blobs are independent sqeazy blobs and stay on their GPUs, only their sizes (the index of
+the sharded container) are all_gathered over RCCL (N>1 only; --gather-to-root also moves the blobs to rank 0).
+Weak scaling: per-GPU work is fixed.  value = (N * input bytes * K) / max-over-ranks wall time, GB = 1e9 bytes.
 
 The JSON line also carries
   roofline      the dominant kernel (largest share of device time, timed with HIP events on the launch
@@ -66,6 +67,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--frames", type=int, default=SHAPE[0], help="z extent per GPU (default: the BASELINE config)")
+    ap.add_argument("--gather-to-root", action="store_true",
+                    help="N>1: also move every rank's compressed blob to rank 0 inside the step (default: blobs stay sharded, only "
+                         "their sizes -- the container index -- are exchanged)")
     ap.add_argument("--inflight", type=int, default=2,
                     help="C-ABI calls in flight per GPU (host threads, one stream + workspace each; the C-ABI is re-entrant like "
                          "the reference's).  1 = strictly one call after the other.  Two already keep the GPU busy (the LZ4 parse "
@@ -99,7 +103,7 @@ def main():
     vol = synth.stack_torch(shape, np.uint16, dev, z_offset=rank * shape[0], z_total=world * shape[0])
     nbytes = vol.numel() * 2
     cap = sqeazy_amd.max_compressed_length(PIPELINE, shape, np.uint16)
-    gather_buf = torch.empty(world * cap, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0) else None
+    gather_buf = torch.empty(world * cap, dtype=torch.uint8, device=dev) if (world > 1 and rank == 0 and args.gather_to_root) else None
     import queue
     import threading
     sys.setswitchinterval(1e-4)      # caller threads hand the GIL over promptly (default 5 ms would show up as whole milliseconds per step)
@@ -146,7 +150,10 @@ def main():
             while nxt in pending:
                 t2, b2, n2 = pending.pop(nxt)
                 if world > 1:
-                    multi.gather_blobs(outs[t2][b2], n2, dst_buffer=gather_buf)
+                    if args.gather_to_root:
+                        multi.gather_blobs(outs[t2][b2], n2, dst_buffer=gather_buf)
+                    else:
+                        multi.exchange_sizes(n2, dev)
                     torch.cuda.current_stream().synchronize()
                 free_q[t2].put(b2)
                 last_n = n2
@@ -212,7 +219,7 @@ def main():
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
             "config": {"workload": "%dx%dx%d uint16 synthetic microscopy stack per GPU, pipeline '%s', one C-ABI call per step, %d calls in flight%s" % (
-                shape[2], shape[1], shape[0], PIPELINE, inflight, ", RCCL gather of compressed slabs to rank 0" if world > 1 else ""),
+                shape[2], shape[1], shape[0], PIPELINE, inflight, (", RCCL gather of the compressed slabs to rank 0" if args.gather_to_root else ", slab blobs stay sharded, sizes all_gathered over RCCL") if world > 1 else ""),
                 "input_bytes_per_gpu": nbytes, "payload_bytes": payload_bytes, "blob_bytes": payload, "calls_in_flight_per_gpu": inflight,
                 "single_call_latency_ms": round(single_call_ms, 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

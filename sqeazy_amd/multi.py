@@ -2,9 +2,11 @@
 
 A volume {Z,Y,X} is cut into `world_size` contiguous z-slabs; every rank encodes its slab on its own GPU
 with one C-ABI call (each slab blob is a bit-exact sqeazy blob: this is exactly what the CPU reference
-produces for the same slab call).  The only exchange step is a variable-length gather of the compressed
-blobs to rank 0 over RCCL/xGMI (backend "nccl" on ROCm), written against torch.distributed so that the
-same code runs on gloo for the CPU tests.
+produces for the same slab call).  The path itself has no exchange step; what a sharded container needs is its
+index: `exchange_sizes` (one 8-byte all_gather).  `gather_blobs` additionally moves the compressed blobs to rank 0
+over RCCL/xGMI (backend "nccl" on ROCm) for callers that want one contiguous container there -- root ingress then
+bounds the job (compressed bytes of all slabs per step).  Written against torch.distributed so that the same code
+runs on gloo for the CPU tests.
 
 Container produced on rank 0 (OUR framing, not sqeazy's):  u64 count | u64 size[count] | blob_0 | blob_1 ...
 """
@@ -16,6 +18,19 @@ def slab_range(Z, rank, world):
     base, rem = divmod(int(Z), int(world))
     z0 = rank * base + min(rank, rem)
     return z0, base + (1 if rank < rem else 0)
+
+
+def exchange_sizes(nbytes, device, group=None):
+    """all_gather of the per-rank blob sizes (8 bytes per rank): the container's index.  Every rank learns where its
+    blob sits in the container (offset = sum of the sizes of the ranks before it); the blobs themselves stay on the
+    GPUs that produced them -- slabs are independent sqeazy blobs, the path has no other exchange step."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    size_t = torch.tensor([int(nbytes)], dtype=torch.int64, device=device)
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=device)
+    dist.all_gather_into_tensor(sizes_t, size_t, group=group)
+    return [int(v) for v in sizes_t.tolist()]
 
 
 def gather_blobs(blob, nbytes, dst_buffer=None, group=None, root=0):

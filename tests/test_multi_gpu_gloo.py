@@ -37,9 +37,12 @@ def _worker(rank, world, port, q):
         t = torch.zeros(len(blob) + 100, dtype=torch.uint8)
         t[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
         # ... and the compressed slabs are gathered to rank 0
+        # the step bench.py times at N > 1: only the sizes (the sharded container's index) are exchanged
+        idx = multi.exchange_sizes(len(blob), t.device)
+        assert len(idx) == world and idx[rank] == len(blob)
         for _ in range(2):                                   # twice: the buffers are reused across steps in bench.py
             sizes, flat = multi.gather_blobs(t, len(blob))
-        assert sizes[rank] == len(blob)
+        assert sizes == idx
         if rank == 0:
             blobs = multi.unpack_container(multi.pack_container(sizes, flat))
             assert len(blobs) == world
