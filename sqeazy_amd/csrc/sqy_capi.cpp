@@ -521,19 +521,35 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 const uint64_t block_bytes = st.lz4.block_bytes();
                 const uint64_t nchunks = total ? (total + chunk - 1) / chunk : 0;
                 const uint64_t max_blocks = std::max<uint64_t>(nchunks * ((chunk + block_bytes - 1) / block_bytes), total / block_bytes + 1) + 16;
-                if (ws->lz4_scratch.ensure(max_blocks * 16 + (max_blocks + 2) * 4 + 64)) return 1;
+                // block list, frame starts, and a table of frame-start candidates (16 B x >= 8 slots per expected frame)
+                const uint64_t idx_bytes = (max_blocks * 16 + (max_blocks + 2) * 4 + 64 + 15) & ~15ull;
+                const uint64_t cand_bytes = sqy::lz4_frame_rank_scratch_bytes(nchunks);
+                if (ws->lz4_scratch.ensure(idx_bytes + cand_bytes)) return 1;
                 uint8_t* blk = static_cast<uint8_t*>(ws->lz4_scratch.p);
                 uint32_t* frame_first = reinterpret_cast<uint32_t*>(blk + max_blocks * 16);
+                void* cand = blk + idx_bytes;
                 if (ws->csize.ensure(64)) return 1;
                 uint32_t* counts = static_cast<uint32_t*>(ws->csize.p);          // [0..2] index result, [4] decode error flag
                 SQY_HIP(hipMemsetAsync(counts, 0, 32, stream));
-                {
-                    ProfScope ps("lz4_frame_index", stream, pend);
-                    SQY_HIP(sqy::launch_lz4_frame_index(cur, cur_bytes, blk, frame_first, max_blocks, counts, stream));
+                uint32_t hc[3] = {0, 0, 100};
+                if (nchunks > 1) {
+                    // chunked layout expected: rank the frame list in parallel
+                    {
+                        ProfScope ps("lz4_frame_rank", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_frame_rank(cur, cur_bytes, blk, frame_first, max_blocks, counts, nchunks, cand, stream));
+                    }
+                    SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
+                    SQY_HIP(hipStreamSynchronize(stream));
                 }
-                uint32_t hc[3];
-                SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
-                SQY_HIP(hipStreamSynchronize(stream));
+                if (hc[2] == 100) {
+                    // one frame, the serial block-linked layout, or anything the parallel ranking does not cover
+                    {
+                        ProfScope ps("lz4_frame_index", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_frame_index(cur, cur_bytes, blk, frame_first, max_blocks, counts, stream));
+                    }
+                    SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
+                    SQY_HIP(hipStreamSynchronize(stream));
+                }
                 if (hc[2]) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 frame stream (code %u)\n", hc[2]); return 1; }
                 const uint32_t nframes = hc[0];
                 if (nframes > 1 && nframes != nchunks) {

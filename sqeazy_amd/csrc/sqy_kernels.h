@@ -38,6 +38,10 @@ hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t f
 // index of every LZ4 block of the concatenated frames: blk[i] = {data offset lo, hi, size | raw << 31, block id in frame}
 hipError_t launch_lz4_frame_index(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
                                   uint32_t* counts /* frames, blocks, error */, hipStream_t stream);
+// parallel variant for the chunked layout (single-block frames): counts[2] == 100 means "not covered, run the serial walk"
+uint64_t lz4_frame_rank_scratch_bytes(uint64_t expected_frames);
+hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
+                                 uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream);
 // frame f decodes to out + f*frame_stride; every block decodes to at most block_bytes
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t* errflag, hipStream_t stream);

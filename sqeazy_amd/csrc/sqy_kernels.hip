@@ -1508,34 +1508,210 @@ void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ o
 // decode (src/sqeazy.cpp:281-335 -> dynamic_pipeline.hpp:740-846): LZ4 frames, inverse filters.
 // ------------------------------------------------------------------------------------------------
 
-// Walk the concatenated LZ4 frames once (one lane chases the size fields) and record every block:
-//   blk[i] = {offset of the block's data in the stream, size | raw flag << 31, frame id, block id in frame}
-// frame_first[f] = index of the first block of frame f.  counts[0] = #frames, counts[1] = #blocks, counts[2] = error.
+// ------------------------------------------------------------------------------------------------
+// Frame index.  blk[i] = {offset of block i's data in the stream (lo, hi), size | raw flag << 31, block id in its frame},
+// frame_first[f] = index of the first block of frame f, counts[0..2] = #frames, #blocks, error code.
+//
+// The frames of the chunked layout form a linked list through their size fields -- walking it is a pointer chase
+// through cold memory (one lane, about 0.75 us per frame: 3 ms for the 4096 frames of a 1 GiB stack).  The fast path
+// ranks the list in parallel instead:
+//   1. lz4_frame_candidates_kernel: every position of the stream that holds the frame magic and a FLG byte sqeazy writes
+//      is a candidate {pos, first block size field, FLG, "the four bytes in front are zero"}, appended to a list and
+//      entered into an open-addressing table pos -> list index (one pass at HBM speed);
+//   2. lz4_frame_rank_kernel (one workgroup): successor of a candidate = the candidate that starts right behind its
+//      block's end mark; pointer doubling (log2 N rounds) gives every candidate its distance to the end of the stream
+//      and marks the candidates reachable from position 0 -- those are the frames, rank = distance(head) - distance.
+// Anything the fast path does not cover (multi-block frames = the serial block-linked layout, empty frames, more
+// candidates than the table holds, a chain that does not end exactly at the end of the stream) sets code 100 and the
+// host runs the serial walk (lz4_frame_index_kernel), which also produces the exact error codes for corrupt streams.
+// ------------------------------------------------------------------------------------------------
+struct FrameCand { unsigned long long pos; uint32_t field; uint32_t flags; };     // flags: bit 0 = 4 zero bytes in front, bits 8..15 = FLG
+struct FrameSlot { unsigned long long key; uint32_t idx; uint32_t pad; };           // key = pos + 1, 0 = empty
+
+__device__ __forceinline__ uint32_t cand_slot(uint64_t pos, uint32_t mask)
+{
+    return (uint32_t)(((pos + 1) * 0x9E3779B97F4A7C15ull) >> 40) & mask;
+}
+
+__global__ __launch_bounds__(256)
+void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, FrameSlot* __restrict__ table, uint32_t mask,
+                                 FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand)
+{
+    // thread t inspects start positions [16 t, 16 t + 16); it needs the bytes [16 t - 4, 16 t + 27)
+    const uint64_t nvec = (n + 15) / 16;
+    for (uint64_t t = (uint64_t)blockIdx.x * 256 + threadIdx.x; t < nvec; t += (uint64_t)gridDim.x * 256) {
+        const uint64_t base = t * 16;
+        uint32_t w[9];                                                   // w[0] = bytes base-4.., w[1..4] = base.., w[5..8] = base+16..
+        if (base >= 16 && base + 32 <= n) {
+            const uint4 a = ld_u128(in + base), b = ld_u128(in + base + 16);     // the payload starts at any alignment
+            w[0] = ld_u32(in + base - 4);
+            w[1] = a.x; w[2] = a.y; w[3] = a.z; w[4] = a.w; w[5] = b.x; w[6] = b.y; w[7] = b.z; w[8] = b.w;
+        } else {
+            for (int i = 0; i < 9; ++i) {
+                uint32_t v = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const int64_t p = (int64_t)base - 4 + 4 * i + k;
+                    const uint32_t byte = (p >= 0 && (uint64_t)p < n) ? in[p] : 0xFFu;
+                    v |= byte << (8 * k);
+                }
+                w[i] = v;
+            }
+        }
+        // any byte equal to the magic's first byte in this window?  (cheap reject for almost every thread)
+        bool any = false;
+#pragma unroll
+        for (int i = 1; i <= 4; ++i) { const uint32_t x = w[i] ^ 0x04040404u; any |= ((x - 0x01010101u) & ~x & 0x80808080u) != 0; }
+        if (!any) continue;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            // little-endian window of 12 bytes starting at base + k: dwords d0 (bytes 0..3), d1 (4..7), d2 (8..11)
+            const int i = 1 + (k >> 2), sh = 8 * (k & 3);
+            const uint32_t d0 = sh ? (w[i] >> sh) | (w[i + 1] << (32 - sh)) : w[i];
+            if (d0 != 0x184D2204u) continue;
+            const uint32_t d1 = sh ? (w[i + 1] >> sh) | (w[i + 2] << (32 - sh)) : w[i + 1];
+            const uint32_t d2 = sh ? (w[i + 2] >> sh) | (w[i + 3] << (32 - sh)) : w[i + 2];
+            const uint32_t flg = d1 & 0xffu;
+            const uint64_t pos = base + (uint64_t)k;
+            if ((flg >> 6) != 1 || (flg & 0x0D) || pos + 11 > n) continue;
+            const uint32_t pz = sh ? (w[i - 1] >> sh) | (w[i] << (32 - sh)) : w[i - 1];   // the four bytes in front
+            const uint32_t idx = atomicAdd(ncand, 1u);
+            if (idx >= cap) continue;                                    // the rank kernel sees ncand > cap and gives up
+            FrameCand c;
+            c.pos = pos; c.field = (d1 >> 24) | (d2 << 8); c.flags = ((pos >= 4 && pz == 0u) ? 1u : 0u) | (flg << 8);
+            list[idx] = c;
+            uint32_t s_ = cand_slot(pos, mask);
+            for (uint32_t probe = 0; probe <= mask; ++probe, s_ = (s_ + 1) & mask) {
+                if (atomicCAS(&table[s_].key, 0ull, (unsigned long long)(pos + 1)) == 0ull) { table[s_].idx = idx; break; }
+            }
+        }
+    }
+}
+
+// one workgroup of 1024 threads; work arrays (global): succ[2][N+2], dist[2][N+2], mark[N+2]
+__global__ __launch_bounds__(1024)
+void lz4_frame_rank_kernel(const uint8_t* __restrict__ in, uint64_t n, const FrameSlot* __restrict__ table, uint32_t mask,
+                           const FrameCand* __restrict__ list, uint32_t cap, const uint32_t* __restrict__ ncand,
+                           uint32_t* __restrict__ work, uint4* __restrict__ blk, uint32_t* __restrict__ frame_first,
+                           uint64_t max_blocks, uint32_t* __restrict__ counts)
+{
+    const uint32_t tid = threadIdx.x;
+    const uint32_t N = *ncand;
+    auto give_up = [&]() { if (tid == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 100; } };
+    if (N == 0 || N > cap) { give_up(); return; }
+    const uint32_t E = N, X = N + 1, M = N + 2;                          // sentinels: end of stream, no successor
+    uint32_t* succ[2] = {work, work + M};
+    uint32_t* dist[2] = {work + 2 * M, work + 3 * M};
+    uint32_t* mark = work + 4 * M;
+    auto lookup = [&](uint64_t pos) -> uint32_t {
+        uint32_t s_ = cand_slot(pos, mask);
+        for (uint32_t probe = 0; probe <= mask; ++probe, s_ = (s_ + 1) & mask) {
+            const unsigned long long k = table[s_].key;
+            if (k == 0ull) return X;
+            if (k == (unsigned long long)(pos + 1)) return table[s_].idx;
+        }
+        return X;
+    };
+    __shared__ uint32_t head_s;
+    if (tid == 0) head_s = lookup(0);
+    for (uint32_t i = tid; i < M; i += 1024) {
+        uint32_t sc = X;
+        if (i < N) {
+            const FrameCand c = list[i];
+            const uint64_t sz = c.field & 0x7fffffffu;
+            const uint64_t e = c.pos + 11 + sz + (((c.flags >> 12) & 1u) ? 4 : 0);   // where the end mark must sit (FLG bit 4: block checksum)
+            if (c.field != 0 && e + 4 <= n) {
+                if (e + 4 == n) sc = (ld_u32(in + e) == 0u) ? E : X;
+                else { const uint32_t j = lookup(e + 4); if (j < N && (list[j].flags & 1u)) sc = j; }
+            }
+        } else if (i == E) sc = E;
+        succ[0][i] = sc;
+        dist[0][i] = i < N ? 1u : 0u;
+        mark[i] = 0;
+    }
+    __threadfence();
+    __syncthreads();
+    const uint32_t head = head_s;
+    if (head >= N) { give_up(); return; }
+    if (tid == 0) mark[head] = 1;
+    __threadfence();
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t span = 1; span < M; span <<= 1) {
+        // reachable set doubles: everything marked marks its (2^b-th) successor, then the pointers jump
+        for (uint32_t i = tid; i < N; i += 1024) if (mark[i]) { const uint32_t sc = succ[cur][i]; if (sc < N) mark[sc] = 1; }
+        for (uint32_t i = tid; i < M; i += 1024) {
+            const uint32_t sc = succ[cur][i];
+            dist[cur ^ 1][i] = dist[cur][i] + dist[cur][sc];
+            succ[cur ^ 1][i] = succ[cur][sc];
+        }
+        __threadfence();
+        __syncthreads();
+        cur ^= 1;
+    }
+    // every pointer now rests on a sentinel; the head's chain must end at the end of the stream
+    if (succ[cur][head] != E) { give_up(); return; }
+    const uint32_t L = dist[cur][head];                                  // number of frames
+    if (L > max_blocks) { give_up(); return; }
+    for (uint32_t i = tid; i < N; i += 1024) {
+        if (!mark[i]) continue;
+        const uint32_t r = L - dist[cur][i];
+        const FrameCand c = list[i];
+        const uint64_t off = c.pos + 11;
+        blk[r] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), c.field, 0u);
+        frame_first[r] = r;
+    }
+    if (tid == 0) { frame_first[L] = L; counts[0] = L; counts[1] = L; counts[2] = 0; }
+}
+
+// Serial walk (one lane chases the size fields): any layout, exact error codes.
 __global__ __launch_bounds__(64)
 void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* __restrict__ blk, uint32_t* __restrict__ frame_first,
                             uint64_t max_blocks, uint32_t* __restrict__ counts)
 {
     if (threadIdx.x != 0) return;
+    // every step fetches 16 bytes at once: behind a block's data sit the end mark (or the next block's size) and --
+    // after an end mark -- the next frame's 7 header bytes and its first block size: one dependent load per
+    // single-block frame.
     uint64_t off = 0;
     uint32_t nframes = 0, nblocks = 0, err = 0;
-    while (off < n) {
-        if (off + 7 > n || in[off] != 0x04 || in[off + 1] != 0x22 || in[off + 2] != 0x4D || in[off + 3] != 0x18) { err = 1; break; }
-        const uint32_t flg = in[off + 4];
+    auto load16 = [&](uint64_t o, uint32_t w[4]) {
+        // bytes past the end of the stream read as 0xFF (never a valid header, size fields fail the bounds checks)
+        if (o + 16 <= n) { const uint4 v = ld_u128(in + o); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; return; }
+        uint8_t b[16];
+        for (int i = 0; i < 16; ++i) b[i] = (o + i < n) ? in[o + i] : 0xFF;
+        for (int i = 0; i < 4; ++i) w[i] = (uint32_t)b[4 * i] | ((uint32_t)b[4 * i + 1] << 8) | ((uint32_t)b[4 * i + 2] << 16) | ((uint32_t)b[4 * i + 3] << 24);
+    };
+    uint32_t w[4];
+    bool have = false;                       // w[0..2] hold the 12 bytes at `off`
+    while (off < n && !err) {
+        if (!have) load16(off, w);
+        have = false;
+        // frame header: magic, FLG, BD, HC, then the first block size (bytes 7..10)
+        if (off + 7 > n || w[0] != 0x184D2204u) { err = 1; break; }
+        const uint32_t flg = w[1] & 0xffu;
         if ((flg >> 6) != 1 || (flg & 0x0D)) { err = 2; break; }       // only what sqeazy writes: no content size / checksum / dictID
         const bool block_checksum = (flg >> 4) & 1;
-        off += 7;
         frame_first[nframes] = nblocks;
+        uint32_t field = (w[1] >> 24) | (w[2] << 8);                    // bytes 7..10
+        off += 7;
         uint32_t j = 0;
         for (;;) {
             if (off + 4 > n) { err = 3; break; }
-            const uint32_t field = ld_u32(in + off);
             off += 4;
-            if (field == 0) break;
+            if (field == 0) break;                                      // end mark (a frame without blocks)
             const uint32_t sz = field & 0x7fffffffu;
             if (off + sz > n || nblocks >= max_blocks) { err = 4; break; }
             blk[nblocks] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), field, j);
             ++nblocks; ++j;
             off += sz + (block_checksum ? 4 : 0);
+            load16(off, w);                                             // next size field or end mark, and 12 bytes behind it
+            field = w[0];
+            if (field == 0 && off + 4 <= n) {                           // end mark: the 12 bytes behind it open the next frame
+                off += 4;
+                w[0] = w[1]; w[1] = w[2]; w[2] = w[3];
+                have = true;
+                break;
+            }
         }
         if (err) break;
         ++nframes;
@@ -1546,16 +1722,19 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
 
 // One wavefront per frame; the last 64 KiB of decoded output live in an LDS ring so that match copies (which may
 // overlap their own output and, in block-linked frames, reach into the previous block) never read global memory
-// the wave has just written.  Output leaves through the ring in 16-byte pieces.
-constexpr uint32_t DEC_RING = 65536;
+// the wave has just written.  Output leaves through the ring in 16-byte pieces.  The compressed bytes are parsed out of
+// a 4 KiB LDS stage refilled 64 x 16 B at a time (a token/length/offset byte costs an LDS broadcast read instead of a
+// dependent global load); stored blocks of single-block frames are copied straight from the stream to the output.
+constexpr uint32_t DEC_RING = 65536, DEC_IN = 4096;
 
 __global__ __launch_bounds__(64)
 void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
                               uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes,
                               uint32_t* __restrict__ errflag)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t dring_raw[];
+    __shared__ __attribute__((aligned(16))) uint8_t dring_raw[DEC_RING + DEC_IN];   // static: 68 KiB (dynamic LDS stops at 64 KiB by default)
     lds_u8* ring = (lds_u8*)dring_raw;
+    lds_u8* stage = (lds_u8*)dring_raw + DEC_RING;
     const int lane = threadIdx.x;
     const uint32_t f = blockIdx.x;
     const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
@@ -1586,7 +1765,24 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         const uint8_t* __restrict__ src = in + (((uint64_t)e.y << 32) | e.x);
         const uint32_t sz = e.z & 0x7fffffffu;
         if (e.z >> 31) {
-            // stored block: straight copy (through the ring, later blocks of a linked frame may reference it)
+            if (pos + sz > block_bytes * (b - b0 + 1)) { bad = true; break; }
+            if (b1 - b0 == 1) {
+                // stored block of a single-block frame: nothing will ever reference it, copy stream -> output directly
+                const uint64_t o = frame_out;
+                if (o + sz > out_bytes) { bad = true; break; }
+                uint8_t* d = out + o;
+                const uint32_t head0 = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15);
+                const uint32_t head = head0 < sz ? head0 : sz;
+                if ((uint32_t)lane < head) d[lane] = src[lane];
+                const uint32_t nvec = (sz - head) >> 4;
+                for (uint32_t i = lane; i < nvec; i += 64) st_u128(d + head + i * 16u, ld_u128(src + head + i * 16u));
+                const uint32_t done = head + (nvec << 4);
+                if ((uint32_t)lane < sz - done) d[done + lane] = src[done + lane];
+                pos += sz;
+                flushed = pos;
+                continue;
+            }
+            // stored block of a linked frame: through the ring, later blocks may reference it
             for (uint32_t i = 0; i < sz; i += 64) {
                 const uint32_t cnt = sz - i < 64 ? sz - i : 64;
                 if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[i + lane];
@@ -1598,30 +1794,65 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         }
         const uint32_t block_start = pos;
         uint32_t ip = 0;
+        uint32_t sbase = 0, shi = 0;                               // stage holds block bytes [sbase, shi)
+        auto fill = [&](uint32_t at) {
+            sbase = at & ~15u;
+#pragma unroll
+            for (uint32_t j = 0; j < DEC_IN / 1024; ++j) {
+                const uint32_t a = sbase + j * 1024u + (uint32_t)lane * 16u;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (a + 16u <= sz) v = ld_u128(src + a);
+                else if (a < sz) {                                  // the block's last, partial 16 bytes: never read past it
+                    uint32_t wv[4] = {0, 0, 0, 0};
+                    for (uint32_t k = 0; a + k < sz; ++k) wv[k >> 2] |= (uint32_t)src[a + k] << (8u * (k & 3u));
+                    v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+                }
+                const v4u vv = {v.x, v.y, v.z, v.w};
+                *reinterpret_cast<SQY_LDS v4u*>(stage + j * 1024u + (uint32_t)lane * 16u) = vv;
+            }
+            wave_lds_sync();
+            shi = sbase + DEC_IN < sz ? sbase + DEC_IN : sz;
+        };
+        auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };   // cnt <= DEC_IN - 16, at + cnt <= sz
+        auto sbyte_at = [&](uint32_t at) -> uint32_t { return stage[at - sbase]; };
+
         while (ip < sz) {
-            const uint32_t token = src[ip++];
+            need(ip, 1);
+            const uint32_t token = sbyte_at(ip++);
             uint32_t lit = token >> 4;
             if (lit == 15) {
                 uint32_t sbyte;
-                do { if (ip >= sz) { bad = true; break; } sbyte = src[ip++]; lit += sbyte; } while (sbyte == 255);
+                do { if (ip >= sz) { bad = true; break; } need(ip, 1); sbyte = sbyte_at(ip++); lit += sbyte; } while (sbyte == 255);
             }
             if (bad || ip + lit > sz || pos - block_start + lit > block_bytes) { bad = true; break; }
-            for (uint32_t i = 0; i < lit; i += 64) {
-                const uint32_t cnt = lit - i < 64 ? lit - i : 64;
-                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[ip + i + lane];
-                wave_lds_sync();
-                pos += cnt;
-                flush(false);
+            if (lit <= DEC_IN - 64u) {
+                if (lit) need(ip, lit);
+                for (uint32_t i = 0; i < lit; i += 64) {
+                    const uint32_t cnt = lit - i < 64 ? lit - i : 64;
+                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = stage[ip - sbase + i + lane];
+                    wave_lds_sync();
+                    pos += cnt;
+                    flush(false);
+                }
+            } else {
+                for (uint32_t i = 0; i < lit; i += 64) {                // long literal run: stream -> ring
+                    const uint32_t cnt = lit - i < 64 ? lit - i : 64;
+                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[ip + i + lane];
+                    wave_lds_sync();
+                    pos += cnt;
+                    flush(false);
+                }
             }
             ip += lit;
             if (ip >= sz) break;                                   // last sequence: literals only
             if (ip + 2 > sz) { bad = true; break; }
-            const uint32_t offset = (uint32_t)src[ip] | ((uint32_t)src[ip + 1] << 8);
+            need(ip, 2);
+            const uint32_t offset = sbyte_at(ip) | (sbyte_at(ip + 1) << 8);
             ip += 2;
             uint32_t ml = token & 15u;
             if (ml == 15) {
                 uint32_t sbyte;
-                do { if (ip >= sz) { bad = true; break; } sbyte = src[ip++]; ml += sbyte; } while (sbyte == 255);
+                do { if (ip >= sz) { bad = true; break; } need(ip, 1); sbyte = sbyte_at(ip++); ml += sbyte; } while (sbyte == 255);
             }
             ml += 4;
             if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
@@ -1890,11 +2121,46 @@ hipError_t launch_lz4_frame_index(const uint8_t* in, uint64_t n, void* blk, uint
     return hipGetLastError();
 }
 
+uint64_t lz4_frame_rank_scratch_bytes(uint64_t expected_frames)
+{
+    const uint64_t cap = expected_frames * 4 + 1024;                     // candidates the list holds
+    uint64_t slots = 1024;
+    while (slots < cap * 4) slots *= 2;
+    return slots * sizeof(FrameSlot) + cap * sizeof(FrameCand) + 5 * (cap + 2) * sizeof(uint32_t) + 64;
+}
+
+hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
+                                 uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream)
+{
+    const uint64_t cap = expected_frames * 4 + 1024;
+    uint64_t slots = 1024;
+    while (slots < cap * 4) slots *= 2;
+    uint8_t* p = static_cast<uint8_t*>(scratch);
+    FrameSlot* table = reinterpret_cast<FrameSlot*>(p);
+    FrameCand* list = reinterpret_cast<FrameCand*>(p + slots * sizeof(FrameSlot));
+    uint32_t* work = reinterpret_cast<uint32_t*>(p + slots * sizeof(FrameSlot) + cap * sizeof(FrameCand));
+    uint32_t* ncand = work + 5 * (cap + 2);
+    hipError_t e = hipMemsetAsync(table, 0, slots * sizeof(FrameSlot), stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(ncand, 0, 4, stream);
+    if (e != hipSuccess) return e;
+    const uint64_t nvec = (n + 15) / 16;
+    uint64_t blocks = (nvec + 255) / 256;
+    const uint64_t gcap = (uint64_t)num_cus() * 16;
+    if (blocks > gcap) blocks = gcap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(lz4_frame_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, table, (uint32_t)(slots - 1), list,
+                       (uint32_t)cap, ncand);
+    hipLaunchKernelGGL(lz4_frame_rank_kernel, dim3(1), dim3(1024), 0, stream, in, n, (const FrameSlot*)table, (uint32_t)(slots - 1),
+                       (const FrameCand*)list, (uint32_t)cap, (const uint32_t*)ncand, work, (uint4*)blk, frame_first, max_blocks, counts);
+    return hipGetLastError();
+}
+
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t* errflag, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
-    hipLaunchKernelGGL(lz4_frames_decode_kernel, dim3(nframes), dim3(64), DEC_RING, stream, in, (const uint4*)blk, frame_first, out,
+    hipLaunchKernelGGL(lz4_frames_decode_kernel, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
                        out_bytes, frame_stride, block_bytes, errflag);
     return hipGetLastError();
 }

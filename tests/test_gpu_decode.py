@@ -86,3 +86,37 @@ def test_decode_rejects_garbage(sqy, oracle):
     blob[h["size"]] ^= 0xff                                  # break the first frame's magic
     rc, _ = sqy.decode(bytes(blob))
     assert rc != 0
+
+
+def test_decode_payload_full_of_frame_magics(sqy, oracle):
+    """stored (incompressible) chunks whose bytes imitate LZ4 frame headers, some of them right behind four zero bytes:
+    the parallel frame ranking collects them as candidates and must still find exactly the real frames"""
+    rng = np.random.default_rng(21)
+    n = 5 * (256 << 10) + 12345
+    d = rng.integers(0, 256, n, dtype=np.uint8)
+    fake = np.frombuffer(bytes([0, 0, 0, 0, 0x04, 0x22, 0x4D, 0x18, 0x40, 0x50, 0x77, 0x10, 0x00, 0x00, 0x00]), np.uint8)
+    for p in rng.integers(0, n - 64, 4000):
+        d[p:p + fake.size] = fake
+    d[:fake.size - 4] = fake[4:]                              # one at the very start of the first chunk, too
+    vol = d.reshape(1, 1, -1)
+    blob = oracle.pipeline_encode("lz4", vol)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+    # the same through the device's own encoder
+    rc, blob2 = sqy.encode("lz4", vol, nthreads=2)
+    assert rc == 0 and blob2 == blob
+
+
+def test_decode_truncated_and_damaged_chunked_streams(sqy, oracle):
+    """damage in the middle of a many-frame stream: the ranking gives up, the serial walk reports the error"""
+    vol = synth.stack((24, 256, 256))
+    blob = bytearray(oracle.pipeline_encode("bitswap1->lz4", vol))
+    h = oracle.header_unpack(bytes(blob))
+    assert sqy.decode(bytes(blob))[0] == 0
+    cut = bytes(blob[:len(blob) - 7])                         # the last frame loses its end
+    assert sqy.decode(cut)[0] != 0
+    mid = h["size"] + (len(blob) - h["size"]) // 2
+    bad = bytearray(blob)
+    bad[mid:mid + 64] = bytes(64)
+    rc, back = sqy.decode(bytes(bad))
+    assert rc != 0 or not np.array_equal(back, vol)           # either refused or visibly different, never a crash

@@ -27,11 +27,15 @@ def run(pipeline, shape, dtype, reps=3, extra=0):
     L = sqeazy_amd.lib(); import ctypes
     fn = L.SQYAMD_Decode_UI16_Device if np.dtype(dtype) == np.uint16 else L.SQYAMD_Decode_UI8_Device
     rc = fn(ctypes.c_void_p(out.data_ptr()), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
+    sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     rc = fn(ctypes.c_void_p(out.data_ptr()), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
     torch.cuda.synchronize(); dd = time.perf_counter() - t0
+    sqeazy_amd.profile_enable(False)
+    pd = sqeazy_amd.profile_get()
     ok = bool((back.view(torch.uint16 if np.dtype(dtype) == np.uint16 else torch.uint8).reshape(shape) == vol).all().item()) if "quantiser" not in pipeline and "frame_shuffle" not in pipeline else None
-    print("    decode rc %d: %.2f ms = %.1f GB/s, round trip equal: %s" % (rc, dd * 1e3, nb / dd / 1e9, ok), flush=True)
+    print("    decode rc %d: %.2f ms = %.1f GB/s, round trip equal: %s | " % (rc, dd * 1e3, nb / dd / 1e9, ok) +
+          "  ".join("%s %.3f" % (k, v[0] / v[1]) for k, v in pd.items()), flush=True)
     del vol, out, back; torch.cuda.empty_cache()
 run("bitswap1->lz4", (512, 1024, 1024), np.uint16)
 run("diff3x3x1->bitswap1->lz4", (256, 2048, 2048), np.uint16)
