@@ -17,6 +17,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "sqy_kernels.h"
@@ -115,10 +116,75 @@ struct Workspace {
 // A context = one HBM workspace + one private stream.  Concurrent C-ABI calls (the reference is re-entrant:
 // every call builds its own pipeline object, src/sqeazy.cpp:123) each lease their own context, so two host
 // threads encoding different volumes overlap on the GPU instead of queueing behind a lock.
+// Host <-> HBM transfers of the reference-protocol entry points (caller memory is pageable).  A plain hipMemcpy from
+// pageable memory runs at 5-6 GB/s; here kLanes host threads each own two pinned staging buffers and a copy stream:
+// memcpy user -> pinned slice k while the DMA of slice k-1 is in flight, slices dealt round-robin to the lanes.
+struct Stager {
+    static constexpr int kLanes = 4;
+    static constexpr size_t kSlice = 8u << 20;
+    char* pin[kLanes][2] = {};
+    hipStream_t st[kLanes] = {};
+    hipEvent_t ev[kLanes][2] = {};
+    bool ready = false;
+
+    bool init()
+    {
+        if (ready) return true;
+        for (int l = 0; l < kLanes; ++l) {
+            if (hipStreamCreateWithFlags(&st[l], hipStreamNonBlocking) != hipSuccess) return false;
+            for (int b = 0; b < 2; ++b) {
+                if (hipHostMalloc((void**)&pin[l][b], kSlice, hipHostMallocDefault) != hipSuccess) return false;
+                if (hipEventCreateWithFlags(&ev[l][b], hipEventDisableTiming) != hipSuccess) return false;
+            }
+        }
+        ready = true;
+        return true;
+    }
+    // to_device: dev <- host;  else host <- dev.  Blocks until the bytes have arrived.  `after` (optional) is a stream
+    // whose work must be complete before device memory is read (D2H of freshly computed data).
+    bool copy(void* dev, void* host, size_t bytes, bool to_device, int device_id)
+    {
+        if (bytes == 0) return true;
+        if (!init()) return false;
+        const size_t nslices = (bytes + kSlice - 1) / kSlice;
+        std::atomic<bool> ok(true);
+        auto lane_fn = [&](int l) {
+            if (hipSetDevice(device_id) != hipSuccess) { ok = false; return; }
+            int b = 0;
+            size_t pending_off[2] = {0, 0}, pending_len[2] = {0, 0};
+            for (size_t k = (size_t)l; k < nslices && ok; k += kLanes, b ^= 1) {
+                const size_t off = k * kSlice, len = std::min(kSlice, bytes - off);
+                // the buffer's previous transfer must be over before it is reused
+                if (hipEventSynchronize(ev[l][b]) != hipSuccess) { ok = false; break; }
+                if (to_device) {
+                    std::memcpy(pin[l][b], static_cast<char*>(host) + off, len);
+                    if (hipMemcpyAsync(static_cast<char*>(dev) + off, pin[l][b], len, hipMemcpyHostToDevice, st[l]) != hipSuccess) { ok = false; break; }
+                } else {
+                    if (pending_len[b]) std::memcpy(static_cast<char*>(host) + pending_off[b], pin[l][b], pending_len[b]);
+                    if (hipMemcpyAsync(pin[l][b], static_cast<char*>(dev) + off, len, hipMemcpyDeviceToHost, st[l]) != hipSuccess) { ok = false; break; }
+                    pending_off[b] = off; pending_len[b] = len;
+                }
+                if (hipEventRecord(ev[l][b], st[l]) != hipSuccess) { ok = false; break; }
+            }
+            if (hipStreamSynchronize(st[l]) != hipSuccess) ok = false;
+            if (!to_device && ok)
+                for (int bb = 0; bb < 2; ++bb)
+                    if (pending_len[bb]) std::memcpy(static_cast<char*>(host) + pending_off[bb], pin[l][bb], pending_len[bb]);
+        };
+        const int lanes = (int)std::min<size_t>(kLanes, nslices);
+        std::vector<std::thread> th;
+        for (int l = 1; l < lanes; ++l) th.emplace_back(lane_fn, l);
+        lane_fn(0);
+        for (auto& t : th) t.join();
+        return ok;
+    }
+};
+
 struct Context {
     Workspace ws;
     hipStream_t stream = nullptr;       // used when the caller brings no stream (host-pointer entry points)
     std::vector<PendingEvent> pending;
+    Stager stager;
     bool busy = false;
 };
 
@@ -447,12 +513,13 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
     // documented "error 1 - destination buffer is not large enough" (inc/sqeazy.h:105) is returned instead.
     const uint64_t bound = dst_capacity >= 0 ? (uint64_t)dst_capacity : Pipeline::from_string(pipeline).max_encoded_size(raw, elem_size);
     if (ws->io_src.ensure(std::max<uint64_t>(raw, 16)) || ws->io_dst.ensure(std::max<uint64_t>(bound, 16))) return 1;
-    SQY_HIP(hipMemcpyAsync(ws->io_src.p, src, raw, hipMemcpyHostToDevice, stream));
+    int dev_id = 0;
+    SQY_HIP(hipGetDevice(&dev_id));
+    if (!lease.ctx->stager.copy(ws->io_src.p, const_cast<char*>(src), raw, true, dev_id)) { std::fprintf(stderr, "[sqeazy]\t host to device transfer failed\n"); return 1; }
     long out_len = 0;
     const int rc = encode_on_device(*lease.ctx, pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, stream);
-    if (rc) return rc;
-    SQY_HIP(hipMemcpyAsync(dst, ws->io_dst.p, (size_t)out_len, hipMemcpyDeviceToHost, stream));
-    SQY_HIP(hipStreamSynchronize(stream));
+    if (rc) return rc;                  // (returns with the blob complete: the stream has been synchronised)
+    if (!lease.ctx->stager.copy(ws->io_dst.p, dst, (size_t)out_len, false, dev_id)) { std::fprintf(stderr, "[sqeazy]\t device to host transfer failed\n"); return 1; }
     *dstlength = out_len;
     return 0;
 }
@@ -651,11 +718,13 @@ int decode_from_host(const char* src, long srclength, char* dst, int elem_size)
     for (uint64_t d : h.shape) n *= d;
     const uint64_t raw = n * (uint64_t)h.elem_size();
     if (ws->io_src.ensure(std::max<uint64_t>((uint64_t)srclength, 16)) || ws->io_dst.ensure(std::max<uint64_t>(raw, 16))) return 1;
-    SQY_HIP(hipMemcpyAsync(ws->io_src.p, src, (size_t)srclength, hipMemcpyHostToDevice, stream));
+    int dev_id = 0;
+    SQY_HIP(hipGetDevice(&dev_id));
+    if (!lease.ctx->stager.copy(ws->io_src.p, const_cast<char*>(src), (size_t)srclength, true, dev_id)) { std::fprintf(stderr, "[sqeazy]\t host to device transfer failed\n"); return 1; }
     const int rc = decode_on_device(*lease.ctx, ws->io_src.p, (uint64_t)srclength, ws->io_dst.p, raw, elem_size, stream);
     if (rc) return rc;
-    SQY_HIP(hipMemcpyAsync(dst, ws->io_dst.p, raw, hipMemcpyDeviceToHost, stream));
     SQY_HIP(hipStreamSynchronize(stream));
+    if (!lease.ctx->stager.copy(ws->io_dst.p, dst, raw, false, dev_id)) { std::fprintf(stderr, "[sqeazy]\t device to host transfer failed\n"); return 1; }
     return 0;
 }
 
