@@ -71,8 +71,8 @@ SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI8(const char* pi
 SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI16(const char* pipeline, long* shape, unsigned shape_size, long* length);
 
 /* inc/sqeazy.h:219-243, src/sqeazy.cpp:233-268.  true iff the string parses as head filters -> sink ->
- * tail filters AND every stage is implemented here: diff3x3x1, bitswap1, frame_shuffle, quantiser, lz4.
- * (The reference additionally accepts its background-removal / reorder filters and pass_through.) */
+ * tail filters AND every stage is implemented here: diff3x3x1, bitswap1, frame_shuffle, raster_reorder, quantiser, lz4.
+ * (The reference additionally accepts its background-removal filters, tile_shuffle, zcurve_reorder and pass_through.) */
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI16(const char* pipeline_string);
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI8(const char* pipeline_string);
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible(const char* pipeline_string, int sizeofpixel);

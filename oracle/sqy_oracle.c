@@ -598,3 +598,53 @@ size_t sqo_base64_encode(const uint8_t* src, size_t n, char* dst)
     }
     return o;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * raster_reorder (encoders/raster_reorder_scheme_impl.hpp:97-127, raster_reorder_utils.hpp:36-367):
+ * the 3-D index space is cut into tiles of tile_size^3 (remainder tiles at the high end of a dimension),
+ * tiles are appended one after the other in (z,y,x) tile order, each tile row-major inside.
+ *   out[ tile_offset(tz,ty,tx) + (z%ts)*ey*ex + (y%ts)*ex + (x%ts) ] = in[z,y,x]
+ * with (ez,ey,ex) the tile's extents and tile_offset the sizes of all tiles before it.
+ * The reference's result is undefined (overlapping writes / unwritten output) when only SOME dimensions
+ * have a remainder (the last tile of a remainder-free dimension gets extent 0, :271-305) and when
+ * tile_size is a proper multiple of the SSE block of 16/sizeof(T) elements on a remainder-free shape
+ * (encode_full_simd overwrites the tile row's head, :160-243): both return -1 here.
+ * ---------------------------------------------------------------------------------------------- */
+static int raster_geometry_ok(const size_t shape[3], size_t ts, int elem_size)
+{
+    if (ts == 0 || shape[0] == 0 || shape[1] == 0 || shape[2] == 0) return 0;
+    const size_t r0 = shape[0] % ts, r1 = shape[1] % ts, r2 = shape[2] % ts;
+    const int nrem = (r0 != 0) + (r1 != 0) + (r2 != 0);
+    if (nrem != 0 && nrem != 3) return 0;
+    const size_t block = 16 / (size_t)elem_size;
+    if (nrem == 0 && ts % block == 0 && ts != block) return 0;
+    return 1;
+}
+
+static size_t raster_offset(const size_t shape[3], size_t ts, size_t z, size_t y, size_t x)
+{
+    const size_t Z = shape[0], Y = shape[1], X = shape[2];
+    const size_t tz = z / ts, ty = y / ts, tx = x / ts;
+    const size_t ez = (tz + 1) * ts <= Z ? ts : Z - tz * ts;
+    const size_t ey = (ty + 1) * ts <= Y ? ts : Y - ty * ts;
+    const size_t ex = (tx + 1) * ts <= X ? ts : X - tx * ts;
+    /* tiles before: whole tile layers, whole tile rows of this layer, tiles of this row */
+    const size_t tile_off = tz * ts * Y * X + ez * (ty * ts * X + ey * tx * ts);
+    return tile_off + (z % ts) * ey * ex + (y % ts) * ex + (x % ts);
+}
+
+int sqo_raster_reorder(const void* in, void* out, const size_t shape[3], size_t tile_size, int elem_size, int decode)
+{
+    if (!raster_geometry_ok(shape, tile_size, elem_size)) return -1;
+    const size_t Z = shape[0], Y = shape[1], X = shape[2];
+    const uint8_t* s = (const uint8_t*)in;
+    uint8_t* d = (uint8_t*)out;
+    for (size_t z = 0; z < Z; ++z)
+        for (size_t y = 0; y < Y; ++y)
+            for (size_t x = 0; x < X; ++x) {
+                const size_t lin = (z * Y + y) * X + x, off = raster_offset(shape, tile_size, z, y, x);
+                if (decode) memcpy(d + lin * (size_t)elem_size, s + off * (size_t)elem_size, (size_t)elem_size);
+                else memcpy(d + off * (size_t)elem_size, s + lin * (size_t)elem_size, (size_t)elem_size);
+            }
+    return 0;
+}

@@ -67,6 +67,8 @@ void sqo_quantiser_apply_u8(const uint8_t* in, size_t len, const uint8_t* lut_en
 /* ---- frame_shuffle : encoders/frame_shuffle_utils.hpp:91-172 (frame_chunk_size=1) ----
  * writes permuted volume and decode_map[z] (source frame of output slot z). */
 int sqo_frame_shuffle_encode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3], uint64_t* decode_map);
+/* raster_reorder (raster_reorder_utils.hpp:36-367); -1 for the geometries the reference leaves undefined */
+int sqo_raster_reorder(const void* in, void* out, const size_t shape[3], size_t tile_size, int elem_size, int decode);
 int sqo_frame_shuffle_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3], uint64_t* decode_map);
 
 /* ---- base64 : base64.hpp:135-162 (RFC 4648, '=' padded) ---- */

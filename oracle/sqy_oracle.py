@@ -269,6 +269,22 @@ def quantiser_encode(a):
     return out.reshape(a.shape), dec.astype(a.dtype)
 
 
+def raster_reorder(a, tile_size=None, decode=False):
+    """raster_reorder_scheme (encoders/raster_reorder_scheme_impl.hpp:97-147); default tile = 16 / sizeof(T)"""
+    a = np.ascontiguousarray(a)
+    if a.ndim != 3:
+        raise ValueError("raster_reorder needs a 3D shape")
+    ts = int(tile_size) if tile_size else 16 // a.dtype.itemsize
+    out = np.empty_like(a)
+    L = lib()
+    L.sqo_raster_reorder.restype = ctypes.c_int
+    rc = L.sqo_raster_reorder(ctypes.c_void_p(a.ctypes.data), ctypes.c_void_p(out.ctypes.data), _shape3(a.shape),
+                              ctypes.c_size_t(ts), ctypes.c_int(a.dtype.itemsize), ctypes.c_int(1 if decode else 0))
+    if rc:
+        raise ValueError("raster_reorder: geometry the reference leaves undefined (shape %r, tile %d)" % (a.shape, ts))
+    return out
+
+
 def frame_shuffle_encode(a):
     a = np.ascontiguousarray(a)
     if a.ndim != 3:
@@ -484,6 +500,9 @@ class _Stage:
             m = parse_minors(cfg)
             self.chunk = int(m.get("frame_chunk_size", "1"))
             self.map = m.get("reorder_map", "") if "reorder_map" in m else ""
+        if name == "raster_reorder":
+            m = parse_minors(cfg)
+            self.tile = int(m["tile_size"]) if "tile_size" in m else None      # None: 16 / sizeof(T), known at encode time
 
     def config(self):
         if self.name == "bitswap1":
@@ -496,6 +515,8 @@ class _Stage:
             return ",".join("%s=%s" % kv for kv in sorted(self.cmap.items()))
         if self.name == "frame_shuffle":
             return "frame_chunk_size=%d,reorder_map=%s" % (self.chunk, self.map)
+        if self.name == "raster_reorder":
+            return "tile_size=%d" % self.tile
         raise NotImplementedError(self.name)
 
     def full_name(self):
@@ -507,14 +528,19 @@ def pipeline_name(stages):
     return "->".join(s.full_name() for s in stages)
 
 
-def build_stages(pipeline):
-    return [_Stage(n, c) for n, c in parse_pairs(pipeline)]
+def build_stages(pipeline, dtype=None):
+    stages = [_Stage(n, c) for n, c in parse_pairs(pipeline)]
+    if dtype is not None:
+        for s in stages:                                     # defaults that depend on the voxel type
+            if s.name == "raster_reorder" and s.tile is None:
+                s.tile = 16 // np.dtype(dtype).itemsize
+    return stages
 
 
 def pipeline_max_encoded_size(pipeline, nbytes, dtype, nthreads=1):
     """dynamic_pipeline::max_encoded_size (dynamic_pipeline.hpp:866-890)"""
     dtype = np.dtype(dtype)
-    stages = build_stages(pipeline)
+    stages = build_stages(pipeline, dtype)
     hdr = header_pack(dtype, (nbytes,), pipeline_name(stages), nbytes * dtype.itemsize)
     sizes = []
     for s in stages:
@@ -536,7 +562,7 @@ def pipeline_encode(pipeline, vol, nthreads=2):
     vol = np.ascontiguousarray(vol)
     if not can_be_built_from(pipeline):
         raise ValueError("invalid pipeline")
-    stages = build_stages(pipeline)
+    stages = build_stages(pipeline, vol.dtype)
     dtype = vol.dtype
     cur = vol
     seen_sink = False
@@ -552,6 +578,12 @@ def pipeline_encode(pipeline, vol, nthreads=2):
         elif s.name == "frame_shuffle":
             cur, dmap = frame_shuffle_encode(cur)
             s.map = to_verbatim(dmap)
+        elif s.name == "raster_reorder":
+            if seen_sink:
+                raise NotImplementedError("raster_reorder as a tail filter is not restated")
+            if s.tile is None:
+                s.tile = 16 // cur.dtype.itemsize
+            cur = raster_reorder(cur, s.tile)
         elif s.name == "quantiser":
             cur, dec = quantiser_encode(cur)
             s.cmap["decode_lut_string"] = to_verbatim(dec)
@@ -600,6 +632,8 @@ def pipeline_decode(blob):
             lut = lut[len("<verbatim>"):-len("</verbatim>")]
             dec = np.frombuffer(base64.b64decode(lut), dtype=dtype)
             cur = dec[np.ascontiguousarray(cur).view(np.uint8)]
+        elif s.name == "raster_reorder":
+            cur = raster_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
         elif s.name == "frame_shuffle":
             import base64
             m = s.map[len("<verbatim>"):-len("</verbatim>")]

@@ -248,7 +248,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
             std::fprintf(stderr, "[sqeazy]\t pipeline %s: %s\n", pipeline.c_str(), why.c_str());
         return 1;
     }
-    Pipeline pipe = Pipeline::from_string(pipeline);
+    Pipeline pipe = Pipeline::from_string(pipeline, elem_size);
     if (pipe.stages.empty()) {
         std::fprintf(stderr, "[sqeazy]\t received %spipeline of size 0, cannot encode buffer\n", pipe.name().c_str());
         return 1;
@@ -300,6 +300,25 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream));
                 else
                     SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
+                cur = out;
+                break;
+            }
+            case StageKind::raster_reorder: {
+                if (dims.size() != 3) {
+                    std::fprintf(stderr, "[sqeazy::detail::reorder::encode] received non-3D shape which is currently unsupported!\n");
+                    return 1;
+                }
+                const uint64_t ts = (uint64_t)std::atoi(st.cfg["tile_size"].c_str());
+                if (!sqy::raster_geometry_defined(dims[0], dims[1], dims[2], ts, cur_elem)) {
+                    std::fprintf(stderr, "[sqeazy]\t raster_reorder: the reference's result is undefined for shape %llux%llux%llu at tile_size=%llu "
+                                         "(remainder in some dimensions only, or a tile wider than one 16-byte block); refused\n",
+                                 (unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2], (unsigned long long)ts);
+                    return 1;
+                }
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                ProfScope ps("raster_reorder", stream, pend);
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, dims[0], dims[1], dims[2], ts, cur_elem, false, stream));
                 cur = out;
                 break;
             }
@@ -505,13 +524,13 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
         return 1;
     }
     const uint64_t raw = len * (uint64_t)elem_size;
-    Pipeline pipe = Pipeline::from_string(pipeline);
+    Pipeline pipe = Pipeline::from_string(pipeline, elem_size);
     pipe.set_n_threads(nthreads);
     // What the caller was told to allocate: SQY_Pipeline_Max_Compressed_Length_* evaluates the bound on a fresh
     // pipeline (n_threads = 1, sqeazy.cpp:144-231).  The reference itself writes past that for pipelines whose
     // header grows while encoding (frame_shuffle's reorder_map on stacks of many small frames); here the
     // documented "error 1 - destination buffer is not large enough" (inc/sqeazy.h:105) is returned instead.
-    const uint64_t bound = dst_capacity >= 0 ? (uint64_t)dst_capacity : Pipeline::from_string(pipeline).max_encoded_size(raw, elem_size);
+    const uint64_t bound = dst_capacity >= 0 ? (uint64_t)dst_capacity : Pipeline::from_string(pipeline, elem_size).max_encoded_size(raw, elem_size);
     if (ws->io_src.ensure(std::max<uint64_t>(raw, 16)) || ws->io_dst.ensure(std::max<uint64_t>(bound, 16))) return 1;
     int dev_id = 0;
     SQY_HIP(hipGetDevice(&dev_id));
@@ -644,6 +663,21 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }
+            case StageKind::raster_reorder: {
+                if (h.shape.size() != 3) return 1;
+                auto t = st.cfg.find("tile_size");
+                const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 0;
+                if (!sqy::raster_geometry_defined(h.shape[0], h.shape[1], h.shape[2], ts, e_in)) {
+                    std::fprintf(stderr, "[sqeazy]\t raster_reorder: tile_size %llu does not fit the shape\n", (unsigned long long)ts);
+                    return 1;
+                }
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                ProfScope ps("raster_reorder_decode", stream, pend);
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
             case StageKind::diff3x3x1: {
                 if (h.shape.size() != 3) return 1;
                 uint8_t* out = out_buf(si, stage_in_bytes);
@@ -733,7 +767,7 @@ int max_compressed_length(const char* pipeline, long pipeline_length, long* leng
     if (!pipeline || !length || pipeline_length < 0) return 1;
     const std::string s(pipeline, pipeline + pipeline_length);
     if (!Pipeline::supported(s, elem_size)) return 1;
-    const Pipeline p = Pipeline::from_string(s);
+    const Pipeline p = Pipeline::from_string(s, elem_size);
     if (p.stages.empty()) {
         std::fprintf(stderr, "[sqeazy]\t received %spipeline of size 0, cannot compite Max_Compressed_Length\n", p.name().c_str());
         return 1;
@@ -952,7 +986,7 @@ int SQYAMD_Header_Build(const char* pipeline, int sizeof_voxel, const long* shap
     if (!pipeline || !shape || !outlength || shape_size == 0 || (sizeof_voxel != 1 && sizeof_voxel != 2) || encoded_bytes < 0) return 1;
     try {
         if (!sqy::Pipeline::supported(pipeline, sizeof_voxel)) return 1;
-        const sqy::Pipeline p = sqy::Pipeline::from_string(pipeline);
+        const sqy::Pipeline p = sqy::Pipeline::from_string(pipeline, sizeof_voxel);
         std::vector<uint64_t> shp(shape, shape + shape_size);
         for (uint64_t v : shp) if ((long)v <= 0) return 1;
         const std::string hdr = sqy::header_pack(sizeof_voxel, false, shp, p.name(), (uint64_t)encoded_bytes);

@@ -30,6 +30,11 @@ hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t c
 hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);
 hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t len, const uint8_t* lut, hipStream_t stream);
 
+// raster_reorder (encoders/raster_reorder_utils.hpp): tiles of tile_size^3 (remainder tiles at the high ends) appended in
+// (z,y,x) tile order, row-major inside; decode = the inverse permutation
+hipError_t launch_raster_reorder(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size, int elem_size,
+                                 bool decode, hipStream_t stream);
+
 // frame_shuffle: per-frame mean in the reference's sequential binary32 order; frame gather out[i] = in[map[i]]
 hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream);
 hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);

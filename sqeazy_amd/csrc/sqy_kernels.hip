@@ -1484,6 +1484,37 @@ void frame_metric_scan_kernel(const T* __restrict__ in, uint64_t per_frame, floa
     if (lane == 0) metric[blockIdx.x] = (float)S;          // exact: S is the float sum
 }
 
+// ------------------------------------------------------------------------------------------------
+// raster_reorder (encoders/raster_reorder_utils.hpp:36-367).  One thread per run of a row that lies inside one tile
+// (tile_size voxels, fewer in a remainder tile): a contiguous piece of the volume <-> a contiguous piece of a tile.
+//   tile offset(tz,ty,tx) = tz*ts*Y*X + ez*(ty*ts*X + ey*tx*ts)     (ez, ey, ex = extents of the tile)
+//   in-tile offset        = (z%ts)*ey*ex + (y%ts)*ex
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256)
+void raster_reorder_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t Z, uint64_t Y, uint64_t X, uint64_t ts,
+                           uint64_t TX, bool decode)
+{
+    const uint64_t run = (uint64_t)blockIdx.x * 256 + threadIdx.x;       // (z, y, tx)
+    const uint64_t rows = Z * Y;
+    if (run >= rows * TX) return;
+    const uint64_t row = run / TX, tx = run - row * TX;
+    const uint64_t z = row / Y, y = row - z * Y;
+    const uint64_t tz = z / ts, ty = y / ts;
+    const uint64_t ez = (tz + 1) * ts <= Z ? ts : Z - tz * ts;
+    const uint64_t ey = (ty + 1) * ts <= Y ? ts : Y - ty * ts;
+    const uint64_t ex = (tx + 1) * ts <= X ? ts : X - tx * ts;
+    const uint64_t lin = row * X + tx * ts;
+    const uint64_t til = tz * ts * Y * X + ez * (ty * ts * X + ey * tx * ts) + (z - tz * ts) * ey * ex + (y - ty * ts) * ex;
+    const T* s = decode ? in + til : in + lin;
+    T* d = decode ? out + lin : out + til;
+    if (ex * sizeof(T) == 16 && ((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+    } else {
+        for (uint64_t i = 0; i < ex; ++i) d[i] = s[i];
+    }
+}
+
 // out frame i = in frame map[i]
 __global__ __launch_bounds__(256)
 void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t frame_bytes,
@@ -2111,6 +2142,23 @@ hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t f
     if (bpf > 64) bpf = 64;
     hipLaunchKernelGGL(frame_gather_kernel, dim3((unsigned)(Z * bpf)), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, frame_bytes,
                        map, (uint32_t)bpf);
+    return hipGetLastError();
+}
+
+hipError_t launch_raster_reorder(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size, int elem_size,
+                                 bool decode, hipStream_t stream)
+{
+    if (Z * Y * X == 0 || tile_size == 0) return hipSuccess;
+    const uint64_t TX = (X + tile_size - 1) / tile_size;
+    const uint64_t runs = Z * Y * TX;
+    const uint64_t blocks = (runs + 255) / 256;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    if (elem_size == 2)
+        hipLaunchKernelGGL((raster_reorder_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out,
+                           Z, Y, X, tile_size, TX, decode);
+    else
+        hipLaunchKernelGGL((raster_reorder_kernel<uint8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out,
+                           Z, Y, X, tile_size, TX, decode);
     return hipGetLastError();
 }
 

@@ -167,6 +167,7 @@ static StageKind kind_of(const std::string& n)
     if (n == "diff3x3x1") return StageKind::diff3x3x1;
     if (n == "bitswap1") return StageKind::bitswap1;
     if (n == "frame_shuffle") return StageKind::frame_shuffle;
+    if (n == "raster_reorder") return StageKind::raster_reorder;
     if (n == "quantiser") return StageKind::quantiser;
     if (n == "lz4") return StageKind::lz4;
     if (n == "pass_through") return StageKind::pass_through;
@@ -188,6 +189,10 @@ std::string Stage::config() const
                 if (count++ < cfg.size() - 1) s += ",";
             }
             return s;
+        }
+        case StageKind::raster_reorder: {                                        // raster_reorder_scheme_impl.hpp:53-59
+            auto t = cfg.find("tile_size");
+            return "tile_size=" + std::to_string(t != cfg.end() ? std::atoi(t->second.c_str()) : 0);
         }
         case StageKind::frame_shuffle: {                                         // frame_shuffle_scheme_impl.hpp:58-66
             auto c = cfg.find("frame_chunk_size");
@@ -252,7 +257,7 @@ bool Pipeline::reference_accepts(const std::string& s)
     return value && rebuild == s.size();
 }
 
-Pipeline Pipeline::from_string(const std::string& s)
+Pipeline Pipeline::from_string(const std::string& s, int elem_size)
 {
     // dynamic_pipeline.hpp:137-170: head filters until the first sink, then tail filters; unknown names are skipped
     Pipeline p;
@@ -262,6 +267,8 @@ Pipeline Pipeline::from_string(const std::string& s)
         st.kind = kind_of(pr.first);
         st.cfg = parse_minors(pr.second);
         if (st.kind == StageKind::lz4) st.lz4 = Lz4Params(pr.second);
+        if (st.kind == StageKind::raster_reorder && elem_size > 0 && !st.cfg.count("tile_size"))
+            st.cfg["tile_size"] = std::to_string(16 / elem_size);                  // raster_reorder_scheme_impl.hpp:23
         if (p.sink_index < 0) {
             if (known_head_filter(pr.first)) { p.stages.push_back(st); continue; }
             if (known_sink(pr.first)) { p.sink_index = (int)p.stages.size(); p.stages.push_back(st); }
@@ -293,6 +300,12 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
                     return fail("frame_shuffle: only frame_chunk_size=1 is implemented on MI355X");
                 break;
             }
+            case StageKind::raster_reorder: {
+                if (after_sink) return fail("raster_reorder as a tail filter is not implemented on MI355X");
+                auto t = st.cfg.find("tile_size");
+                if (t != st.cfg.end() && std::atoi(t->second.c_str()) <= 0) return fail("raster_reorder: tile_size must be positive");
+                break;
+            }
             case StageKind::quantiser: {
                 if (elem_size != 2) return fail("quantiser: only 16-bit input is implemented on MI355X");
                 auto w = st.cfg.find("weighting_function");
@@ -321,6 +334,16 @@ std::string Pipeline::name() const
         v += stages[i].full_name();
     }
     return v;
+}
+
+bool raster_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t ts, int elem_size)
+{
+    if (ts == 0 || Z == 0 || Y == 0 || X == 0) return false;
+    const int nrem = (Z % ts != 0) + (Y % ts != 0) + (X % ts != 0);
+    if (nrem != 0 && nrem != 3) return false;                            // raster_reorder_utils.hpp:271-305: extent-0 tiles
+    const uint64_t block = 16 / (uint64_t)elem_size;
+    if (nrem == 0 && ts % block == 0 && ts != block) return false;       // :160-243: encode_full_simd overwrites the tile row's head
+    return true;
 }
 
 int clean_number_of_threads(int n)

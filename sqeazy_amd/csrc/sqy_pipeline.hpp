@@ -27,7 +27,7 @@ std::vector<std::string> split_outside_verbatim(const std::string& s, const std:
 pairs_t parse_pairs(const std::string& pipeline);
 std::map<std::string, std::string> parse_minors(const std::string& cfg);
 
-enum class StageKind { diff3x3x1, bitswap1, frame_shuffle, quantiser, lz4, pass_through, unsupported };
+enum class StageKind { diff3x3x1, bitswap1, frame_shuffle, raster_reorder, quantiser, lz4, pass_through, unsupported };
 
 struct Lz4Params {
     int accel = 1;
@@ -64,7 +64,8 @@ struct Pipeline {
     static bool reference_accepts(const std::string& s);
     // true when every stage is one this library implements (subset of the above)
     static bool supported(const std::string& s, int elem_size, std::string* why = nullptr);
-    static Pipeline from_string(const std::string& s);
+    // elem_size > 0 fills the defaults that depend on the voxel type (raster_reorder: tile_size = 16 / sizeof(T))
+    static Pipeline from_string(const std::string& s, int elem_size = 0);
 
     std::string name() const;
     uint64_t max_encoded_size(uint64_t nbytes, int elem_size) const;
@@ -72,6 +73,11 @@ struct Pipeline {
 };
 
 int clean_number_of_threads(int n);
+
+// raster_reorder (encoders/raster_reorder_utils.hpp:36-367): false for the geometries whose result the reference leaves
+// undefined (a remainder in some but not all dimensions; tile_size a proper multiple of the 16-byte SSE block on a
+// remainder-free shape)
+bool raster_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size, int elem_size);
 
 // ---- header ----
 std::string header_pack(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,

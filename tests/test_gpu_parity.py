@@ -149,3 +149,26 @@ def test_quantiser(sqy, oracle, pipeline):
         assert rc == 0
         want = oracle.pipeline_encode(pipeline, vol)
         assert blob == want, (pipeline, vol.shape)
+
+
+@pytest.mark.parametrize("pipeline", ["raster_reorder->lz4", "raster_reorder(tile_size=4)->bitswap1->lz4", "raster_reorder(tile_size=5)",
+                                      "diff3x3x1->raster_reorder->lz4"])
+def test_raster_reorder(sqy, oracle, pipeline):
+    """raster_reorder as a head filter: full tiles (default tile = one 16-byte block), remainder tiles in all three
+    dimensions, u16 and u8; blob bytes against the oracle and back through SQY_Decode"""
+    vols = [synth.stack((32, 64, 96), np.uint16), synth.stack((16, 32, 48), np.uint8)]
+    if "tile_size=5" in pipeline:
+        vols = [synth.stack((33, 64, 97), np.uint16), synth.stack((7, 13, 21), np.uint8)]          # remainders everywhere
+    if "tile_size=4" in pipeline:
+        vols = [synth.stack((32, 64, 96), np.uint16), synth.stack((33, 66, 99), np.uint16)]        # full, and remainder 1/2/3
+    if pipeline.startswith("diff"):
+        vols = [synth.stack((32, 64, 96), np.uint16)]
+    for vol in vols:
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2)
+        assert rc == 0, (pipeline, vol.shape)
+        assert blob == oracle.pipeline_encode(pipeline, vol), (pipeline, vol.shape, vol.dtype)
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, vol)
+    # undefined in the reference: refused
+    assert sqy.encode("raster_reorder(tile_size=4)->lz4", synth.stack((8, 8, 9), np.uint16), nthreads=2)[0] == 1
+    assert sqy.encode("raster_reorder(tile_size=16)->lz4", synth.stack((16, 16, 32), np.uint16), nthreads=2)[0] == 1

@@ -125,3 +125,32 @@ def test_header_alignment_and_delimiter(oracle):
     name = "quantiser(decode_lut_string=<verbatim>ab/cd+ef==</verbatim>)->lz4"
     h = oracle.header_pack(np.uint16, (2, 2, 2), name, 1)
     assert oracle.header_unpack(h)["pipename"] == name
+
+
+def test_raster_reorder_reference_kats(oracle):
+    """tests/test_raster_reorder_scheme_impl.cpp: uint16 cube of 8 holding 0..511
+       :178-201 tile_of_4 (first 32 outputs), :234-255 tile_of_3 (remainder tiles, first 18 outputs),
+       :154-176 / :203-230 label stacks (every tile's voxels end up contiguous), round trips :314-374"""
+    ramp = np.arange(512, dtype=np.uint16).reshape(8, 8, 8)
+    e4 = oracle.raster_reorder(ramp, 4).reshape(-1)
+    assert e4[:32].tolist() == [0, 1, 2, 3, 8, 9, 10, 11, 16, 17, 18, 19, 24, 25, 26, 27,
+                                64, 65, 66, 67, 72, 73, 74, 75, 80, 81, 82, 83, 88, 89, 90, 91]
+    e3 = oracle.raster_reorder(ramp, 3).reshape(-1)
+    assert e3[:18].tolist() == [0, 1, 2, 8, 9, 10, 16, 17, 18, 64, 65, 66, 72, 73, 74, 80, 81, 82]
+    for ts in (2, 4):
+        z, y, x = np.indices((8, 8, 8))
+        n = 8 // ts
+        labels = ((z // ts) * n * n + (y // ts) * n + x // ts).astype(np.uint16)     # label_stack_by_tile (:20-57)
+        want = np.repeat(np.arange(n ** 3, dtype=np.uint16), ts ** 3)                  # encoded_tile_labels (:59-94)
+        assert np.array_equal(oracle.raster_reorder(labels, ts).reshape(-1), want)
+    for ts in (2, 3, 4, 5, 7, 8):
+        assert np.array_equal(oracle.raster_reorder(oracle.raster_reorder(ramp, ts), ts, decode=True), ramp)
+    # default tile = 16 / sizeof(T) (raster_reorder_scheme_impl.hpp:23) and it shows in the pipeline name
+    blob = oracle.pipeline_encode("raster_reorder->lz4", ramp)
+    assert oracle.header_unpack(blob)["pipename"].startswith("raster_reorder(tile_size=8)->lz4(")
+    assert np.array_equal(oracle.pipeline_decode(blob), ramp)
+    # geometries whose result the reference leaves undefined are refused, not invented
+    with pytest.raises(ValueError):
+        oracle.raster_reorder(np.zeros((8, 8, 9), np.uint16), 4)          # remainder in x only
+    with pytest.raises(ValueError):
+        oracle.raster_reorder(np.zeros((16, 16, 16), np.uint16), 16)      # tile = 2 SSE blocks, encode_full_simd overwrites
