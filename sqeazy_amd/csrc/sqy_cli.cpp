@@ -420,7 +420,7 @@ void usage(const char* me)
               << "  compare     compare two stacks and see if they are equal              (compare|cmp)\n"
               << "  bench       benchmark the compression to native sqy format            (ben|bench)\n\n"
               << "options:\n"
-              << "  -p, --pipeline <str>       compression pipeline (default bitswap1->lz4); stages: diff3x3x1, bitswap1, frame_shuffle, quantiser, lz4\n"
+              << "  -p, --pipeline <str>       compression pipeline (default bitswap1->lz4); stages: diff3x3x1, bitswap1, frame_shuffle, raster_reorder, quantiser, lz4\n"
               << "  -o, --output_name <file>   output file (single input only)\n"
               << "  -e, --output_suffix <ext>  output extension (compress: .sqy; decompress: .tif or .raw)\n"
               << "  -n, --nthreads <n>         LZ4 layout selector as in the reference; 0 = all (default), 1 is not available on the GPU\n"

@@ -1798,17 +1798,9 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         if (e.z >> 31) {
             if (pos + sz > block_bytes * (b - b0 + 1)) { bad = true; break; }
             if (b1 - b0 == 1) {
-                // stored block of a single-block frame: nothing will ever reference it, copy stream -> output directly
-                const uint64_t o = frame_out;
-                if (o + sz > out_bytes) { bad = true; break; }
-                uint8_t* d = out + o;
-                const uint32_t head0 = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15);
-                const uint32_t head = head0 < sz ? head0 : sz;
-                if ((uint32_t)lane < head) d[lane] = src[lane];
-                const uint32_t nvec = (sz - head) >> 4;
-                for (uint32_t i = lane; i < nvec; i += 64) st_u128(d + head + i * 16u, ld_u128(src + head + i * 16u));
-                const uint32_t done = head + (nvec << 4);
-                if ((uint32_t)lane < sz - done) d[done + lane] = src[done + lane];
+                // stored block of a single-block frame: nothing will ever reference it; lz4_stored_frames_copy_kernel
+                // moves it from the stream to the output, this wave only vouches for the bounds
+                if (frame_out + sz > out_bytes) { bad = true; break; }
                 pos += sz;
                 flushed = pos;
                 continue;
@@ -1890,19 +1882,78 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
             // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
             const uint32_t lmod = (uint32_t)lane % offset;
-            for (uint32_t j = 0; j < ml; j += 64) {
+            // long matches switch to 1 KiB steps (16 bytes per lane) once enough of the match is written: byte p also
+            // equals byte p - off2 for any multiple off2 of the offset, and off2 >= 1024 makes a step's source disjoint
+            // from its destination
+            if (ml < 2048u) {                                       // the usual short match: nothing but the byte steps
+                for (uint32_t j = 0; j < ml; j += 64) {
+                    const uint32_t cnt = ml - j < 64 ? ml - j : 64;
+                    uint32_t v = 0;
+                    if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
+                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                    wave_lds_sync();
+                    pos += cnt;
+                    flush(false);
+                }
+                continue;
+            }
+            const uint32_t off2 = offset >= 1024u ? offset : offset * ((1024u + offset - 1u) / offset);
+            uint32_t j = 0;
+            while (j < ml) {
+                const uint32_t sp = (pos - off2) & (DEC_RING - 1), dp = pos & (DEC_RING - 1);
+                if (ml - j >= 1024u && j + offset >= off2 && off2 <= pos && sp + 1024u <= DEC_RING && dp + 1024u <= DEC_RING) {
+                    const v4u_any v = *reinterpret_cast<const SQY_LDS v4u_any*>(ring + sp + (uint32_t)lane * 16u);
+                    wave_lds_sync();
+                    *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = v;
+                    wave_lds_sync();
+                    pos += 1024u;
+                    j += 1024u;
+                    flush(false);
+                    continue;
+                }
                 const uint32_t cnt = ml - j < 64 ? ml - j : 64;
                 uint32_t v = 0;
                 if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
                 if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
                 wave_lds_sync();
                 pos += cnt;
+                j += cnt;
                 flush(false);
             }
         }
     }
     flush(true);
     if (bad && lane == 0) atomicExch(errflag, 1u);
+}
+
+// stored (uncompressed) blocks of single-block frames: plain copy stream -> output, one workgroup per 32 KiB slice
+constexpr uint32_t DEC_COPY_SLICE = 32768;
+
+__global__ __launch_bounds__(256)
+void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
+                                   uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint32_t slices_per_frame)
+{
+    const uint32_t f = blockIdx.x / slices_per_frame, slice = blockIdx.x % slices_per_frame;
+    const uint32_t b0 = frame_first[f];
+    if (frame_first[f + 1] - b0 != 1) return;
+    const uint4 e = blk[b0];
+    if (!(e.z >> 31)) return;
+    const uint32_t sz = e.z & 0x7fffffffu;
+    const uint64_t o = (uint64_t)f * frame_stride;
+    if (o + sz > out_bytes) return;                              // the decode kernel reports it
+    const uint32_t begin = slice * DEC_COPY_SLICE;
+    if (begin >= sz) return;
+    const uint32_t len0 = sz - begin < DEC_COPY_SLICE ? sz - begin : DEC_COPY_SLICE;
+    const uint8_t* __restrict__ s = in + (((uint64_t)e.y << 32) | e.x) + begin;
+    uint8_t* __restrict__ d = out + o + begin;
+    const int tid = threadIdx.x;
+    const uint32_t head0 = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15);
+    const uint32_t head = head0 < len0 ? head0 : len0;
+    if ((uint32_t)tid < head) d[tid] = s[tid];
+    const uint32_t nvec = (len0 - head) >> 4;
+    for (uint32_t i = tid; i < nvec; i += 256) *reinterpret_cast<uint4*>(d + head + (size_t)i * 16) = ld_u128(s + head + (size_t)i * 16);
+    const uint32_t done = head + (nvec << 4);
+    if ((uint32_t)tid < len0 - done) d[done + tid] = s[done + tid];
 }
 
 // inverse bitswap1 (bitplane_reorder_scalar.hpp:81-116): one thread per group of W voxels
@@ -2210,6 +2261,12 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     if (nframes == 0) return hipSuccess;
     hipLaunchKernelGGL(lz4_frames_decode_kernel, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
                        out_bytes, frame_stride, block_bytes, errflag);
+    {   // stored blocks of single-block frames (a block never exceeds block_bytes)
+        const uint32_t slices = (uint32_t)((block_bytes + DEC_COPY_SLICE - 1) / DEC_COPY_SLICE);
+        if (slices == 0 || (uint64_t)nframes * slices > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(lz4_stored_frames_copy_kernel, dim3(nframes * slices), dim3(256), 0, stream, in, (const uint4*)blk, frame_first,
+                           out, out_bytes, frame_stride, slices);
+    }
     return hipGetLastError();
 }
 
