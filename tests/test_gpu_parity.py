@@ -172,3 +172,17 @@ def test_raster_reorder(sqy, oracle, pipeline):
     # undefined in the reference: refused
     assert sqy.encode("raster_reorder(tile_size=4)->lz4", synth.stack((8, 8, 9), np.uint16), nthreads=2)[0] == 1
     assert sqy.encode("raster_reorder(tile_size=16)->lz4", synth.stack((16, 16, 32), np.uint16), nthreads=2)[0] == 1
+
+
+@pytest.mark.parametrize("kb", [1024, 4096])
+def test_lz4_large_blocks(sqy, oracle, kb):
+    """1 MiB and 4 MiB LZ4F block sizes: chunks of that size go through one wavefront each (positions need 20 / 22 bits of
+    the table entry, the tag shrinks accordingly)"""
+    pipeline = "bitswap1->lz4(blocksize_kb=%d,framestep_kb=%d)" % (kb, kb)
+    vol = synth.stack((40, 256, 512), np.uint16)              # 10 MiB: several chunks of either size, ragged last one
+    vol[::3, ::5, :] //= 7                                    # some structure in the low planes as well
+    rc, blob = sqy.encode(pipeline, vol, nthreads=2)
+    assert rc == 0
+    assert blob == oracle.pipeline_encode(pipeline, vol)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
