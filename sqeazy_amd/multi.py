@@ -20,16 +20,19 @@ def slab_range(Z, rank, world):
     return z0, base + (1 if rank < rem else 0)
 
 
-def exchange_sizes(nbytes, device, group=None):
+def exchange_sizes(nbytes, device, group=None, out=None, sync=True):
     """all_gather of the per-rank blob sizes (8 bytes per rank): the container's index.  Every rank learns where its
     blob sits in the container (offset = sum of the sizes of the ranks before it); the blobs themselves stay on the
-    GPUs that produced them -- slabs are independent sqeazy blobs, the path has no other exchange step."""
+    GPUs that produced them -- slabs are independent sqeazy blobs, the path has no other exchange step.
+    sync=False leaves the index on the device (tensor `out`, world int64) and does not block the host."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
-    size_t = torch.tensor([int(nbytes)], dtype=torch.int64, device=device)
-    sizes_t = torch.zeros(world, dtype=torch.int64, device=device)
+    size_t = torch.empty(1, dtype=torch.int64, device=device).fill_(int(nbytes))     # no host synchronisation
+    sizes_t = out if out is not None else torch.zeros(world, dtype=torch.int64, device=device)
     dist.all_gather_into_tensor(sizes_t, size_t, group=group)
+    if not sync:
+        return sizes_t                           # stays on the device; valid after the stream / the next fence
     return [int(v) for v in sizes_t.tolist()]
 
 

@@ -6,7 +6,7 @@ cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 P=gpurun_out/prof
 rm -rf $P; mkdir -p $P
-B="bench.py --steps 10 --warmup 2"
+B="bench.py"
 timeout -k 10 300 python3 $B > $P/bench_plain.log 2>&1 || exit 1
 tail -1 $P/bench_plain.log | cut -c1-400
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 $B --no-cpu-baseline > $P/bench_trace.log 2>&1 || exit 1
