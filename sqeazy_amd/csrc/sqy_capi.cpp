@@ -288,6 +288,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     bool payload_is_lz4 = false;
     const sqy::Lz4Params* lz4p = nullptr;
     uint64_t lz4_total = 0, lz4_nchunks = 0, lz4_chunk = 0, lz4_stride = 0;
+    const uint64_t* lz4_frame_map = nullptr;     // frame_shuffle directly in front of lz4: frames are read through the map
+    uint64_t lz4_frame_bytes = 0;
 
     for (size_t si = 0; si < pipe.stages.size(); ++si) {
         Stage& st = pipe.stages[si];
@@ -356,8 +358,10 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 float* d_sums = static_cast<float*>(ws->small.p);
                 uint64_t* d_map = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(ws->small.p) + ((Z * 4 + 15) & ~(uint64_t)15));
                 {
+                    const uint64_t fm_bytes = sqy::frame_metric_scratch_bytes(Z, per_frame, cur_elem);
+                    if (ws->lz4_scratch.ensure(std::max<uint64_t>(fm_bytes, 16))) return 1;      // free until the sink runs
                     ProfScope ps("frame_metric", stream, pend);
-                    SQY_HIP(sqy::launch_frame_metric(cur, Z, per_frame, cur_elem, d_sums, stream));
+                    SQY_HIP(sqy::launch_frame_metric(cur, Z, per_frame, cur_elem, d_sums, stream, ws->lz4_scratch.p, fm_bytes));
                 }
                 std::vector<float> sums(Z);
                 std::vector<uint64_t> map(Z);
@@ -365,16 +369,31 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 SQY_HIP(hipStreamSynchronize(stream));
                 sqy::frame_shuffle_order(sums.data(), Z, per_frame, map.data());
                 SQY_HIP(hipMemcpyAsync(d_map, map.data(), Z * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
-                uint8_t* out = next_buf(cur_len * cur_elem);
-                if (!out) return 1;
-                {
-                    ProfScope ps("frame_gather", stream, pend);
-                    SQY_HIP(sqy::launch_frame_gather(cur, out, Z, per_frame * (uint64_t)cur_elem, d_map, stream));
+                // when lz4 follows immediately and its chunks tile the frames, the permuted copy is never materialised:
+                // the LZ4 kernels read frame map[f] where the stream has frame f
+                const uint64_t frame_bytes = per_frame * (uint64_t)cur_elem;
+                bool fused = false;
+                if (si + 1 < pipe.stages.size() && pipe.stages[si + 1].kind == StageKind::lz4 && frame_bytes) {
+                    const uint64_t total = cur_len * (uint64_t)cur_elem;
+                    const uint64_t chunk = pipe.stages[si + 1].lz4.bytes_per_chunk(total);
+                    fused = chunk && frame_bytes % chunk == 0 && chunk <= pipe.stages[si + 1].lz4.block_bytes();
                 }
-                SQY_HIP(hipStreamSynchronize(stream));                     // `map` (host) is read by the async copy above
+                if (fused) {
+                    lz4_frame_map = d_map;
+                    lz4_frame_bytes = frame_bytes;
+                    SQY_HIP(hipStreamSynchronize(stream));                 // `map` (host) is read by the async copy above
+                } else {
+                    uint8_t* out = next_buf(cur_len * cur_elem);
+                    if (!out) return 1;
+                    {
+                        ProfScope ps("frame_gather", stream, pend);
+                        SQY_HIP(sqy::launch_frame_gather(cur, out, Z, frame_bytes, d_map, stream));
+                    }
+                    SQY_HIP(hipStreamSynchronize(stream));                 // `map` (host) is read by the async copy above
+                    cur = out;
+                }
                 st.cfg["frame_chunk_size"] = "1";
                 st.cfg["reorder_map"] = sqy::to_verbatim(map.data(), Z * sizeof(uint64_t));   // frame_shuffle_scheme_impl.hpp:86-90
-                cur = out;
                 break;
             }
             case StageKind::quantiser: {
@@ -427,7 +446,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 {
                     ProfScope ps("lz4_chunks", stream, pend);
                     SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                   static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream));
+                                                   static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes));
                 }
                 {
                     ProfScope ps("lz4_frame_scan", stream, pend);
@@ -483,7 +502,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
             ProfScope ps("lz4_frame_gather", stream, pend);
             SQY_HIP(sqy::launch_lz4_frame_gather(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                  static_cast<uint32_t*>(ws->csize.p), static_cast<uint64_t*>(ws->frame_off.p),
-                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream));
+                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes));
         }
     } else {
         ProfScope ps("payload_copy", stream, pend);

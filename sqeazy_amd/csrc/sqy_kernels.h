@@ -16,15 +16,19 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 
 // LZ4: every `chunk` bytes of in[0,total) compressed on its own into scratch + k*stride (capacity chunk-1);
 // csize[k] = compressed bytes, 0 when the chunk has to be stored raw.
+// frame_map != nullptr: the stream is frame frame_map[f] of `in` for f = 0, 1, .. (frame_bytes each, a multiple of chunk),
+// read in place (frame_shuffle directly in front of lz4)
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
-                             uint32_t* csize, uint64_t nchunks, hipStream_t stream);
+                             uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
+                             uint64_t frame_bytes = 0);
 // frame_off[k] = byte offset of frame k in the concatenated stream, frame_off[nchunks] = total payload bytes
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
                                  uint64_t* frame_off, hipStream_t stream);
 // writes [04 22 4D 18 | 40 | BD | HC][u32 size][data][00 00 00 00] per chunk at out + frame_off[k]
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
-                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream);
+                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
+                                   uint64_t frame_bytes = 0);
 
 // quantiser: 65536-bin histogram of u16 voxels (histo is zeroed by the launcher), and out[i] = lut[in[i]]
 hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);
@@ -36,7 +40,10 @@ hipError_t launch_raster_reorder(const void* in, void* out, uint64_t Z, uint64_t
                                  bool decode, hipStream_t stream);
 
 // frame_shuffle: per-frame mean in the reference's sequential binary32 order; frame gather out[i] = in[map[i]]
-hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream);
+hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream,
+                               void* scratch = nullptr, uint64_t scratch_bytes = 0);
+// scratch that lets long frames take the block-parallel path (16 bytes per 4 KiB block)
+uint64_t frame_metric_scratch_bytes(uint64_t Z, uint64_t per_frame, int elem_size);
 hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
 
 // ---- decode ----

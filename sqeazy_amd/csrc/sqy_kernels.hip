@@ -644,7 +644,8 @@ struct Lz4Out {
 
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
-                       uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize SQY_DIAG_ARG)
+                       uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
+                       const uint64_t* __restrict__ fmap, uint64_t fbytes SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -655,7 +656,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
     const uint64_t blk = blockIdx.x;
-    const uint8_t* __restrict__ src = in + blk * chunk;
+    // frame_shuffle in front of the sink: the stream is the frames of `in` in the order fmap gives (a chunk never straddles
+    // two frames, the host checks fbytes % chunk == 0), read in place instead of gathered into a copy first
+    const uint64_t lin = blk * chunk;
+    const uint8_t* __restrict__ src = fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin;
     const uint64_t left = total - blk * chunk;
     const uint32_t n = (uint32_t)(left < chunk ? left : chunk);
     uint8_t* __restrict__ dst = scratch + blk * stride;
@@ -1180,7 +1184,8 @@ __global__ __launch_bounds__(256)
 void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
                              const uint8_t* __restrict__ scratch, uint64_t stride,
                              const uint32_t* __restrict__ csize, const uint64_t* __restrict__ frame_off,
-                             uint8_t* __restrict__ out, uint32_t bd_byte, uint32_t hc_byte, uint32_t slices_per_chunk)
+                             uint8_t* __restrict__ out, uint32_t bd_byte, uint32_t hc_byte, uint32_t slices_per_chunk,
+                             const uint64_t* __restrict__ fmap, uint64_t fbytes)
 {
     const uint64_t k = blockIdx.x / slices_per_chunk;
     const uint32_t slice = blockIdx.x % slices_per_chunk;
@@ -1188,7 +1193,8 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
     const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
     const uint32_t c = csize[k];
     const uint32_t body = c ? c : nk;
-    const uint8_t* __restrict__ s = c ? scratch + k * stride : in + k * chunk;
+    const uint64_t lin = k * chunk;
+    const uint8_t* __restrict__ s = c ? scratch + k * stride : (fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin);
     uint8_t* __restrict__ d = out + frame_off[k];
     const int tid = threadIdx.x;
 
@@ -1390,20 +1396,15 @@ void frame_metric_kernel(const T* __restrict__ in, uint64_t Z, uint64_t per_fram
 // symbolically), and the 64 lane results are chained in lane order.  Blocks that may cross into the next binade (at most
 // a dozen per frame) are added by the lanes one after the other with real v_add_f32.  Below 2^24 everything is exact.
 // Checked against numpy's sequential float32 cumsum (tests) and, end to end, against the oracle's C loop.
+// building blocks of the exact evaluation, one 4 KiB block of a frame per wavefront step
 template <typename T>
-__global__ __launch_bounds__(64)
-void frame_metric_scan_kernel(const T* __restrict__ in, uint64_t per_frame, float* __restrict__ metric)
-{
-    constexpr uint32_t EPL = 64 / sizeof(T);              // elements per lane and block (64 bytes)
-    constexpr uint32_t BLK = 64 * EPL;
-    const int lane = threadIdx.x;
-    const T* __restrict__ p = in + (uint64_t)blockIdx.x * per_frame;
-    const uint64_t nblk = (per_frame + BLK - 1) / BLK;
-    uint64_t S = 0;                                        // the float sum, held exactly (it is an integer < 2^40)
+struct FmBlock {
+    static constexpr uint32_t EPL = 64 / sizeof(T);          // elements per lane and block (64 bytes)
+    static constexpr uint32_t BLK = 64 * EPL;
 
-    for (uint64_t b = 0; b < nblk; ++b) {
-        // this lane's 64 bytes (zero padded past the frame: adding 0 never changes the sum)
-        uint32_t x[EPL];
+    // this lane's 64 bytes of block b (zero padded past the frame: adding 0 never changes the sum)
+    static __device__ __forceinline__ void load(const T* __restrict__ p, uint64_t per_frame, uint64_t b, int lane, uint32_t x[EPL])
+    {
         const uint64_t e0 = b * BLK + (uint64_t)lane * EPL;
         if (e0 + EPL <= per_frame) {
             const uint4* q = reinterpret_cast<const uint4*>(p + e0);
@@ -1417,38 +1418,22 @@ void frame_metric_scan_kernel(const T* __restrict__ in, uint64_t per_frame, floa
 #pragma unroll
             for (uint32_t i = 0; i < EPL; ++i) x[i] = (e0 + i < per_frame) ? (uint32_t)p[e0 + i] : 0u;
         }
-        uint32_t lsum = 0;
+    }
+    static __device__ __forceinline__ uint32_t wave_sum(const uint32_t x[EPL])     // <= 4096 * 255 or 2048 * 65535 < 2^28
+    {
+        uint32_t tot = 0;
 #pragma unroll
-        for (uint32_t i = 0; i < EPL; ++i) lsum += x[i];
-        uint32_t tot = lsum;                               // <= 4096 * 255 or 2048 * 65535 < 2^28
+        for (uint32_t i = 0; i < EPL; ++i) tot += x[i];
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
-        tot = sgpr(tot);
-
-        if (S + tot < (1ull << 24)) { S += tot; continue; }            // exact regime
-        uint32_t k = 0;
-        bool safe = false;
-        if (S >= (1ull << 24)) {
-            const uint32_t e = 63u - (uint32_t)__builtin_clzll(S);
-            k = e - 23u;
-            safe = S + tot + (uint64_t)BLK * ((1ull << k) >> 1) < (1ull << (e + 1));
-        }
-        if (!safe) {
-            // the block may change binade: lanes add their elements one after the other with the hardware's float add
-            float sf = (float)S;                                       // S is representable: it IS the float sum
-            for (int L = 0; L < 64; ++L) {
-                if (lane == L) {
-#pragma unroll
-                    for (uint32_t i = 0; i < EPL; ++i) sf = sf + (float)x[i];
-                }
-                sf = __builtin_bit_cast(float, lane_read(__builtin_bit_cast(uint32_t, sf), L));
-            }
-            S = (uint64_t)sf;
-            continue;
-        }
+        return sgpr(tot);
+    }
+    // what this lane's elements do to the running sum in regime k: flags = seen-a-tie | C0 << 1 | parity-after << 2
+    static __device__ __forceinline__ void lanes(const uint32_t x[EPL], uint32_t k, uint32_t& flags, int32_t& D0, int32_t& Df)
+    {
         const uint32_t u = 1u << k, half = u >> 1, um = u - 1u;
         uint32_t seen = 0, C0 = 0, pcur = 0;
-        int32_t D0 = 0, Df = 0;
+        D0 = 0; Df = 0;
 #pragma unroll
         for (uint32_t i = 0; i < EPL; ++i) {
             const uint32_t r = x[i] & um, dbit = (x[i] >> k) & 1u;
@@ -1463,25 +1448,191 @@ void frame_metric_scan_kernel(const T* __restrict__ in, uint64_t per_frame, floa
                 else { Df += dl_nt; pcur = base ^ (up ? 1u : 0u); }
             }
         }
-        // chain the 64 lane results in order
-        uint32_t par = (uint32_t)(S >> k) & 1u;
+        flags = seen | (C0 << 1) | (pcur << 2);
+    }
+    // the 64 lane results in lane order, starting from parity par: returns the total delta, par becomes the parity after
+    static __device__ __forceinline__ int64_t chain(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, uint32_t& par)
+    {
+        const int32_t half = (int32_t)((1u << k) >> 1);
         int64_t delta = 0;
-        const uint32_t flags = seen | (C0 << 1) | (pcur << 2);
         for (int L = 0; L < 64; ++L) {
             const uint32_t fl = lane_read(flags, L);
             const int32_t d0 = (int32_t)lane_read((uint32_t)D0, L);
             if (fl & 1u) {
                 const uint32_t base = par ^ ((fl >> 1) & 1u);
-                delta += d0 + (base ? (int32_t)half : -(int32_t)half) + (int32_t)lane_read((uint32_t)Df, L);
+                delta += d0 + (base ? half : -half) + (int32_t)lane_read((uint32_t)Df, L);
                 par = (fl >> 2) & 1u;
             } else {
                 delta += d0;
                 par ^= (fl >> 1) & 1u;
             }
         }
-        S = (uint64_t)((int64_t)(S + tot) + delta);
+        return delta;
+    }
+    // both starting parities in one pass over the lanes (the block records of the planned path)
+    static __device__ __forceinline__ void chain2(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, int32_t& delta0, uint32_t& par0,
+                                                  int32_t& delta1, uint32_t& par1)
+    {
+        const int32_t half = (int32_t)((1u << k) >> 1);
+        par0 = 0; par1 = 1; delta0 = 0; delta1 = 0;
+        for (int L = 0; L < 64; ++L) {
+            const uint32_t fl = lane_read(flags, L);
+            const int32_t d0 = (int32_t)lane_read((uint32_t)D0, L);
+            if (fl & 1u) {
+                const int32_t df = (int32_t)lane_read((uint32_t)Df, L);
+                const uint32_t c = (fl >> 1) & 1u;
+                delta0 += d0 + ((par0 ^ c) ? half : -half) + df;
+                delta1 += d0 + ((par1 ^ c) ? half : -half) + df;
+                par0 = par1 = (fl >> 2) & 1u;
+            } else {
+                delta0 += d0; delta1 += d0;
+                par0 ^= (fl >> 1) & 1u; par1 ^= (fl >> 1) & 1u;
+            }
+        }
+    }
+    // the block may change binade: lanes add their elements one after the other with the hardware's float add
+    static __device__ __forceinline__ uint64_t sequential(const uint32_t x[EPL], uint64_t S, int lane)
+    {
+        float sf = (float)S;                                           // S is representable: it IS the float sum
+        for (int L = 0; L < 64; ++L) {
+            if (lane == L) {
+#pragma unroll
+                for (uint32_t i = 0; i < EPL; ++i) sf = sf + (float)x[i];
+            }
+            sf = __builtin_bit_cast(float, lane_read(__builtin_bit_cast(uint32_t, sf), L));
+        }
+        return (uint64_t)sf;
+    }
+    // one block onto the exact running sum S
+    static __device__ __forceinline__ uint64_t apply(const uint32_t x[EPL], uint32_t tot, uint64_t S, int lane)
+    {
+        if (S + tot < (1ull << 24)) return S + tot;                    // exact regime
+        if (S >= (1ull << 24)) {
+            const uint32_t e = 63u - (uint32_t)__builtin_clzll(S);
+            const uint32_t k = e - 23u;
+            if (S + tot + (uint64_t)BLK * ((1ull << k) >> 1) < (1ull << (e + 1))) {
+                uint32_t flags; int32_t D0, Df;
+                lanes(x, k, flags, D0, Df);
+                uint32_t par = (uint32_t)(S >> k) & 1u;
+                return (uint64_t)((int64_t)(S + tot) + chain(flags, D0, Df, k, par));
+            }
+        }
+        return sequential(x, S, lane);
+    }
+};
+
+// one wavefront per frame, blocks one after the other (short frames, or no scratch for the planned path below)
+template <typename T>
+__global__ __launch_bounds__(64)
+void frame_metric_scan_kernel(const T* __restrict__ in, uint64_t per_frame, float* __restrict__ metric)
+{
+    using B = FmBlock<T>;
+    const int lane = threadIdx.x;
+    const T* __restrict__ p = in + (uint64_t)blockIdx.x * per_frame;
+    const uint64_t nblk = (per_frame + B::BLK - 1) / B::BLK;
+    uint64_t S = 0;                                        // the float sum, held exactly (it is an integer < 2^40)
+    for (uint64_t b = 0; b < nblk; ++b) {
+        uint32_t x[B::EPL];
+        B::load(p, per_frame, b, lane, x);
+        S = B::apply(x, B::wave_sum(x), S, lane);
     }
     if (lane == 0) metric[blockIdx.x] = (float)S;          // exact: S is the float sum
+}
+
+// Planned path for long frames: almost all of the work leaves the per-frame serial chain.
+//   A  frame_block_sums_kernel        integer sum of every block (parallel over all blocks of all frames)
+//   B  frame_block_summaries_kernel   per block: predict the regime from the INTEGER prefix sum of the frame (the float sum
+//                                     differs from it by far less than a binade except close to a power of two) and store
+//                                     what the block does to the sum for both incoming parities {delta, parity after}
+//   C  frame_chain_kernel             one wavefront per frame walks the block records: the true S says whether a record's
+//                                     regime holds and the block stays inside the binade -- then it is one add; otherwise
+//                                     (a dozen blocks per frame) the block is evaluated from the data as above.
+struct FmRecord { int32_t d0, d1; uint32_t info; };          // info: bit 0 valid, bits 8..15 k, bit 16/17 parity after for parity-in 0/1
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void frame_block_sums_kernel(const T* __restrict__ in, uint64_t per_frame, uint32_t nb, uint64_t nblocks, uint32_t* __restrict__ bsum)
+{
+    using B = FmBlock<T>;
+    const int lane = threadIdx.x & 63;
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nblocks) return;
+    const uint64_t z = g / nb, b = g - z * nb;
+    uint32_t x[B::EPL];
+    B::load(in + z * per_frame, per_frame, b, lane, x);
+    const uint32_t tot = B::wave_sum(x);
+    if (lane == 0) bsum[g] = tot;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256)
+void frame_block_summaries_kernel(const T* __restrict__ in, uint64_t per_frame, uint32_t nb, uint64_t nblocks,
+                                  const uint32_t* __restrict__ bsum, FmRecord* __restrict__ rec)
+{
+    using B = FmBlock<T>;
+    const int lane = threadIdx.x & 63;
+    const uint64_t g = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (g >= nblocks) return;
+    const uint64_t z = g / nb, b = g - z * nb;
+    // integer prefix of the frame in front of this block
+    uint64_t P = 0;
+    for (uint64_t i = (uint64_t)lane; i < b; i += 64) P += bsum[z * nb + i];
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) P += __shfl_xor(P, o);
+    const uint32_t tot = bsum[g];
+    FmRecord r; r.d0 = 0; r.d1 = 0; r.info = 0;
+    if (P >= (1ull << 24)) {
+        const uint32_t e = 63u - (uint32_t)__builtin_clzll(P);
+        const uint32_t k = e - 23u;
+        if (P + tot + (uint64_t)B::BLK * ((1ull << k) >> 1) < (1ull << (e + 1))) {
+            uint32_t x[B::EPL];
+            B::load(in + z * per_frame, per_frame, b, lane, x);
+            uint32_t flags; int32_t D0, Df;
+            B::lanes(x, k, flags, D0, Df);
+            uint32_t p0, p1;
+            B::chain2(flags, D0, Df, k, r.d0, p0, r.d1, p1);
+            r.info = 1u | (k << 8) | (p0 << 16) | (p1 << 17);
+        }
+    }
+    if (lane == 0) rec[g] = r;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64)
+void frame_chain_kernel(const T* __restrict__ in, uint64_t per_frame, uint32_t nb, const uint32_t* __restrict__ bsum,
+                        const FmRecord* __restrict__ rec, float* __restrict__ metric)
+{
+    using B = FmBlock<T>;
+    const int lane = threadIdx.x;
+    const uint64_t z = blockIdx.x;
+    const T* __restrict__ p = in + z * per_frame;
+    uint64_t S = 0;
+    for (uint32_t base = 0; base < nb; base += 64) {
+        // records of the next 64 blocks, one per lane
+        const uint32_t mine = base + (uint32_t)lane;
+        uint32_t mtot = 0; FmRecord mr; mr.d0 = 0; mr.d1 = 0; mr.info = 0;
+        if (mine < nb) { mtot = bsum[z * nb + mine]; mr = rec[z * nb + mine]; }
+        const uint32_t cnt = nb - base < 64u ? nb - base : 64u;
+        for (uint32_t l = 0; l < cnt; ++l) {
+            const uint32_t tot = lane_read(mtot, l);
+            if (S + tot < (1ull << 24)) { S += tot; continue; }
+            const uint32_t info = lane_read(mr.info, l);
+            if (S >= (1ull << 24) && (info & 1u)) {
+                const uint32_t e = 63u - (uint32_t)__builtin_clzll(S);
+                const uint32_t k = e - 23u;
+                if (k == ((info >> 8) & 0xffu) && S + tot + (uint64_t)B::BLK * ((1ull << k) >> 1) < (1ull << (e + 1))) {
+                    const uint32_t par = (uint32_t)(S >> k) & 1u;
+                    const int32_t d = par ? (int32_t)lane_read((uint32_t)mr.d1, l) : (int32_t)lane_read((uint32_t)mr.d0, l);
+                    S = (uint64_t)((int64_t)(S + tot) + (int64_t)d);
+                    continue;
+                }
+            }
+            uint32_t x[B::EPL];                                        // the record does not apply: evaluate the block itself
+            B::load(p, per_frame, base + l, lane, x);
+            S = B::apply(x, tot, S, lane);
+        }
+    }
+    if (lane == 0) metric[z] = (float)S;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2112,14 +2263,16 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 }
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
-                             uint32_t* csize, uint64_t nchunks, hipStream_t stream)
+                             uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes)
 {
     if (nchunks == 0) return hipSuccess;
+    if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
 #ifdef SQY_LZ4_DIAG
     hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       (unsigned long long*)nullptr);
+                       frame_map, frame_bytes, (unsigned long long*)nullptr);
 #else
-    hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize);
+    hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+                       frame_map, frame_bytes);
 #endif
     return hipGetLastError();
 }
@@ -2133,12 +2286,12 @@ hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64
 
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
-                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream)
+                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes)
 {
     if (nchunks == 0) return hipSuccess;
     const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;
     hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(nchunks * slices)), dim3(256), 0, stream, in, total, chunk,
-                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices);
+                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes);
     return hipGetLastError();
 }
 
@@ -2165,11 +2318,44 @@ hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t
     return hipGetLastError();
 }
 
-hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream)
+uint64_t frame_metric_scratch_bytes(uint64_t Z, uint64_t per_frame, int elem_size)
+{
+    const uint64_t blk = 4096 / (uint64_t)elem_size;                     // FmBlock<T>::BLK
+    const uint64_t nb = (per_frame + blk - 1) / blk;
+    return Z * nb * (sizeof(uint32_t) + sizeof(FmRecord)) + 64;
+}
+
+hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream,
+                               void* scratch, uint64_t scratch_bytes)
 {
     if (Z == 0) return hipSuccess;
-    if ((per_frame * (uint64_t)elem_size) % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && Z <= 0x7fffffffull &&
-        per_frame * (elem_size == 2 ? 65535ull : 255ull) < (1ull << 39)) {
+    const bool vector_ok = (per_frame * (uint64_t)elem_size) % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && Z <= 0x7fffffffull &&
+                           per_frame * (elem_size == 2 ? 65535ull : 255ull) < (1ull << 39);
+    const uint64_t blk = 4096 / (uint64_t)elem_size;
+    const uint64_t nb = (per_frame + blk - 1) / blk;
+    if (vector_ok && nb >= 16 && nb <= 0x7fffffffull && scratch && scratch_bytes >= frame_metric_scratch_bytes(Z, per_frame, elem_size) &&
+        (Z * nb + 3) / 4 <= 0x7fffffffull) {
+        // long frames: block sums, block records, then a short chain per frame
+        const uint64_t nblocks = Z * nb;
+        uint32_t* bsum = static_cast<uint32_t*>(scratch);
+        FmRecord* rec = reinterpret_cast<FmRecord*>(static_cast<uint8_t*>(scratch) + ((nblocks * sizeof(uint32_t) + 15) & ~(uint64_t)15));
+        const unsigned grid = (unsigned)((nblocks + 3) / 4);
+        if (elem_size == 2) {
+            hipLaunchKernelGGL((frame_block_sums_kernel<uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)in, per_frame, (uint32_t)nb, nblocks, bsum);
+            hipLaunchKernelGGL((frame_block_summaries_kernel<uint16_t>), dim3(grid), dim3(256), 0, stream, (const uint16_t*)in, per_frame, (uint32_t)nb, nblocks,
+                               (const uint32_t*)bsum, rec);
+            hipLaunchKernelGGL((frame_chain_kernel<uint16_t>), dim3((unsigned)Z), dim3(64), 0, stream, (const uint16_t*)in, per_frame, (uint32_t)nb,
+                               (const uint32_t*)bsum, (const FmRecord*)rec, metric);
+        } else {
+            hipLaunchKernelGGL((frame_block_sums_kernel<uint8_t>), dim3(grid), dim3(256), 0, stream, (const uint8_t*)in, per_frame, (uint32_t)nb, nblocks, bsum);
+            hipLaunchKernelGGL((frame_block_summaries_kernel<uint8_t>), dim3(grid), dim3(256), 0, stream, (const uint8_t*)in, per_frame, (uint32_t)nb, nblocks,
+                               (const uint32_t*)bsum, rec);
+            hipLaunchKernelGGL((frame_chain_kernel<uint8_t>), dim3((unsigned)Z), dim3(64), 0, stream, (const uint8_t*)in, per_frame, (uint32_t)nb,
+                               (const uint32_t*)bsum, (const FmRecord*)rec, metric);
+        }
+        return hipGetLastError();
+    }
+    if (vector_ok) {
         // one wavefront per frame, block-parallel exact emulation of the sequential float sum
         if (elem_size == 2)
             hipLaunchKernelGGL((frame_metric_scan_kernel<uint16_t>), dim3((unsigned)Z), dim3(64), 0, stream, (const uint16_t*)in, per_frame, metric);

@@ -25,7 +25,7 @@ int main(int argc, char** argv)
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(sqy::lz4_chunks_kernel, dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, ddg);
+        hipLaunchKernelGGL(sqy::lz4_chunks_kernel, dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0, ddg);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
