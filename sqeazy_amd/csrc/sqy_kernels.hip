@@ -2032,7 +2032,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
             // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
             // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
-            const uint32_t lmod = (uint32_t)lane % offset;
+            const uint32_t lmod = offset >= 64u ? (uint32_t)lane : (uint32_t)lane % offset;   // (an integer modulo is ~40 instructions)
             // long matches switch to 1 KiB steps (16 bytes per lane) once enough of the match is written: byte p also
             // equals byte p - off2 for any multiple off2 of the offset, and off2 >= 1024 makes a step's source disjoint
             // from its destination
@@ -2159,7 +2159,18 @@ void quantiser_decode_kernel(const uint8_t* __restrict__ in, uint16_t* __restric
     __shared__ uint16_t sl[256];
     sl[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (uint64_t)gridDim.x * 256) out[i] = sl[in[i]];
+    // 8 voxels per thread and step: one 8-byte load, one 16-byte store
+    const uint64_t nvec = ((reinterpret_cast<uintptr_t>(in) & 7) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0) ? len / 8 : 0;
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * 256) {
+        const uint2 x = reinterpret_cast<const uint2*>(in)[v];
+        uint4 y;
+        y.x = (uint32_t)sl[x.x & 0xffu] | ((uint32_t)sl[(x.x >> 8) & 0xffu] << 16);
+        y.y = (uint32_t)sl[(x.x >> 16) & 0xffu] | ((uint32_t)sl[x.x >> 24] << 16);
+        y.z = (uint32_t)sl[x.y & 0xffu] | ((uint32_t)sl[(x.y >> 8) & 0xffu] << 16);
+        y.w = (uint32_t)sl[(x.y >> 16) & 0xffu] | ((uint32_t)sl[x.y >> 24] << 16);
+        reinterpret_cast<uint4*>(out)[v] = y;
+    }
+    for (uint64_t i = nvec * 8 + (uint64_t)blockIdx.x * 256 + threadIdx.x; i < len; i += (uint64_t)gridDim.x * 256) out[i] = sl[in[i]];
 }
 
 // inverse frame_shuffle: out frame map[i] = in frame i (frame_shuffle_utils.hpp:313-357)
@@ -2171,7 +2182,15 @@ void frame_scatter_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ 
     const uint32_t part = blockIdx.x % blocks_per_frame;
     const uint8_t* s = in + f * frame_bytes;
     uint8_t* d = out + map[f] * frame_bytes;
-    for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < frame_bytes; i += (uint64_t)blocks_per_frame * 256) d[i] = s[i];
+    const uint64_t nvec = frame_bytes / 16;
+    if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
+        for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < nvec; v += (uint64_t)blocks_per_frame * 256)
+            reinterpret_cast<uint4*>(d)[v] = reinterpret_cast<const uint4*>(s)[v];
+        if (part == 0)
+            for (uint64_t i = nvec * 16 + threadIdx.x; i < frame_bytes; i += 256) d[i] = s[i];
+    } else {
+        for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < frame_bytes; i += (uint64_t)blocks_per_frame * 256) d[i] = s[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
