@@ -654,6 +654,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ uint32_t table[4096];
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
+#ifdef SQY_LZ4_PAD
+    // occupancy experiment (tools/pad_experiment.sh, never set in the product build): fewer chunk waves per CU
+    __shared__ uint8_t lds_pad[SQY_LZ4_PAD];
+    lds_pad[threadIdx.x * 64 % SQY_LZ4_PAD] = (uint8_t)threadIdx.x;
+    if (total == 0xdeadbeefull) csize[blockIdx.x] = lds_pad[(blockIdx.x * 7) % SQY_LZ4_PAD];   // keeps the array alive
+#endif
     const int lane = threadIdx.x;
     const uint64_t blk = blockIdx.x;
     // frame_shuffle in front of the sink: the stream is the frames of `in` in the order fmap gives (a chunk never straddles

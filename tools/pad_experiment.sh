@@ -1,9 +1,12 @@
 #!/bin/bash
-# LDS occupancy sensitivity of the LZ4 kernel: the same build with fewer chunk waves per CU (padding experiment;
-# build the variants with SQY_EXTRA_HIPCC_FLAGS=-DSQY_LZ4_PAD=<bytes> and copy the library to libsqeazy_amd_pad<bytes>.so)
-for lib in "" _pad1536 _pad4096 _pad8192; do
-  echo "== lib$lib"
+# LDS occupancy sensitivity of the LZ4 kernel: the same build with fewer chunk waves per CU.
+#   here (no GPU):  for p in 6144 14336; do SQY_EXTRA_HIPCC_FLAGS=-DSQY_LZ4_PAD=$p python3 -m sqeazy_amd.build --force &&
+#                   cp sqeazy_amd/lib/libsqeazy_amd.so sqeazy_amd/lib/libsqeazy_amd_pad$p.so; done; python3 -m sqeazy_amd.build --force
+#   GPU box:        tools/pad_experiment.sh          (26 KiB -> 6 waves/CU; +6 KiB -> 5; +14 KiB -> 4)
+for lib in "" _pad6144 _pad14336; do
   L=$PWD/sqeazy_amd/lib/libsqeazy_amd$lib.so
+  [ -f "$L" ] || continue
+  echo "== lib$lib"
   SQEAZY_AMD_LIB=$L timeout -k 10 200 python bench.py --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
