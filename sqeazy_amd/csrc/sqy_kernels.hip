@@ -449,7 +449,11 @@ __device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
 // flight (vmcnt(0)) and the prefetch hides nothing.  commit() waits for it explicitly when ip gets within AHEAD
 // bytes of whi, one refill later.  (The compiler's own vmcnt(N) waits only become stricter by the extra
 // outstanding operation, never too weak: VMEM operations retire in order.)
-constexpr uint32_t LZ4_WIN = 8192, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
+#ifndef SQY_LZ4_WIN
+#define SQY_LZ4_WIN 8192
+#define SQY_LZ4_AHEAD 2048
+#endif
+constexpr uint32_t LZ4_WIN = SQY_LZ4_WIN, LZ4_FB = 1024, LZ4_AHEAD = SQY_LZ4_AHEAD, LZ4_MIRROR = 16;
 
 struct Lz4Window {
     glb_u8* src;           // chunk source (global)
