@@ -1,0 +1,42 @@
+"""The C-ABI is re-entrant like the reference's (SURVEY 8b "Threading"): calls from several host threads at once, mixed
+encode/decode, different pipelines and shapes, more threads than pooled contexts -- every result must be the oracle's."""
+import threading
+
+import numpy as np
+import pytest
+
+from sqeazy_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def test_many_threads_mixed_calls(sqy, oracle):
+    jobs = [("bitswap1->lz4", synth.stack((24, 128, 160), np.uint16)),
+            ("diff3x3x1->bitswap1->lz4", synth.stack((20, 96, 128), np.uint16)),
+            ("lz4", synth.stack((16, 200, 300), np.uint8)),
+            ("quantiser->bitswap1->lz4", synth.stack((12, 128, 128), np.uint16)),
+            ("raster_reorder->lz4", synth.stack((16, 64, 96), np.uint16)),
+            ("frame_shuffle->lz4", synth.stack((18, 64, 128), np.uint8))]
+    want = [oracle.pipeline_encode(p, v) for p, v in jobs]
+    back = [oracle.pipeline_decode(b) for b in want]
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(8):
+                k = (t + it) % len(jobs)
+                p, v = jobs[k]
+                extra = 16 * v.shape[0] + 512 if "frame_shuffle" in p else 0
+                rc, blob = sqy.encode(p, v, nthreads=0, extra_capacity=extra)
+                assert rc == 0 and blob == want[k], ("encode", t, it, p)
+                rc, dec = sqy.decode(blob)
+                assert rc == 0 and np.array_equal(dec, back[k]), ("decode", t, it, p)
+        except Exception as e:   # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(12)]     # more than the 8 pooled contexts
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors[:3]
