@@ -418,6 +418,8 @@ void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __rest
 //     probe as candidate instead, resolved in lane order;
 //   - the table is then restored and the committed prefix re-inserted with ds_max (positions grow).
 // Match extension, backward catch-up, literal copies and token emission are wave-parallel.
+// Two implementations of the batch share the loop: the LEAN loop for the batch right after a match (15 probes + the
+// pending ip-2 insertion in one round of LDS reads, see there) and the GENERIC path (64 probes, any step schedule).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t LZ4_MFLIMIT = 12, LZ4_LASTLITERALS = 5, LZ4_MINLENGTH = 13, LZ4_MAXD = 65535;
 
@@ -589,13 +591,6 @@ __device__ __forceinline__ uint32_t common16(const Lz4Window& w, uint32_t a, uin
     return c;
 }
 
-// h of the lane `d` lanes below (DPP row_shr, valid inside a row of 16 lanes; lanes < d get ~0)
-template <int D>
-__device__ __forceinline__ uint32_t row_shr(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffffu, (int)v, 0x110 + D, 0xf, 0xf, false);
-}
-
 // Compressed bytes are staged in LDS and written out in 16-byte pieces when the stage fills: the parse then
 // issues almost no global stores, so the s_waitcnt vmcnt(0) in front of the occasional global LOAD (far
 // candidate, window refill) no longer queues behind a stream of tiny stores on the critical path.
@@ -741,7 +736,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             uint32_t fwl = 0;                // forward bytes beyond MINMATCH for the winner: exact when fw_exact, else "at least"
             bool fw_exact = false;
             uint32_t bkl = 0xffffffffu;      // bytes known equal in front of (ip, match) for the winner (0..3 exact), ~0 = unknown
-            bool batch_done = false;         // fast path handled table commit
+            bool batch_done = false;         // the lean loop found the winner and committed the table; the tail below finishes the match
             uint32_t nvalid = 64, next_P = 0;
 
             // ---------------------------------------------------------------------------------------
