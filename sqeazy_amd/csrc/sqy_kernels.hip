@@ -1995,9 +1995,122 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };   // cnt <= DEC_IN - 16, at + cnt <= sz
         auto sbyte_at = [&](uint32_t at) -> uint32_t { return stage[at - sbase]; };
 
+        // match copy: `ml` bytes from `offset` bytes back, onto the ring at pos
+        auto copy_match = [&](uint32_t offset, uint32_t ml) {
+            // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
+            // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
+            const uint32_t lmod = offset >= 64u ? (uint32_t)lane : (uint32_t)lane % offset;   // (an integer modulo is ~40 instructions)
+            // long matches switch to 1 KiB steps (16 bytes per lane) once enough of the match is written: byte p also
+            // equals byte p - off2 for any multiple off2 of the offset, and off2 >= 1024 makes a step's source disjoint
+            // from its destination
+            if (ml < 2048u) {                                       // the usual short match: nothing but the byte steps
+                for (uint32_t j = 0; j < ml; j += 64) {
+                    const uint32_t cnt = ml - j < 64 ? ml - j : 64;
+                    uint32_t v = 0;
+                    if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
+                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                    wave_lds_sync();
+                    pos += cnt;
+                    flush(false);
+                }
+                return;
+            }
+            const uint32_t off2 = offset >= 1024u ? offset : offset * ((1024u + offset - 1u) / offset);
+            uint32_t j = 0;
+            while (j < ml) {
+                const uint32_t sp = (pos - off2) & (DEC_RING - 1), dp = pos & (DEC_RING - 1);
+                if (ml - j >= 1024u && j + offset >= off2 && off2 <= pos && sp + 1024u <= DEC_RING && dp + 1024u <= DEC_RING) {
+                    const v4u_any v = *reinterpret_cast<const SQY_LDS v4u_any*>(ring + sp + (uint32_t)lane * 16u);
+                    wave_lds_sync();
+                    *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = v;
+                    wave_lds_sync();
+                    pos += 1024u;
+                    j += 1024u;
+                    flush(false);
+                    continue;
+                }
+                const uint32_t cnt = ml - j < 64 ? ml - j : 64;
+                uint32_t v = 0;
+                if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
+                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                wave_lds_sync();
+                pos += cnt;
+                j += cnt;
+                flush(false);
+            }
+        };
         while (ip < sz) {
-            need(ip, 1);
-            const uint32_t token = sbyte_at(ip++);
+            // a sequence whose header (token, a few literals, offset, match-length extension bytes) lies inside 16 bytes --
+            // nearly all of them -- is parsed out of ONE 16-byte broadcast read of the stage
+            uint32_t token;
+            bool have_token = false;
+            if (ip + 16u <= sz) {
+                need(ip, 16);
+                const v4u_any hw = *reinterpret_cast<const SQY_LDS v4u_any*>(stage + (ip - sbase));
+                const uint32_t w0 = sgpr(hw.x);
+                const uint32_t tok = w0 & 0xffu, flit = tok >> 4, fml = tok & 15u;
+                token = tok; have_token = true;
+                if (flit <= 13u && fml < 15u) {
+                    // no extension bytes at all: token, literals, offset
+                    const uint32_t w1 = sgpr(hw.y), w2 = sgpr(hw.z), w3 = sgpr(hw.w);
+                    const uint32_t oi = 1u + flit;
+                    const uint64_t lo = ((uint64_t)w1 << 32) | w0, hi = ((uint64_t)w3 << 32) | w2;
+                    const uint32_t b0 = oi < 8u ? (uint32_t)(lo >> (8u * oi)) & 0xffu : (uint32_t)(hi >> (8u * (oi - 8u))) & 0xffu;
+                    const uint32_t oj = oi + 1u;
+                    const uint32_t b1 = oj < 8u ? (uint32_t)(lo >> (8u * oj)) & 0xffu : (uint32_t)(hi >> (8u * (oj - 8u))) & 0xffu;
+                    const uint32_t offset = b0 | (b1 << 8);
+                    const uint32_t ml = fml + 4u;
+                    if (offset == 0 || offset > pos + flit || pos - block_start + flit + ml > block_bytes) { bad = true; break; }
+                    if (flit) {
+                        const uint32_t bi = 1u + (uint32_t)lane;               // literal k is window byte 1 + k
+                        const uint32_t wsel = bi < 4u ? w0 : bi < 8u ? w1 : bi < 12u ? w2 : w3;
+                        if ((uint32_t)lane < flit) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)(wsel >> (8u * (bi & 3u)));
+                        wave_lds_sync();
+                        pos += flit;
+                    }
+                    const uint32_t lm = offset >= 64u ? (uint32_t)lane : (uint32_t)lane % offset;
+                    uint32_t v = 0;
+                    if ((uint32_t)lane < ml) v = ring[(pos - offset + lm) & (DEC_RING - 1)];
+                    if ((uint32_t)lane < ml) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                    wave_lds_sync();
+                    pos += ml;
+                    ip += 3u + flit;
+                    flush(false);
+                    continue;
+                }
+                if (flit <= 11u && fml == 15u) {
+                    // match-length extension bytes inside the window
+                    const uint32_t w1 = sgpr(hw.y), w2 = sgpr(hw.z), w3 = sgpr(hw.w);
+                    const uint64_t lo = ((uint64_t)w1 << 32) | w0, hi = ((uint64_t)w3 << 32) | w2;
+                    auto wbyte = [&](uint32_t i) -> uint32_t {      // window byte i (uniform), i < 16
+                        return i < 8u ? (uint32_t)(lo >> (8u * i)) & 0xffu : (uint32_t)(hi >> (8u * (i - 8u))) & 0xffu;
+                    };
+                    const uint32_t offset = wbyte(1u + flit) | (wbyte(2u + flit) << 8);
+                    uint32_t ml = 15u, used = 3u + flit;
+                    bool parsed = false;
+                    while (used < 16u) {
+                        const uint32_t sbyte = wbyte(used++);
+                        ml += sbyte;
+                        if (sbyte != 255u) { parsed = true; break; }
+                    }
+                    if (parsed) {
+                        ml += 4u;
+                        if (offset == 0 || offset > pos + flit || pos - block_start + flit + ml > block_bytes) { bad = true; break; }
+                        if (flit) {
+                            const uint32_t bi = 1u + (uint32_t)lane;
+                            const uint32_t wsel = bi < 4u ? w0 : bi < 8u ? w1 : bi < 12u ? w2 : w3;
+                            if ((uint32_t)lane < flit) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)(wsel >> (8u * (bi & 3u)));
+                            wave_lds_sync();
+                            pos += flit;
+                        }
+                        ip += used;
+                        copy_match(offset, ml);
+                        continue;
+                    }
+                }
+            }
+            if (!have_token) { need(ip, 1); token = sbyte_at(ip); }
+            ++ip;
             uint32_t lit = token >> 4;
             if (lit == 15) {
                 uint32_t sbyte;
@@ -2035,47 +2148,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             }
             ml += 4;
             if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
-            // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
-            // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
-            const uint32_t lmod = offset >= 64u ? (uint32_t)lane : (uint32_t)lane % offset;   // (an integer modulo is ~40 instructions)
-            // long matches switch to 1 KiB steps (16 bytes per lane) once enough of the match is written: byte p also
-            // equals byte p - off2 for any multiple off2 of the offset, and off2 >= 1024 makes a step's source disjoint
-            // from its destination
-            if (ml < 2048u) {                                       // the usual short match: nothing but the byte steps
-                for (uint32_t j = 0; j < ml; j += 64) {
-                    const uint32_t cnt = ml - j < 64 ? ml - j : 64;
-                    uint32_t v = 0;
-                    if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
-                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
-                    wave_lds_sync();
-                    pos += cnt;
-                    flush(false);
-                }
-                continue;
-            }
-            const uint32_t off2 = offset >= 1024u ? offset : offset * ((1024u + offset - 1u) / offset);
-            uint32_t j = 0;
-            while (j < ml) {
-                const uint32_t sp = (pos - off2) & (DEC_RING - 1), dp = pos & (DEC_RING - 1);
-                if (ml - j >= 1024u && j + offset >= off2 && off2 <= pos && sp + 1024u <= DEC_RING && dp + 1024u <= DEC_RING) {
-                    const v4u_any v = *reinterpret_cast<const SQY_LDS v4u_any*>(ring + sp + (uint32_t)lane * 16u);
-                    wave_lds_sync();
-                    *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = v;
-                    wave_lds_sync();
-                    pos += 1024u;
-                    j += 1024u;
-                    flush(false);
-                    continue;
-                }
-                const uint32_t cnt = ml - j < 64 ? ml - j : 64;
-                uint32_t v = 0;
-                if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
-                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
-                wave_lds_sync();
-                pos += cnt;
-                j += cnt;
-                flush(false);
-            }
+            copy_match(offset, ml);
         }
     }
     flush(true);
