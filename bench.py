@@ -188,13 +188,20 @@ def main():
     sqeazy_amd.profile_enable(False)
     prof = sqeazy_amd.profile_get()
 
-    # latency of one isolated call (nothing else in flight), for the record
+    # one call at a time (nothing else in flight), for the record: latency of the call and the kernels' undisturbed durations
     fence()
-    tl = time.perf_counter()
-    rc, _n = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[0][0].data_ptr(), cap, nthreads=0,
-                                      stream=streams[0].cuda_stream)
-    torch.cuda.synchronize()
-    single_call_ms = (time.perf_counter() - tl) * 1e3
+    sqeazy_amd.profile_reset()
+    sqeazy_amd.profile_enable(True)
+    single_call_ms = None
+    for _ in range(3):
+        tl = time.perf_counter()
+        rc, _n = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[0][0].data_ptr(), cap, nthreads=0,
+                                          stream=streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - tl) * 1e3
+        single_call_ms = ms if single_call_ms is None else min(single_call_ms, ms)
+    sqeazy_amd.profile_enable(False)
+    prof_alone = sqeazy_amd.profile_get()
 
     if dist_on:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -229,6 +236,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 4),
+                         # the same kernel with the GPU to itself (one call at a time, measured right after the timed region)
+                         "alone_launch_ms": round(prof_alone[dom][0] / max(prof_alone[dom][1], 1), 4) if dom in prof_alone else None,
+                         "alone_frac": round((algo_bytes / 1e9) / (prof_alone[dom][0] / max(prof_alone[dom][1], 1) / 1e3) / HBM_PEAK_GBS, 5)
+                         if dom in prof_alone and prof_alone[dom][0] else None,
                          "kernels_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}},
         }
         if world == 1 and not args.no_cpu_baseline:
