@@ -64,6 +64,20 @@ def gen_bytes(kind, n, seed):
         return words[rng.integers(0, 50, n // 12 + 1)].reshape(-1)[:n]
     if kind == "period7":
         return np.tile(np.arange(7, dtype=np.uint8), n // 7 + 1)[:n]
+    if kind == "farrep":                                   # repeats just inside the 64 KiB window, across block borders
+        c = rng.integers(0, 256, n, dtype=np.uint8)
+        for i in range(66000, n - 300, 66000):
+            c[i:i + 300] = c[i - 65000:i - 65000 + 300]
+        return c
+    if kind == "rawmix":                                   # every other 256 KiB incompressible (stored raw), the rest zeros
+        d = rng.integers(0, 256, n, dtype=np.uint8)
+        for i in range(0, n, 2 * (256 << 10)):
+            d[i:i + (256 << 10)] = 0
+        return d
+    if kind == "periodic":
+        b = np.tile(rng.integers(0, 256, 7000, dtype=np.uint8), n // 7000 + 1)[:n].copy()
+        b[::1531] ^= 1
+        return b
     raise KeyError(kind)
 
 
@@ -107,6 +121,26 @@ def main():
         assert np.array_equal(r, mine), kb
         G["lz4_frames"].append({"kind": "8level", "n": int(d.size), "seed": 77, "config": "blocksize_kb=%d,framestep_kb=%d" % (kb, kb), "bytes": int(r.size),
                                 "sha256": sha(r.tobytes()), "source": "liblz4-1.9.3"})
+    # ---- block-linked frames: encode_serial (nthreads == 1) and chunks of several blocks ----
+    G["lz4_linked"] = []
+    lkinds = ["zeros", "random", "2level", "8level", "ramp", "sparse", "words", "farrep", "rawmix", "periodic"]
+    for kind in lkinds:
+        for n in (300000, 2 * (1 << 20) + 12345):
+            d = gen_bytes(kind, n, 3000 + n)
+            for cfg, step, bid in (("", 256 << 10, 5), ("blocksize_kb=64", 256 << 10, 4), ("framestep_kb=1024", 1 << 20, 5),
+                                   ("n_chunks_of_input=3", n // 3, 5), ("blocksize_kb=64,n_chunks_of_input=7", n // 7, 4)):
+                c = o.Lz4Config(cfg)
+                assert c.bytes_per_chunk(n) == min(step, n) and c.block_id == bid, (cfg, c.bytes_per_chunk(n), step)
+                r1 = ref.lz4_encode_serial(d, framestep=c.bytes_per_chunk(n), block_id=bid)
+                m1 = o.lz4_encode_serial(d, c)
+                assert np.array_equal(r1, m1), ("oracle serial frame differs from liblz4", kind, n, cfg)
+                r2 = ref.lz4_encode_parallel(d, chunk=c.bytes_per_chunk(n), block_id=bid, nthreads=2)
+                m2 = o.lz4_encode_chunked(d, c)
+                assert np.array_equal(r2, m2), ("oracle multi-block chunks differ from liblz4", kind, n, cfg)
+                G["lz4_linked"].append({"kind": kind, "n": n, "seed": 3000 + n, "config": cfg,
+                                        "serial_bytes": int(r1.size), "serial_sha256": sha(r1.tobytes()),
+                                        "chunked_bytes": int(r2.size), "chunked_sha256": sha(r2.tobytes()),
+                                        "source": "liblz4-1.9.3 via sqeazy's encode_serial / encode_parallel call sequences"})
     # LZ4F constants the reference's tests pin (tests/test_lz4_sandbox.cpp:387-430)
     G["_meta"]["LZ4F_compressBound_256k"] = int(ref.lz4f_compress_bound(262144))
     G["_meta"]["LZ4F_HEADER_SIZE_MAX"] = int(ref.lib().ref_lz4f_header_size_max())
@@ -129,6 +163,8 @@ def main():
                 continue
             blob = o.pipeline_encode(pipe, vol)
             entry = {"volume": vname, "pipeline": pipe, "bytes": len(blob), "sha256": sha(blob), "source": "oracle"}
+            blob1 = o.pipeline_encode(pipe, vol, nthreads=1)
+            entry["nthreads1_bytes"], entry["nthreads1_sha256"] = len(blob1), sha(blob1)
             if pipe in ("bitswap1->lz4", "lz4") and vol.dtype == np.uint16 and vol.size % 128 == 0:
                 # fully reference-backed payload: reference SSE bitswap + liblz4 frames
                 stream = ref.bitswap1_encode_u16(vol, 2).view(np.uint8) if pipe.startswith("bitswap1") else vol.reshape(-1).view(np.uint8)
@@ -136,6 +172,9 @@ def main():
                 h = o.header_unpack(blob)
                 assert blob[h["size"]:] == payload
                 entry["payload_sha256"] = sha(payload)
+                payload1 = ref.lz4_encode_serial(stream).tobytes()
+                assert blob1[o.header_unpack(blob1)["size"]:] == payload1
+                entry["nthreads1_payload_sha256"] = sha(payload1)
                 entry["source"] = "payload: reference SSE bitswap + liblz4 1.9.3; header: oracle"
             G["pipelines"].append(entry)
 

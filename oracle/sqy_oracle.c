@@ -509,15 +509,274 @@ static size_t lz4f_write_single_block_frame(const uint8_t* src, size_t n, uint8_
     return (size_t)(op - dst);
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* Block-linked frames: lz4::encode_serial (encoders/lz4_utils.hpp:99-173) = LZ4F_compressBegin,  */
+/* one LZ4F_compressUpdate per `framestep` bytes (options NULL => stableSrc 0), LZ4F_compressEnd, */
+/* with prefs {blockLinked, autoFlush 0} (encoders/lz4.hpp:103-113).  What liblz4 1.9.3 does then: */
+/*   - one LZ4_stream_t for the frame: the byU32 table and currentOffset carry across blocks;      */
+/*   - full blocks are compressed straight from the caller's buffer, a remainder < blockSize is    */
+/*     parked in tmpBuff and compressed from there by the next update / by compressEnd;            */
+/*   - after an update that compressed from the caller's buffer the last 64 KiB are copied into    */
+/*     tmpBuff (LZ4F_localSaveDict), so the first block of the next update runs in liblz4's        */
+/*     external-dictionary mode, blocks that follow their dictionary in memory in prefix mode.     */
+/* Both modes see the same logically contiguous history (at most 65535 bytes back); they differ in */
+/* how far the backward catch-up may move the match (`lowLimit`), which is modelled per block.     */
+/* Restated from upstream behaviour; pinned against liblz4.so.1.9.3 (oracle/gen_golden.py,         */
+/* tests/test_oracle_golden.py::test_serial_*).                                                    */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint32_t table[1 << LZ4_HASHLOG];
+    uint32_t currentOffset;
+    int dict_space;          /* 0 = none (NULL), 1 = caller's buffer, 2 = tmpBuff */
+    uint64_t dict_addr;      /* address of the dictionary inside its space */
+    uint32_t dictSize;
+} lz4_stream_model;
+
+/* LZ4_compress_fast_continue(stream, block, dst, n, cap, 1) on the logical stream `s0` (position 0 = first byte of the
+ * frame's input); the block is s0[start, start+n) and sits at (space, addr) in memory. */
+static int lz4_block_continue(lz4_stream_model* st, const uint8_t* s0, uint64_t start, int n, int space, uint64_t addr,
+                              uint8_t* dst, int cap)
+{
+    /* LZ4_renormDictT */
+    if ((uint64_t)st->currentOffset + (uint32_t)n > 0x80000000u) {
+        const uint32_t delta = st->currentOffset - (64u << 10);
+        for (int i = 0; i < (1 << LZ4_HASHLOG); ++i) st->table[i] = st->table[i] < delta ? 0 : st->table[i] - delta;
+        st->currentOffset = 64u << 10;
+        if (st->dictSize > (64u << 10)) { st->dict_addr += st->dictSize - (64u << 10); st->dictSize = 64u << 10; }
+    }
+    int dict_follows = st->dict_space == space && st->dict_addr + st->dictSize == addr;
+    if ((st->dictSize - 1u < 4u - 1u) && !dict_follows) {      /* invalidate tiny dictionaries */
+        st->dictSize = 0; st->dict_space = space; st->dict_addr = addr; dict_follows = 1;
+    }
+    const int prefix = dict_follows;
+    const int dict_small = (st->dictSize < (64u << 10)) && (st->dictSize < st->currentOffset);
+    const uint32_t dictSize = st->dictSize;
+    const uint32_t startIndex = st->currentOffset;
+    const uint32_t prefixIdxLimit = startIndex - dictSize;
+    /* logical position of table index i: start + (i - startIndex) */
+    const uint64_t low_dict = start - dictSize;                /* dictionary start (prefix mode: lowLimit) */
+    const uint64_t low_in = prefix ? low_dict : start;
+
+    /* context update (top of LZ4_compress_generic), then what LZ4_compress_fast_continue does after an extDict block */
+    st->currentOffset += (uint32_t)n;
+    if (prefix) st->dictSize += (uint32_t)n;
+    else { st->dict_space = space; st->dict_addr = addr; st->dictSize = (uint32_t)n; }
+
+    const uint8_t* const src = s0 + start;
+    const uint8_t* ip = src;
+    const uint8_t* anchor = src;
+    const uint8_t* const iend = src + n;
+    const uint8_t* const mflimitPlusOne = iend - LZ4_MFLIMIT + 1;
+    const uint8_t* const matchlimit = iend - LZ4_LASTLITERALS;
+    uint8_t* op = dst;
+    uint8_t* const olimit = dst + cap;
+    uint32_t forwardH;
+#define IDX(p) ((uint32_t)(startIndex + (uint32_t)((p) - src)))
+#define POS(i) (src + (int64_t)(int32_t)((i) - startIndex))
+
+    if (n < LZ4_MINLENGTH) goto last_literals;
+    st->table[lz4_hash5(ip)] = IDX(ip);
+    ip++;
+    forwardH = lz4_hash5(ip);
+
+    for (;;) {
+        const uint8_t* match;
+        const uint8_t* lowLimit;
+        uint8_t* token;
+        uint32_t offset;
+        {
+            const uint8_t* forwardIp = ip;
+            int step = 1;
+            int searchMatchNb = 1 << LZ4_SKIPTRIGGER;
+            do {
+                const uint32_t h = forwardH;
+                const uint32_t current = IDX(forwardIp);
+                const uint32_t matchIndex = st->table[h];
+                ip = forwardIp;
+                forwardIp += step;
+                step = (searchMatchNb++ >> LZ4_SKIPTRIGGER);
+                if (forwardIp > mflimitPlusOne) goto last_literals;
+                match = POS(matchIndex);
+                lowLimit = s0 + ((matchIndex < startIndex) ? low_dict : low_in);
+                forwardH = lz4_hash5(forwardIp);
+                st->table[h] = current;
+                if (dict_small && matchIndex < prefixIdxLimit) continue;
+                if (matchIndex + LZ4_MAXD < current) continue;
+                if (rd32(match) == rd32(ip)) { offset = current - matchIndex; break; }
+            } while (1);
+        }
+        while ((ip > anchor) && (match > lowLimit) && (ip[-1] == match[-1])) { ip--; match--; }
+        {
+            const unsigned litLength = (unsigned)(ip - anchor);
+            token = op++;
+            if (op + litLength + (2 + 1 + LZ4_LASTLITERALS) + (litLength / 255) > olimit) return 0;
+            if (litLength >= LZ4_RUNMASK) {
+                int len = (int)(litLength - LZ4_RUNMASK);
+                *token = (uint8_t)(LZ4_RUNMASK << LZ4_MLBITS);
+                for (; len >= 255; len -= 255) *op++ = 255;
+                *op++ = (uint8_t)len;
+            } else {
+                *token = (uint8_t)(litLength << LZ4_MLBITS);
+            }
+            memcpy(op, anchor, litLength);
+            op += litLength;
+        }
+    next_match:
+        *op++ = (uint8_t)offset;
+        *op++ = (uint8_t)(offset >> 8);
+        {
+            unsigned matchCode;
+            {
+                /* extDict: count to the dictionary's end, then on from the block's first byte -- the same bytes as
+                 * one count over the logically contiguous stream */
+                const uint8_t* pi = ip + LZ4_MINMATCH;
+                const uint8_t* pm = match + LZ4_MINMATCH;
+                while (pi < matchlimit && *pi == *pm) { pi++; pm++; }
+                matchCode = (unsigned)(pi - (ip + LZ4_MINMATCH));
+            }
+            ip += (size_t)matchCode + LZ4_MINMATCH;
+            if (op + (1 + LZ4_LASTLITERALS) + (matchCode + 240) / 255 > olimit) return 0;
+            if (matchCode >= LZ4_MLMASK) {
+                *token = (uint8_t)(*token + LZ4_MLMASK);
+                matchCode -= LZ4_MLMASK;
+                while (matchCode >= 255) { *op++ = 255; matchCode -= 255; }
+                *op++ = (uint8_t)matchCode;
+            } else {
+                *token = (uint8_t)(*token + matchCode);
+            }
+        }
+        anchor = ip;
+        if (ip >= mflimitPlusOne) break;
+        st->table[lz4_hash5(ip - 2)] = IDX(ip - 2);
+        {
+            const uint32_t h = lz4_hash5(ip);
+            const uint32_t current = IDX(ip);
+            const uint32_t matchIndex = st->table[h];
+            match = POS(matchIndex);
+            lowLimit = s0 + ((matchIndex < startIndex) ? low_dict : low_in);
+            st->table[h] = current;
+            if ((dict_small ? (matchIndex >= prefixIdxLimit) : 1) && (matchIndex + LZ4_MAXD >= current) &&
+                (rd32(match) == rd32(ip))) {
+                token = op++;
+                *token = 0;
+                offset = current - matchIndex;
+                goto next_match;
+            }
+        }
+        forwardH = lz4_hash5(++ip);
+    }
+
+last_literals:
+    {
+        const size_t lastRun = (size_t)(iend - anchor);
+        if (op + lastRun + 1 + ((lastRun + 255 - LZ4_RUNMASK) / 255) > olimit) return 0;
+        if (lastRun >= LZ4_RUNMASK) {
+            size_t acc = lastRun - LZ4_RUNMASK;
+            *op++ = (uint8_t)(LZ4_RUNMASK << LZ4_MLBITS);
+            for (; acc >= 255; acc -= 255) *op++ = 255;
+            *op++ = (uint8_t)acc;
+        } else {
+            *op++ = (uint8_t)(lastRun << LZ4_MLBITS);
+        }
+        memcpy(op, anchor, lastRun);
+        op += lastRun;
+    }
+#undef IDX
+#undef POS
+    return (int)(op - dst);
+}
+
+typedef struct {
+    lz4_stream_model st;
+    const uint8_t* s0;
+    uint8_t* op;
+    size_t blockSize;
+} lz4f_model;
+
+/* LZ4F_makeBlock: compress with capacity n-1, store raw when that fails */
+static void lz4f_make_block(lz4f_model* f, uint64_t start, size_t n, int space, uint64_t addr)
+{
+    int c = lz4_block_continue(&f->st, f->s0, start, (int)n, space, addr, f->op + 4, (int)n - 1);
+    uint32_t field;
+    if (c == 0) { field = (uint32_t)n | 0x80000000u; memcpy(f->op + 4, f->s0 + start, n); c = (int)n; }
+    else field = (uint32_t)c;
+    f->op[0] = (uint8_t)field; f->op[1] = (uint8_t)(field >> 8); f->op[2] = (uint8_t)(field >> 16); f->op[3] = (uint8_t)(field >> 24);
+    f->op += 4 + (size_t)c;
+}
+
+/* LZ4_saveDict(stream, tmpBuff, 64 KB) */
+static uint32_t lz4f_save_dict(lz4f_model* f)
+{
+    uint32_t d = 64u << 10;
+    if (d > f->st.dictSize) d = f->st.dictSize;
+    f->st.dict_space = 2; f->st.dict_addr = 0; f->st.dictSize = d;
+    return d;
+}
+
+size_t sqo_lz4_encode_serial(const uint8_t* src, size_t n, uint8_t* dst, size_t framestep, int blocksize_id)
+{
+    if (blocksize_id < 4 || blocksize_id > 7 || framestep == 0) return 0;
+    lz4f_model f;
+    memset(&f.st, 0, sizeof(f.st));
+    f.s0 = src; f.blockSize = lz4f_block_bytes[blocksize_id];
+    /* LZ4F_compressBegin */
+    uint8_t* op = dst;
+    op[0] = 0x04; op[1] = 0x22; op[2] = 0x4D; op[3] = 0x18;
+    op[4] = 0x40;
+    op[5] = (uint8_t)(blocksize_id << 4);
+    op[6] = (uint8_t)((sqo_xxh32(op + 4, 2, 0) >> 8) & 0xff);
+    f.op = op + 7;
+    const size_t blockSize = f.blockSize;
+    const size_t maxBufferSize = blockSize + (128u << 10);
+    size_t tmpIn = 0, tmpInSize = 0;           /* offset of tmpIn in tmpBuff, bytes parked there */
+    uint64_t tmp_logical = 0;                  /* logical position of the first parked byte */
+    const size_t n_steps = (n + framestep - 1) / framestep;
+    uint64_t pos = 0;
+    for (size_t s = 0; s < n_steps; ++s) {
+        const size_t src_size = (n - pos) < framestep ? (size_t)(n - pos) : framestep;
+        /* ---- LZ4F_compressUpdate ---- */
+        uint64_t srcPtr = pos;
+        const uint64_t srcEnd = pos + src_size;
+        int last = 0;                          /* 1 = fromTmpBuffer, 2 = fromSrcBuffer */
+        if (tmpInSize > 0) {
+            const size_t sizeToCopy = blockSize - tmpInSize;
+            if (sizeToCopy > src_size) { tmpInSize += src_size; srcPtr = srcEnd; }
+            else {
+                last = 1;
+                srcPtr += sizeToCopy;
+                lz4f_make_block(&f, tmp_logical, blockSize, 2, tmpIn);
+                tmpIn += blockSize;
+                tmpInSize = 0;
+            }
+        }
+        while (srcEnd - srcPtr >= blockSize) {
+            last = 2;
+            lz4f_make_block(&f, srcPtr, blockSize, 1, srcPtr);
+            srcPtr += blockSize;
+        }
+        if (last == 2) tmpIn = lz4f_save_dict(&f);
+        if (tmpIn + blockSize > maxBufferSize) tmpIn = lz4f_save_dict(&f);
+        if (srcPtr < srcEnd) { tmp_logical = srcPtr; tmpInSize = (size_t)(srcEnd - srcPtr); }
+        pos += src_size;
+    }
+    /* ---- LZ4F_compressEnd: flush, end mark ---- */
+    if (tmpInSize > 0) lz4f_make_block(&f, tmp_logical, tmpInSize, 2, tmpIn);
+    f.op[0] = f.op[1] = f.op[2] = f.op[3] = 0;
+    f.op += 4;
+    return (size_t)(f.op - dst);
+}
+
 size_t sqo_lz4_encode_chunked(const uint8_t* src, size_t n, uint8_t* dst, size_t chunk, int blocksize_id)
 {
     if (blocksize_id < 4 || blocksize_id > 7) return 0;
-    if (chunk == 0 || chunk > lz4f_block_bytes[blocksize_id]) return 0; /* linked multi-block frames not restated */
+    if (chunk == 0) return 0;
     uint8_t* op = dst;
     if (n == 0) return lz4f_write_single_block_frame(src, 0, dst, blocksize_id);
     for (size_t off = 0; off < n; off += chunk) {
         const size_t len = (n - off < chunk) ? (n - off) : chunk;
-        op += lz4f_write_single_block_frame(src + off, len, op, blocksize_id);
+        /* encode_parallel hands every chunk to encode_serial with framestep = chunk (lz4_utils.hpp:245-251) */
+        if (chunk > lz4f_block_bytes[blocksize_id]) op += sqo_lz4_encode_serial(src + off, len, op, chunk, blocksize_id);
+        else op += lz4f_write_single_block_frame(src + off, len, op, blocksize_id);
     }
     return (size_t)(op - dst);
 }

@@ -47,9 +47,12 @@ int sqo_lz4_block_decompress(const uint8_t* src, int n, uint8_t* dst, int cap);
 
 /* ---- LZ4 framing as sqeazy calls it ----
  * chunked layout: encoders/lz4_utils.hpp:193-274 (encode_parallel): every `chunk` bytes of input
- * becomes its own LZ4 frame; frames concatenated.  Only chunk <= block_bytes is restated
- * (one block per frame).  blocksize_id is LZ4F's 4..7 (64K,256K,1M,4M).  returns bytes written. */
+ * becomes its own LZ4 frame; frames concatenated.  Chunks larger than a block become block-linked frames (encode_serial).  blocksize_id is LZ4F's 4..7 (64K,256K,1M,4M).  returns bytes written. */
 size_t sqo_lz4_encode_chunked(const uint8_t* src, size_t n, uint8_t* dst, size_t chunk, int blocksize_id);
+/* serial layout: encoders/lz4_utils.hpp:99-173 (encode_serial): ONE frame of block-linked blocks, one
+ * LZ4F_compressUpdate per `framestep` bytes.  Also what a chunk larger than one block becomes inside the chunked
+ * layout (framestep = chunk).  dst needs n + 4 * (blocks + 1) + 11 bytes.  returns bytes written. */
+size_t sqo_lz4_encode_serial(const uint8_t* src, size_t n, uint8_t* dst, size_t framestep, int blocksize_id);
 /* upper bound of the above as the reference computes it: encoders/lz4.hpp:166-188 */
 size_t sqo_lz4_max_encoded_size(size_t n, size_t chunk, int blocksize_id, int nthreads);
 /* decoder for concatenated frames: encoders/lz4.hpp:257-339.  returns decoded bytes or (size_t)-1 */

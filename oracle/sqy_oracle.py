@@ -43,7 +43,7 @@ def lib():
         L = ctypes.CDLL(path)
         L.sqo_lz4_block_compress.restype = ctypes.c_int
         L.sqo_lz4_block_decompress.restype = ctypes.c_int
-        for f in ("sqo_lz4_encode_chunked", "sqo_lz4_max_encoded_size", "sqo_lz4_decode_frames",
+        for f in ("sqo_lz4_encode_chunked", "sqo_lz4_encode_serial", "sqo_lz4_max_encoded_size", "sqo_lz4_decode_frames",
                   "sqo_base64_encode", "sqo_diff3x3x1_offsets"):
             getattr(L, f).restype = ctypes.c_size_t
         L.sqo_xxh32.restype = ctypes.c_uint32
@@ -208,8 +208,14 @@ class Lz4Config:
                                               ctypes.c_int(self.block_id), ctypes.c_int(nthreads))
 
 
+def _lz4_dst(n, cfg, nframes):
+    blocks = n // (64 << 10) + 2 * nframes + 2
+    return np.zeros(n + 4 * blocks + 15 * nframes + 64, dtype=np.uint8)
+
+
 def lz4_encode_chunked(data, cfg=None):
-    """nthreads >= 2 layout (encoders/lz4.hpp:227-239 -> lz4_utils.hpp:193-274)."""
+    """nthreads >= 2 layout (encoders/lz4.hpp:227-239 -> lz4_utils.hpp:193-274): every chunk its own frame; a chunk
+    larger than one LZ4F block is a frame of block-linked blocks."""
     cfg = cfg or Lz4Config()
     src = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
     src = np.ascontiguousarray(src).view(np.uint8).reshape(-1)
@@ -218,12 +224,36 @@ def lz4_encode_chunked(data, cfg=None):
     if cfg.accel >= 3:
         raise NotImplementedError("accel >= 3 selects LZ4HC in liblz4 (not restated)")
     nchunks = (n + chunk - 1) // chunk if n else 1
-    dst = np.zeros(nchunks * (chunk + 15 + 8) + 64, dtype=np.uint8)
+    dst = _lz4_dst(n, cfg, nchunks)
     r = lib().sqo_lz4_encode_chunked(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(chunk),
                                      ctypes.c_int(cfg.block_id))
     if r == 0:
-        raise NotImplementedError("chunk larger than one LZ4F block (linked multi-block frames not restated)")
+        raise ValueError("lz4 configuration not encodable")
     return dst[:r]
+
+
+def lz4_encode_serial(data, cfg=None, framestep=None):
+    """nthreads == 1 layout (encoders/lz4.hpp:227-234 -> lz4_utils.hpp:99-173): ONE frame of block-linked blocks, fed to
+    LZ4F_compressUpdate `framestep` bytes at a time."""
+    cfg = cfg or Lz4Config()
+    src = data if isinstance(data, np.ndarray) else np.frombuffer(bytes(data), dtype=np.uint8)
+    src = np.ascontiguousarray(src).view(np.uint8).reshape(-1)
+    n = src.size
+    if cfg.accel >= 3:
+        raise NotImplementedError("accel >= 3 selects LZ4HC in liblz4 (not restated)")
+    if framestep is None:
+        framestep = cfg.bytes_per_chunk(n) if n else 1
+    dst = _lz4_dst(n, cfg, 1)
+    r = lib().sqo_lz4_encode_serial(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(framestep),
+                                    ctypes.c_int(cfg.block_id))
+    if r == 0:
+        raise ValueError("lz4 configuration not encodable")
+    return dst[:r]
+
+
+def lz4_encode(data, cfg=None, nthreads=2):
+    """lz4_scheme::encode (encoders/lz4.hpp:214-242): the serial layout for exactly one thread, the chunked one otherwise."""
+    return lz4_encode_serial(data, cfg) if nthreads == 1 else lz4_encode_chunked(data, cfg)
 
 
 def lz4_decode_frames(data, cap):
@@ -555,10 +585,9 @@ def pipeline_max_encoded_size(pipeline, nbytes, dtype, nthreads=1):
 
 
 def pipeline_encode(pipeline, vol, nthreads=2):
-    """Whole-blob oracle for the supported stage set, chunked (nthreads >= 2) LZ4 layout.
+    """Whole-blob oracle for the supported stage set; `nthreads` as the caller passes it to SQY_PipelineEncode_* after
+    the reference's "<= 0 means all cores" rule (1 = the serial LZ4 layout, anything else the chunked one).
     `vol` is a uint8/uint16 ndarray in {z,y,x} order.  Returns bytes."""
-    if nthreads < 2:
-        raise NotImplementedError("serial single-frame LZ4 layout is not restated (block-linked frame)")
     vol = np.ascontiguousarray(vol)
     if not can_be_built_from(pipeline):
         raise ValueError("invalid pipeline")
@@ -588,7 +617,7 @@ def pipeline_encode(pipeline, vol, nthreads=2):
             cur, dec = quantiser_encode(cur)
             s.cmap["decode_lut_string"] = to_verbatim(dec)
         elif s.name == "lz4":
-            payload = lz4_encode_chunked(cur.reshape(-1).view(np.uint8), s.lz4)
+            payload = lz4_encode(cur.reshape(-1).view(np.uint8), s.lz4, nthreads)
             cur = payload
         else:
             raise NotImplementedError(s.name)

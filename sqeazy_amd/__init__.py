@@ -50,7 +50,7 @@ def lib():
                 import torch  # noqa: F401
             except Exception:
                 pass
-        L = ctypes.CDLL(os.environ.get("SQEAZY_AMD_LIB", LIB_PATH))   # override: kernel experiments (tools/)
+        L = ctypes.CDLL(LIB_PATH)
         c_long_p = ctypes.POINTER(ctypes.c_long)
         L.SQY_Pipeline_Possible_UI16.restype = ctypes.c_bool
         L.SQY_Pipeline_Possible_UI8.restype = ctypes.c_bool

@@ -14,6 +14,8 @@ LIB = os.path.join(LIBDIR, "libsqeazy_amd.so")
 SOURCES = ["sqy_kernels.hip", "sqy_pipeline.cpp", "sqy_capi.cpp"]
 HEADERS = ["sqy_kernels.h", "sqy_pipeline.hpp", os.path.join("..", "..", "include", "sqeazy_amd.h")]
 ARCH = "gfx950"
+# the one and only configuration of libsqeazy_amd.so; kernel experiments live in tools/ and build their own binaries
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-DSQY_PRODUCT_BUILD"]
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "sqy")                 # command line front end over the C-ABI (csrc/sqy_cli.cpp)
 
@@ -38,8 +40,7 @@ def build(force=False, verbose=False):
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     objs = []
-    common = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value"]
-    common += os.environ.get("SQY_EXTRA_HIPCC_FLAGS", "").split()      # kernel experiments (tools/), never set by the product build
+    common = list(FLAGS)
     for src in SOURCES:
         obj = os.path.join(LIBDIR, os.path.splitext(src)[0] + ".o")
         cmd = [_hipcc(), "--offload-arch=" + ARCH] + common + ["-c", os.path.join(CSRC, src), "-o", obj]

@@ -104,12 +104,12 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small;
+    DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan;
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
     void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
-        io_src.release(); io_dst.release(); small.release();
+        io_src.release(); io_dst.release(); small.release(); plan.release();
     }
 };
 
@@ -229,6 +229,22 @@ struct ContextLease {
     ContextLease& operator=(const ContextLease&) = delete;
 };
 
+// Every exit of an encode / decode -- the early error returns included -- leaves the stream idle before the context goes
+// back to the pool: kernels and async copies still in flight would otherwise read host vectors that are being destroyed
+// and HBM buffers the next call (on another stream) may reuse or free.  Timing events that nobody harvested are dropped.
+struct DrainOnExit {
+    hipStream_t s;
+    std::vector<PendingEvent>* pending;
+    ~DrainOnExit()
+    {
+        (void)hipStreamSynchronize(s);
+        if (!pending->empty()) {
+            if (g_prof_on.load()) prof_collect(*pending);
+            else { for (PendingEvent& p : *pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); } pending->clear(); }
+        }
+    }
+};
+
 bool device_present()
 {
     int n = 0;
@@ -271,6 +287,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
 
     Workspace* ws = &cx.ws;
     std::vector<PendingEvent>* pend = &cx.pending;
+    DrainOnExit drain{stream, pend};
 
     // ---- walk the stages ----
     const uint8_t* cur = static_cast<const uint8_t*>(d_src);
@@ -290,6 +307,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     uint64_t lz4_total = 0, lz4_nchunks = 0, lz4_chunk = 0, lz4_stride = 0;
     const uint64_t* lz4_frame_map = nullptr;     // frame_shuffle directly in front of lz4: frames are read through the map
     uint64_t lz4_frame_bytes = 0;
+    const sqy::Lz4Block* lz4_blocks = nullptr;   // block-linked frames (nthreads == 1, or chunks of several LZ4 blocks): the block list in HBM
+    static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
     for (size_t si = 0; si < pipe.stages.size(); ++si) {
         Stage& st = pipe.stages[si];
@@ -376,7 +395,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 if (si + 1 < pipe.stages.size() && pipe.stages[si + 1].kind == StageKind::lz4 && frame_bytes) {
                     const uint64_t total = cur_len * (uint64_t)cur_elem;
                     const uint64_t chunk = pipe.stages[si + 1].lz4.bytes_per_chunk(total);
-                    fused = chunk && frame_bytes % chunk == 0 && chunk <= pipe.stages[si + 1].lz4.block_bytes();
+                    fused = chunk && frame_bytes % chunk == 0 && chunk <= pipe.stages[si + 1].lz4.block_bytes() &&
+                            !(pipe.nthreads == 1 && total > chunk);               // (block-linked frames read a gathered copy)
                 }
                 if (fused) {
                     lz4_frame_map = d_map;
@@ -429,29 +449,51 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 lz4_total = cur_len * (uint64_t)cur_elem;
                 lz4_chunk = lz4_total ? st.lz4.bytes_per_chunk(lz4_total) : 1;
                 lz4_nchunks = lz4_total ? (lz4_total + lz4_chunk - 1) / lz4_chunk : 0;
-                if (lz4_chunk > st.lz4.block_bytes()) {
-                    std::fprintf(stderr, "[sqeazy]\t lz4: %llu-byte chunks span several linked LZ4 blocks; not available on MI355X\n",
-                                 (unsigned long long)lz4_chunk);
-                    return 1;
-                }
-                if (pipe.nthreads == 1 && lz4_nchunks > 1) {
-                    std::fprintf(stderr, "[sqeazy]\t lz4: nthreads=1 asks for one block-linked frame over %llu chunks (inherently serial); "
-                                         "not available on MI355X, pass nthreads=0 or >=2\n", (unsigned long long)lz4_nchunks);
-                    return 1;
-                }
-                lz4_stride = (lz4_chunk + 15) & ~(uint64_t)15;
-                if (ws->lz4_scratch.ensure(std::max<uint64_t>(lz4_nchunks * lz4_stride, 16))) return 1;
-                if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
-                if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
-                {
-                    ProfScope ps("lz4_chunks", stream, pend);
-                    SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                   static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes));
+                const bool serial = pipe.nthreads == 1 && lz4_nchunks > 1;          // lz4.hpp:227-234: one block-linked frame
+                if (!serial && lz4_chunk <= st.lz4.block_bytes()) {
+                    // chunked layout, one LZ4 block per frame: every chunk is independent
+                    lz4_stride = (lz4_chunk + 15) & ~(uint64_t)15;
+                    if (ws->lz4_scratch.ensure(std::max<uint64_t>(lz4_nchunks * lz4_stride, 16))) return 1;
+                    if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
+                    if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
+                    {
+                        ProfScope ps("lz4_chunks", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
+                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes));
+                    }
+                } else if (lz4_total) {
+                    // block-linked frames: the serial layout (nthreads == 1) or chunks that span several LZ4 blocks.  The table
+                    // of a frame is carried from block to block, so one wavefront walks each frame (lz4_utils.hpp:99-173)
+                    const sqy::Lz4Plan plan = sqy::lz4_plan_blocks(lz4_total, lz4_chunk, st.lz4.block_bytes(), serial);
+                    if (!plan.ok || plan.blocks.empty()) {
+                        std::fprintf(stderr, "[sqeazy]\t lz4: block layout not available on MI355X\n");
+                        return 1;
+                    }
+                    const uint64_t nblocks = plan.blocks.size(), nframes = plan.frame_first.size() - 1;
+                    const uint64_t blocks_bytes = nblocks * sizeof(sqy::Lz4Block), first_bytes = (nframes + 1) * sizeof(uint32_t);
+                    if (ws->plan.ensure(blocks_bytes + first_bytes)) return 1;
+                    sqy::Lz4Block* d_blocks = static_cast<sqy::Lz4Block*>(ws->plan.p);
+                    uint32_t* d_first = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(ws->plan.p) + blocks_bytes);
+                    SQY_HIP(hipMemcpyAsync(d_blocks, plan.blocks.data(), blocks_bytes, hipMemcpyHostToDevice, stream));
+                    SQY_HIP(hipMemcpyAsync(d_first, plan.frame_first.data(), first_bytes, hipMemcpyHostToDevice, stream));
+                    lz4_stride = ((uint64_t)plan.max_block + 15) & ~(uint64_t)15;
+                    if (ws->lz4_scratch.ensure(std::max<uint64_t>(nblocks * lz4_stride, 16))) return 1;
+                    if (ws->csize.ensure(nblocks * sizeof(uint32_t))) return 1;
+                    if (ws->frame_off.ensure((nblocks + 1) * sizeof(uint64_t))) return 1;
+                    {
+                        ProfScope ps("lz4_linked", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_linked(cur, d_blocks, d_first, nframes, plan.max_block, static_cast<uint8_t*>(ws->lz4_scratch.p),
+                                                       lz4_stride, static_cast<uint32_t*>(ws->csize.p), stream));
+                    }
+                    SQY_HIP(hipStreamSynchronize(stream));                 // `plan` (host) is read by the async copies above
+                    lz4_blocks = d_blocks;
+                    lz4_nchunks = nblocks;                                  // scan and gather work per block from here on
+                    lz4_chunk = plan.max_block;
                 }
                 {
                     ProfScope ps("lz4_frame_scan", stream, pend);
                     SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
-                                                       static_cast<uint64_t*>(ws->frame_off.p), stream));
+                                                       static_cast<uint64_t*>(ws->frame_off.p), stream, lz4_blocks));
                 }
                 payload_is_lz4 = true;
                 break;
@@ -502,7 +544,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
             ProfScope ps("lz4_frame_gather", stream, pend);
             SQY_HIP(sqy::launch_lz4_frame_gather(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                  static_cast<uint32_t*>(ws->csize.p), static_cast<uint64_t*>(ws->frame_off.p),
-                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes));
+                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, lz4_blocks));
         }
     } else {
         ProfScope ps("payload_copy", stream, pend);
@@ -570,6 +612,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
     const uint8_t* d_src = static_cast<const uint8_t*>(d_src_v);
     Workspace* ws = &cx.ws;
     std::vector<PendingEvent>* pend = &cx.pending;
+    DrainOnExit drain{stream, pend};
 
     // header: fetch a prefix of the blob, grow until the delimiter is inside
     std::vector<char> head;
@@ -591,13 +634,28 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
         return 1;
     }
     Pipeline pipe = Pipeline::from_string(h.pipename);
+    // the header is untrusted input: every extent positive, the voxel count below 2^31 (what one encode call can have
+    // produced), no wrap-around anywhere
+    if (h.shape.empty() || h.shape.size() > 16) { std::fprintf(stderr, "[sqeazy]\t decode: header with rank %zu\n", h.shape.size()); return 1; }
     uint64_t n = 1;
-    for (uint64_t d : h.shape) n *= d;
+    for (uint64_t d : h.shape) {
+        if (d == 0 || d >= ((uint64_t)1 << 31)) { std::fprintf(stderr, "[sqeazy]\t decode: header with an extent of %llu\n", (unsigned long long)d); return 1; }
+        n *= d;
+        if (n >= ((uint64_t)1 << 31)) { std::fprintf(stderr, "[sqeazy]\t decode: header claims 2^31 or more voxels\n"); return 1; }
+    }
     const uint64_t raw_bytes = n * (uint64_t)elem;
-    if (raw_bytes > dst_capacity || h.size + h.payload_bytes > srclen) {
+    if (raw_bytes > dst_capacity || h.size > srclen || h.payload_bytes > srclen - h.size) {
         std::fprintf(stderr, "[sqeazy]\t decode: buffer too small or blob truncated\n");
         return 1;
     }
+    // composite return codes of dynamic_pipeline::detail_decode (dynamic_pipeline.hpp:795-846): a failing tail filter
+    // returns its code, a failing sink code + 10, a failing head filter code + 100
+    const int sink_index = pipe.sink_index;
+    auto stage_error = [&](size_t si) -> int {
+        if (sink_index >= 0 && (int)si > sink_index) return 1;
+        if (sink_index >= 0 && (int)si == sink_index) return 1 + 10;
+        return 1 + 100;
+    };
     // element size of the stream in front of every stage (the quantiser sink turns it into bytes)
     std::vector<int> elem_before(pipe.stages.size());
     {
@@ -655,11 +713,15 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                     SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
                     SQY_HIP(hipStreamSynchronize(stream));
                 }
-                if (hc[2]) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 frame stream (code %u)\n", hc[2]); return 1; }
+                if (hc[2]) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 frame stream (code %u)\n", hc[2]); return stage_error(si); }
                 const uint32_t nframes = hc[0];
                 if (nframes > 1 && nframes != nchunks) {
                     std::fprintf(stderr, "[sqy::lz4] %u frames where %llu chunks were expected\n", nframes, (unsigned long long)nchunks);
-                    return 1;
+                    return stage_error(si);
+                }
+                if (nframes == 0 && total > 0) {
+                    std::fprintf(stderr, "[sqy::lz4] no LZ4 frame in the payload, %llu bytes expected\n", (unsigned long long)total);
+                    return stage_error(si);
                 }
                 uint8_t* out = out_buf(si, total);
                 if (!out) return 1;
@@ -670,7 +732,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 uint32_t bad = 0;
                 SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
                 SQY_HIP(hipStreamSynchronize(stream));
-                if (bad) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 block\n"); return 1; }
+                if (bad) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 block, or a frame that does not decode to its share of the volume\n"); return stage_error(si); }
                 cur = out; cur_bytes = total;
                 break;
             }
@@ -795,6 +857,21 @@ int max_compressed_length(const char* pipeline, long pipeline_length, long* leng
     return 0;
 }
 
+// No C++ exception may cross the C-ABI (std::bad_alloc from a std::string / std::vector, anything a parser throws):
+// every entry point runs inside one of these and turns an exception into the reference's generic error code.
+template <class F>
+int guarded(F&& f) noexcept
+{
+    try { return f(); }
+    catch (const std::exception& e) { std::fprintf(stderr, "[sqeazy]\t %s\n", e.what()); return 1; }
+    catch (...) { std::fprintf(stderr, "[sqeazy]\t unknown exception\n"); return 1; }
+}
+template <class F>
+bool guarded_bool(F&& f) noexcept
+{
+    try { return f(); } catch (...) { return false; }
+}
+
 } // namespace
 
 // =================================================================================================
@@ -804,73 +881,93 @@ extern "C" {
 
 int SQY_Header_Size(const char* src, long* length)
 {
+    return guarded([&]() -> int {
     if (!src || !length) return 1;
     const sqy::HeaderInfo h = sqy::header_unpack(src, src + *length);
     *length = h.valid ? (long)h.size : 0;
     return 0;
+    });
 }
 
 int SQY_Decompressed_NDims(const char* src, long* num)
 {
+    return guarded([&]() -> int {
     if (!src || !num) return 1;
     const sqy::HeaderInfo h = sqy::header_unpack(src, src + *num);
     *num = (long)h.shape.size();
     return 0;
+    });
 }
 
 int SQY_Decompressed_Shape(const char* src, long* shape)
 {
+    return guarded([&]() -> int {
     if (!src || !shape) return 1;
     const sqy::HeaderInfo h = sqy::header_unpack(src, src + shape[0]);
     for (size_t i = 0; i < h.shape.size(); ++i) shape[i] = (long)h.shape[i];
     return 0;
+    });
 }
 
 int SQY_Decompressed_Sizeof(const char* src, long* Sizeof)
 {
+    return guarded([&]() -> int {
     if (!src || !Sizeof) return 1;
     const sqy::HeaderInfo h = sqy::header_unpack(src, src + *Sizeof);
     *Sizeof = h.valid ? h.elem_size() : 0;
     return 0;
+    });
 }
 
 int SQY_Decompressed_Length(const char* data, long* length)
 {
+    return guarded([&]() -> int {
     if (!data || !length) return 1;
     const sqy::HeaderInfo h = sqy::header_unpack(data, data + *length);
     uint64_t n = 1;
     for (uint64_t d : h.shape) n *= d;
     *length = h.valid ? (long)(n * (uint64_t)h.elem_size()) : 0;
     return 0;
+    });
 }
 
 int SQY_Version_Triple(int* version)
 {
+    return guarded([&]() -> int {
     if (!version) return 1;
     version[0] = sqy::kVersionTriple[0];
     version[1] = sqy::kVersionTriple[1];
     version[2] = sqy::kVersionTriple[2];
     return 0;
+    });
 }
 
 int SQY_PipelineEncode_UI8(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst, long* dstlength, int nthreads)
 {
+    return guarded([&]() -> int {
     return encode_from_host(pipeline, src, shape, shape_size, 1, dst, dstlength, nthreads);
+    });
 }
 
 int SQY_PipelineEncode_UI16(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst, long* dstlength, int nthreads)
 {
+    return guarded([&]() -> int {
     return encode_from_host(pipeline, src, shape, shape_size, 2, dst, dstlength, nthreads);
+    });
 }
 
 int SQY_Pipeline_Max_Compressed_Length_UI8(const char* pipeline, long pipeline_length, long* length)
 {
+    return guarded([&]() -> int {
     return length ? max_compressed_length(pipeline, pipeline_length, length, 1, (uint64_t)*length) : 1;
+    });
 }
 
 int SQY_Pipeline_Max_Compressed_Length_UI16(const char* pipeline, long pipeline_length, long* length)
 {
+    return guarded([&]() -> int {
     return length ? max_compressed_length(pipeline, pipeline_length, length, 2, (uint64_t)*length) : 1;
+    });
 }
 
 static int max_len_3d(const char* pipeline, long* shape, unsigned shape_size, long* length, int elem)
@@ -883,78 +980,100 @@ static int max_len_3d(const char* pipeline, long* shape, unsigned shape_size, lo
 
 int SQY_Pipeline_Max_Compressed_Length_3D_UI8(const char* pipeline, long* shape, unsigned shape_size, long* length)
 {
+    return guarded([&]() -> int {
     return max_len_3d(pipeline, shape, shape_size, length, 1);
+    });
 }
 
 int SQY_Pipeline_Max_Compressed_Length_3D_UI16(const char* pipeline, long* shape, unsigned shape_size, long* length)
 {
+    return guarded([&]() -> int {
     return max_len_3d(pipeline, shape, shape_size, length, 2);
+    });
 }
 
-bool SQY_Pipeline_Possible_UI16(const char* s) { return s && Pipeline::supported(s, 2); }
-bool SQY_Pipeline_Possible_UI8(const char* s) { return s && Pipeline::supported(s, 1); }
+bool SQY_Pipeline_Possible_UI16(const char* s) { return guarded_bool([&]() -> bool { return s && Pipeline::supported(s, 2); }); }
+bool SQY_Pipeline_Possible_UI8(const char* s) { return guarded_bool([&]() -> bool { return s && Pipeline::supported(s, 1); }); }
 bool SQY_Pipeline_Possible(const char* s, int sizeofpixel)
 {
+    return guarded_bool([&]() -> bool {
     if (!s) return false;
     if (sizeofpixel == 2) return Pipeline::supported(s, 2);
     if (sizeofpixel == 1) return Pipeline::supported(s, 1);
     return false;
+    });
 }
 
 int SQY_Decode_UI16(const char* src, long srclength, char* dst, int nthreads)
 {
+    return guarded([&]() -> int {
     (void)nthreads;   // the layout is read from the blob; the GPU decodes every frame in parallel
     return decode_from_host(src, srclength, dst, 2);
+    });
 }
 
 int SQY_Decode_UI8(const char* src, long srclength, char* dst, int nthreads)
 {
+    return guarded([&]() -> int {
     (void)nthreads;
     return decode_from_host(src, srclength, dst, 1);
+    });
 }
 
 int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
                                       long dst_capacity, long* dstlength, int nthreads, void* hip_stream)
 {
+    return guarded([&]() -> int {
     ContextLease lease;
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream));
+    });
 }
 
 int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
                                      long dst_capacity, long* dstlength, int nthreads, void* hip_stream)
 {
+    return guarded([&]() -> int {
     ContextLease lease;
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream));
+    });
 }
 
 int SQYAMD_PipelineEncode_UI16_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst,
                                    long dst_capacity, long* dstlength, int nthreads)
 {
+    return guarded([&]() -> int {
     return encode_from_host(pipeline, src, shape, shape_size, 2, dst, dstlength, nthreads, std::max(dst_capacity, 0l));
+    });
 }
 
 int SQYAMD_PipelineEncode_UI8_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size, char* dst,
                                   long dst_capacity, long* dstlength, int nthreads)
 {
+    return guarded([&]() -> int {
     return encode_from_host(pipeline, src, shape, shape_size, 1, dst, dstlength, nthreads, std::max(dst_capacity, 0l));
+    });
 }
 
 int SQYAMD_Decode_UI16_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream)
 {
+    return guarded([&]() -> int {
     ContextLease lease;
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     return decode_on_device(*lease.ctx, d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 2, static_cast<hipStream_t>(hip_stream));
+    });
 }
 
 int SQYAMD_Decode_UI8_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream)
 {
+    return guarded([&]() -> int {
     ContextLease lease;
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     return decode_on_device(*lease.ctx, d_src, (uint64_t)std::max(srclength, 0l), d_dst, (uint64_t)std::max(dst_capacity, 0l), 1, static_cast<hipStream_t>(hip_stream));
+    });
 }
 
 void SQYAMD_Profile_Enable(int enable)
@@ -987,6 +1106,7 @@ void SQYAMD_Release_Workspace(void)
 
 int SQYAMD_Header_Pipeline(const char* src, long srclength, char* out, long* outlength)
 {
+    return guarded([&]() -> int {
     if (!src || !outlength || srclength <= 0) return 1;
     const sqy::HeaderInfo h = sqy::header_unpack(src, src + srclength);
     if (!h.valid) return 1;
@@ -997,11 +1117,13 @@ int SQYAMD_Header_Pipeline(const char* src, long srclength, char* out, long* out
     if (have < need) return 1;
     std::memcpy(out, h.pipename.c_str(), (size_t)need);
     return 0;
+    });
 }
 
 int SQYAMD_Header_Build(const char* pipeline, int sizeof_voxel, const long* shape, unsigned shape_size, long encoded_bytes,
                         char* out, long* outlength)
 {
+    return guarded([&]() -> int {
     if (!pipeline || !shape || !outlength || shape_size == 0 || (sizeof_voxel != 1 && sizeof_voxel != 2) || encoded_bytes < 0) return 1;
     try {
         if (!sqy::Pipeline::supported(pipeline, sizeof_voxel)) return 1;
@@ -1020,6 +1142,7 @@ int SQYAMD_Header_Build(const char* pipeline, int sizeof_voxel, const long* shap
         std::fprintf(stderr, "[sqeazy]\t %s\n", e.what());
         return 1;
     }
+    });
 }
 
 const char* SQYAMD_Version(void) { return "sqeazy_amd 0.1.0 (gfx950, sqy header 0.5.2)"; }

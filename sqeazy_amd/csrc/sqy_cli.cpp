@@ -9,8 +9,8 @@
 //   sqy bench      [-p pipeline] [-r repetitions] [-c] [--noheader] [--comment text] stack.tif ...
 //
 // Differences, all forced by the hardware behind the library:
-//   * -n/--nthreads defaults to 0 (= all), not 1: nthreads == 1 selects the serial block-linked LZ4 frame, which the
-//     MI355X path does not produce;
+//   * -n/--nthreads defaults to 1 like the reference (src/sqy.cpp:190): ONE block-linked LZ4 frame, walked by a single
+//     wavefront on the GPU -- bit-identical to the reference's default output, but slow; pass -n 0 for the chunked layout;
 //   * outputs other than .sqy (the reference can wrap the blob into .tif or .h5) are not written;
 //   * TIFF input/output is the uncompressed 8/16-bit grayscale subset the reference itself writes (tiff_utils.hpp:
 //     286-310), read and written here without libtiff; .raw needs --shape and --dtype.
@@ -223,7 +223,7 @@ struct Options {
     std::string verb;
     std::vector<std::string> files;
     std::string pipeline = "bitswap1->lz4", output_name, output_suffix, comment, shape, dtype = "uint16";
-    int nthreads = 0, repetitions = 10;
+    int nthreads = 1, repetitions = 10;
     bool verbose = false, help = false, as_csv = false, noheader = false;
 };
 
@@ -423,7 +423,7 @@ void usage(const char* me)
               << "  -p, --pipeline <str>       compression pipeline (default bitswap1->lz4); stages: diff3x3x1, bitswap1, frame_shuffle, raster_reorder, quantiser, lz4\n"
               << "  -o, --output_name <file>   output file (single input only)\n"
               << "  -e, --output_suffix <ext>  output extension (compress: .sqy; decompress: .tif or .raw)\n"
-              << "  -n, --nthreads <n>         LZ4 layout selector as in the reference; 0 = all (default), 1 is not available on the GPU\n"
+              << "  -n, --nthreads <n>         as in the reference (default 1 = one block-linked LZ4 frame, serial); 0 = all = chunked layout, fast\n"
               << "  -s, --shape ZxYxX          shape of .raw input;   -t, --dtype uint8|uint16\n"
               << "  -r, --repetitions <n>      bench: repetitions (default 10);  -c, --as-csv;  --noheader;  --comment <str>\n"
               << "  -v, --verbose              -h, --help              --version\n";

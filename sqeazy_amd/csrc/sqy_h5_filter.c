@@ -67,8 +67,13 @@ static size_t H5Z_filter_sqy(unsigned flags, size_t cd_nelmts, const unsigned cd
                     if (okc == 0 && voxels * (size_t)voxel == nbytes) {
                         out = (char*)malloc((size_t)cap);
                         if (out) {
-                            ret = voxel == 2 ? SQY_PipelineEncode_UI16(pipeline, in, shape, (unsigned)rank, out, &outlen, 0)
-                                             : SQY_PipelineEncode_UI8(pipeline, in, shape, (unsigned)rank, out, &outlen, 0);
+                            /* the reference's filter encodes with a freshly built pipeline, i.e. n_threads = 1
+                             * (inc/sqeazy_h5_filter.hpp:153-170, dynamic_pipeline.hpp:268): ONE block-linked LZ4 frame.
+                             * Same bytes by default; SQY_H5_NTHREADS=0 selects the chunked layout (parallel on the GPU). */
+                            const char* nt_env = getenv("SQY_H5_NTHREADS");
+                            const int nt = nt_env ? atoi(nt_env) : 1;
+                            ret = voxel == 2 ? SQY_PipelineEncode_UI16(pipeline, in, shape, (unsigned)rank, out, &outlen, nt)
+                                             : SQY_PipelineEncode_UI8(pipeline, in, shape, (unsigned)rank, out, &outlen, nt);
                         }
                     } else {
                         fprintf(stderr, "[sqeazy]\t h5 filter: chunk of %zu bytes does not match the shape in cd_values\n", nbytes);

@@ -21,14 +21,29 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
                              uint64_t frame_bytes = 0);
+// One block of a block-linked LZ4 frame (liblz4's LZ4F_blockLinked, what lz4::encode_serial produces: lz4_utils.hpp:99-173):
+// where it sits in the stream and how far liblz4's backward catch-up may move a match that starts inside the block
+// (low_in) or in the history in front of it (low_dict); stream offsets, may lie below `start - 64 KiB`.
+struct Lz4Block {
+    uint64_t start;          // byte offset of the block in the stream
+    uint32_t n;              // bytes
+    uint32_t flags;          // bit 0: first block of its frame (fresh LZ4 stream), bit 1: last block of its frame
+    int64_t low_in, low_dict;
+};
+// block-linked frames: wavefront f compresses blocks [frame_first[f], frame_first[f+1]) in order, hash table carried from
+// block to block; block k -> scratch + k*stride, csize[k] (0 = store raw).  max_block = largest blocks[k].n (<= 4 MiB)
+hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const uint32_t* frame_first, uint64_t nframes,
+                             uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream);
 // frame_off[k] = byte offset of frame k in the concatenated stream, frame_off[nchunks] = total payload bytes
+// (blocks != nullptr: offset of what block k contributes -- frame header if it opens a frame, size field, body, end mark
+// if it closes one)
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                                 uint64_t* frame_off, hipStream_t stream);
+                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks = nullptr);
 // writes [04 22 4D 18 | 40 | BD | HC][u32 size][data][00 00 00 00] per chunk at out + frame_off[k]
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
                                    uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                                   uint64_t frame_bytes = 0);
+                                   uint64_t frame_bytes = 0, const Lz4Block* blocks = nullptr);
 
 // quantiser: 65536-bin histogram of u16 voxels (histo is zeroed by the launcher), and out[i] = lut[in[i]]
 hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);

@@ -451,11 +451,7 @@ __device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
 // flight (vmcnt(0)) and the prefetch hides nothing.  commit() waits for it explicitly when ip gets within AHEAD
 // bytes of whi, one refill later.  (The compiler's own vmcnt(N) waits only become stricter by the extra
 // outstanding operation, never too weak: VMEM operations retire in order.)
-#ifndef SQY_LZ4_WIN
-#define SQY_LZ4_WIN 8192
-#define SQY_LZ4_AHEAD 2048
-#endif
-constexpr uint32_t LZ4_WIN = SQY_LZ4_WIN, LZ4_FB = 1024, LZ4_AHEAD = SQY_LZ4_AHEAD, LZ4_MIRROR = 16;
+constexpr uint32_t LZ4_WIN = 8192, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 struct Lz4Window {
     glb_u8* src;           // chunk source (global)
@@ -464,6 +460,7 @@ struct Lz4Window {
     uint32_t whi, wlo;     // resident range [wlo, whi), whi a multiple of FB
     uint32_t nif;          // blocks [whi, whi + nif * FB) are in flight into their slots (1 in the steady state)
     uint32_t lane16;       // lane * 16
+    uint32_t pmin;         // first position of the block being parsed (0, or 65536 in a block-linked frame): the ring never holds less
 
     __device__ __forceinline__ void issue()
     {
@@ -499,7 +496,7 @@ struct Lz4Window {
         if (ip >= whi + (LZ4_WIN - LZ4_FB)) {                 // jumped past everything resident: restart the ring
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (a copy in flight must not land on top of the new ones)
             uint32_t start = ip & ~(LZ4_FB - 1);
-            if (start >= LZ4_FB) start -= LZ4_FB;              // keep one block of history
+            if (start >= pmin + LZ4_FB) start -= LZ4_FB;       // keep one block of history
             whi = wlo = start;
             nif = 0;
         }
@@ -625,9 +622,13 @@ struct Lz4Out {
     __device__ __forceinline__ lds_u8* at(uint32_t o) const { return ob + (o - base); }
 };
 
-// SQY_LZ4_DIAG (tools/lz4_diag.hip only, never set in the product build): cycles of ONE region of the parse loop per
-// build, between mark SQY_DIAG_A and mark SQY_DIAG_B (s_memtime; one region at a time keeps the probe's own register and
-// issue cost out of the number), plus event counters.
+// SQY_LZ4_DIAG: defined only by tools/lz4_diag.hip, which #includes this file into a stand-alone diagnostic program; the
+// product build (sqeazy_amd/build.py passes -DSQY_PRODUCT_BUILD and nothing else) cannot turn it on.  Cycles of ONE
+// region of the parse loop per build, between mark SQY_DIAG_A and mark SQY_DIAG_B (s_memtime; one region at a time keeps
+// the probe's own register and issue cost out of the number), plus event counters.
+#if defined(SQY_PRODUCT_BUILD) && defined(SQY_LZ4_DIAG)
+#error "SQY_LZ4_DIAG is a tools/ build switch; libsqeazy_amd.so has exactly one configuration"
+#endif
 #ifdef SQY_LZ4_DIAG
 #define SQY_DIAG_ARG , unsigned long long* __restrict__ diag
 #define SQY_REASON(i) do { dreason[i] += 1; } while (0)
@@ -641,10 +642,22 @@ struct Lz4Out {
 #define SQY_REASON(i) do { } while (0)
 #endif
 
+// One block of a block-linked frame (LINKED kernel): where it sits in the stream and how far liblz4's backward catch-up
+// may move a match that starts inside the block (low_in) or in the history in front of it (low_dict) -- the one place
+// where liblz4's prefix and external-dictionary modes differ (host: sqy::lz4_plan_blocks, LZ4F's buffer management).
+// (struct Lz4Block: sqy_kernels.h)
+constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positions [HIST, HIST + n), its history sits below
+
+// LINKED = false: one independent chunk per wavefront (the chunked layout's single-block frames).
+// LINKED = true: wavefront f walks the blocks [frame_first[f], frame_first[f+1]) of one frame in order; the table lives on
+// across blocks (positions are re-based by the previous block's size, entries that fall more than 64 KiB behind the new
+// block die), candidates may sit in the 64 KiB in front of the block (far fetches from global memory).
+template <bool LINKED>
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
-                       const uint64_t* __restrict__ fmap, uint64_t fbytes SQY_DIAG_ARG)
+                       const uint64_t* __restrict__ fmap, uint64_t fbytes,
+                       const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -653,51 +666,90 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ uint32_t table[4096];
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
-#ifdef SQY_LZ4_PAD
-    // occupancy experiment (tools/pad_experiment.sh, never set in the product build): fewer chunk waves per CU
-    __shared__ uint8_t lds_pad[SQY_LZ4_PAD];
-    lds_pad[threadIdx.x * 64 % SQY_LZ4_PAD] = (uint8_t)threadIdx.x;
-    if (total == 0xdeadbeefull) csize[blockIdx.x] = lds_pad[(blockIdx.x * 7) % SQY_LZ4_PAD];   // keeps the array alive
-#endif
     const int lane = threadIdx.x;
-    const uint64_t blk = blockIdx.x;
-    // frame_shuffle in front of the sink: the stream is the frames of `in` in the order fmap gives (a chunk never straddles
-    // two frames, the host checks fbytes % chunk == 0), read in place instead of gathered into a copy first
-    const uint64_t lin = blk * chunk;
-    const uint8_t* __restrict__ src = fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin;
-    const uint64_t left = total - blk * chunk;
-    const uint32_t n = (uint32_t)(left < chunk ? left : chunk);
+    const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : blockIdx.x;
+    const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
+    uint32_t n_prev = 0;
+  for (uint32_t bi = b_first; bi < b_last; ++bi) {
+    const uint64_t blk = bi;
+    // position of the block's first byte (p0) and of the stream's first byte (p_lo) in the block's own coordinates
+    const uint32_t p0 = LINKED ? LZ4_HIST : 0u;
+    uint32_t n, p_lo = 0;
+    int64_t low_in = 0, low_dict = 0;                          // catch-up limits, same coordinates
+    bool fresh = true;
+    const uint8_t* __restrict__ src;
+    if (LINKED) {
+        const Lz4Block bd = blocks[bi];
+        n = bd.n;
+        src = in + bd.start - LZ4_HIST;                        // (never dereferenced below `in`: p_lo)
+        p_lo = bd.start >= LZ4_HIST ? 0u : (uint32_t)(LZ4_HIST - bd.start);
+        low_in = bd.low_in - (int64_t)bd.start + LZ4_HIST;
+        low_dict = bd.low_dict - (int64_t)bd.start + LZ4_HIST;
+        fresh = (bd.flags & 1u) != 0;
+    } else {
+        // frame_shuffle in front of the sink: the stream is the frames of `in` in the order fmap gives (a chunk never straddles
+        // two frames, the host checks fbytes % chunk == 0), read in place instead of gathered into a copy first
+        const uint64_t lin = blk * chunk;
+        src = fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin;
+        const uint64_t left = total - blk * chunk;
+        n = (uint32_t)(left < chunk ? left : chunk);
+    }
+    const uint32_t pend = p0 + n;                              // end of the block
+    // bytes the backward catch-up may take on the match side (liblz4: match > lowLimit)
+    auto back_room = [&](uint32_t mt) -> uint32_t {
+        if (!LINKED) return mt;
+        const int64_t r = (int64_t)mt - (mt >= p0 ? low_in : low_dict);
+        return r < 0 ? 0u : (r > 0x7fffffff ? 0x7fffffffu : (uint32_t)r);
+    };
     uint8_t* __restrict__ dst = scratch + blk * stride;
 
     Lz4Window w;
-    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = n; w.whi = 0; w.wlo = 0; w.nif = 0; w.lane16 = (uint32_t)lane * 16u;
+    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = pend; w.whi = p0; w.wlo = p0; w.nif = 0; w.lane16 = (uint32_t)lane * 16u;
+    w.pmin = p0;
     w.issue();
     Lz4Out o;
     o.dst = (SQY_GLB uint8_t*)dst; o.ob = (lds_u8*)stage; o.base = 0; o.lane = lane;
     // Table entry = position << tsh | tag, tag = tsh-bit hash of the 4 bytes at that position.  Positions stay in the
     // high bits, so entries order like positions (ds_max commit, flag bit 31 free) and a tag mismatch proves that the
     // candidate's first 4 bytes differ -- no read of a far candidate just to reject it.  An empty bucket means
-    // "position 0" in liblz4, so the table starts out as entry(0).
-    const uint32_t pos_bits = n > 1 ? 32u - (uint32_t)__builtin_clz(n - 1) : 1u;
-    const uint32_t tsh = 31u - pos_bits;                       // >= 9 for chunks up to 4 MiB
+    // "position 0" in liblz4, so the table starts out as entry(first byte of the stream).
+    const uint32_t pmax = LINKED ? LZ4_HIST + max_block : n;
+    const uint32_t pos_bits = pmax > 1 ? 32u - (uint32_t)__builtin_clz(pmax - 1) : 1u;
+    const uint32_t tsh = 31u - pos_bits;                       // >= 8 for blocks up to 4 MiB
     const uint32_t tmask = (1u << tsh) - 1u;
     auto tag_of = [&](uint32_t seq32) -> uint32_t { return (seq32 * 2654435761u) >> (32u - tsh); };
-    {
-        const uint32_t e0 = n >= 4 ? tag_of(glb_ld_u32((glb_u8*)src)) : 0u;
+    if (fresh) {
+        const uint32_t e0 = (p0 << tsh) | (n >= 4 ? tag_of(glb_ld_u32((glb_u8*)src + p0)) : 0u);
         uint4* t4 = reinterpret_cast<uint4*>(table);
 #pragma unroll
         for (int i = 0; i < 16; ++i) t4[i * 64 + lane] = make_uint4(e0, e0, e0, e0);
+    } else {
+        // the stream moved on by n_prev bytes: positions shift down, whatever falls below 0 is more than 64 KiB behind
+        // every position of this block ("too far" for good) and parks at position 0
+#pragma unroll 4
+        for (int i = 0; i < 64; ++i) {
+            const uint32_t e = table[i * 64 + lane];
+            const uint32_t pp = e >> tsh;
+            table[i * 64 + lane] = pp >= n_prev ? (((pp - n_prev) << tsh) | (e & tmask)) : 0u;
+        }
     }
     __syncthreads();
+    n_prev = n;
 
     const uint32_t olimit = n - 1;       // capacity n-1 (LZ4F_makeBlock); offsets into dst
-    uint32_t op = 0, anchor = 0;
+    uint32_t op = 0, anchor = p0;
     bool failed = false;
 
     if (n >= LZ4_MINLENGTH) {
-        const uint32_t mflimitPlusOne = n - LZ4_MFLIMIT + 1;
-        const uint32_t matchlimit = n - LZ4_LASTLITERALS;
-        uint32_t P = 1, U = 1;           // first probe of the block: search from ip = 1 (table[hash(0)] = 0 is a no-op)
+        const uint32_t mflimitPlusOne = pend - LZ4_MFLIMIT + 1;
+        const uint32_t matchlimit = pend - LZ4_LASTLITERALS;
+        if (LINKED && !fresh) {
+            // LZ4_putPosition(ip) on the block's first byte (a no-op on a fresh table, which already says "first byte")
+            const uint64_t s0 = glb_ld_u64((glb_u8*)src + p0);
+            if (lane == 0) table[lz4_hash5(s0)] = (p0 << tsh) | tag_of((uint32_t)s0);
+            wave_lds_sync();
+        }
+        uint32_t P = p0 + 1, U = 1;      // first probe of the block: search from ip = first byte + 1
         uint32_t put2 = 0xffffffffu;     // position whose hash has to enter the table before the next batch (ip - 2)
 
         // A sequence found by the lean path is written out one iteration LATER, between the issue of the next batch's
@@ -713,7 +765,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
             if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
                 op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; return; }
-#ifndef SQY_LZ4_NOEMIT
             o.reserve(op, seq_bytes);
             const uint32_t k = (uint32_t)lane;
             uint32_t v = ((lit << 4) | (matchCode < 15u ? matchCode : 15u));
@@ -723,7 +774,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t j = k - (lit + 3u);
             v = (k > lit + 2u) ? ((j + 1u < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1u) * 255u)) : v;
             if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
-#endif
             op += seq_bytes;
         };
 
@@ -791,7 +841,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         if (farm & upto) {
                             if (far) {
                                 c16 = glb_ld_u128(w.src + old);                         // old + 16 <= pos + 15 < matchlimit
-                                cb4 = old >= 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src) << (8u * (4u - old)));
+                                cb4 = old >= p_lo + 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src + p_lo) << (8u * (4u - (old - p_lo))));
                                 d = first_diff16(s16, c16);
                             }
                             SQY_REASON(2);
@@ -814,7 +864,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     // catch-up of the winner: ip - anchor = f0 literals, match > 0
                     const uint32_t xb = lane_read(b4 ^ cb4, f0);
                     const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;   // equal bytes in front, 4 = maybe more
-                    const uint32_t lim = f0 < mt0 ? f0 : mt0;
+                    const uint32_t room0 = back_room(mt0);
+                    const uint32_t lim = f0 < room0 ? f0 : room0;
                     const uint32_t bck = bk < lim ? bk : lim;
                     const bool slow_back = bk == 4u && lim > 4u;
                     bool settled = true;
@@ -1004,7 +1055,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // backward catch-up: while (ip > anchor && match > 0 && ip[-1] == match[-1])
             uint32_t back;
             {
-                const uint32_t lim_a = ip0 - anchor, lim_m = mt0;
+                const uint32_t lim_a = ip0 - anchor, lim_m = back_room(mt0);
                 const uint32_t lim = lim_a < lim_m ? lim_a : lim_m;
                 if (bkl < 4u || lim <= bkl) {
                     back = bkl < lim ? bkl : lim;                          // settled by the speculative 4-byte compare
@@ -1013,21 +1064,29 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     back = 0xffffffffu;
                 }
                 if (back == 0xffffffffu) {
-                    uint32_t ip = ip0, mt = mt0;
+                    // 64 bytes per round: lane l tests byte `done + l + 1` in front of (ip0, mt0); the first mismatch or the
+                    // limit (literals available / liblz4's lowLimit on the match side) ends it
+                    uint32_t done = 0;
                     for (;;) {
-                        const uint32_t k = lane + 1;
-                        bool ok = (ip >= anchor + k) && (mt >= k);
-                        if (mt >= w.wlo + 64u && ip <= w.hi_valid()) {                   // uniform: both sides resident
-                            if (ok) ok = w.lds8(ip - k) == w.lds8(mt - k);
-                        } else {
-                            if (ok) ok = w.rd8(ip - k) == w.rd8(mt - k);
+                        const uint32_t k = done + (uint32_t)lane + 1u;
+                        bool ok = k <= lim;
+                        const uint32_t pi = ip0 - k;
+                        // LINKED: the match side may reach below position 0 (history more than 64 KiB in front of the block,
+                        // liblz4's prefix mode inside one LZ4F_compressUpdate) -- signed, read from global memory there
+                        const int32_t pm = (int32_t)mt0 - (int32_t)k;
+                        if (mt0 >= done + w.wlo + 64u && ip0 - done <= w.hi_valid()) {       // uniform: both sides resident
+                            if (ok) ok = w.lds8(pi) == w.lds8((uint32_t)pm);
+                        } else if (ok) {
+                            const uint32_t bm = (pm >= (int32_t)w.wlo && (uint32_t)pm < w.hi_valid()) ? w.lds8((uint32_t)pm)
+                                                                                                      : glb_ld_u8(w.src + pm);
+                            ok = w.rd8(pi) == bm;
                         }
                         const uint64_t bad = ~ballot(ok);
                         const uint32_t nb = bad ? ctz64(bad) : 64u;
-                        ip -= nb; mt -= nb;
+                        done += nb;
                         if (nb < 64) break;
                     }
-                    back = ip0 - ip;
+                    back = done;
                 }
             }
             
@@ -1045,12 +1104,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (matchCode < 15 ? matchCode : 15u);
             const uint32_t seq_bytes = 1 + lit_ext + lit + 2 + ml_ext;
 
-#ifdef SQY_LZ4_NOEMIT
-            op += seq_bytes;
-            if (false) {
-#else
             if (seq_bytes <= 64 && lit < 15) {
-#endif
                 // whole sequence at once into the LDS stage: lane k writes byte k
                 o.reserve(op, seq_bytes);
                 const uint32_t k = (uint32_t)lane;
@@ -1068,11 +1122,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
                 op += seq_bytes;
             }
-#ifdef SQY_LZ4_NOEMIT
-            else if (false) {
-#else
             else {
-#endif
                 o.flush(op);
                 if (lane == 0) dst[op] = (uint8_t)token;
                 op += 1;
@@ -1115,7 +1165,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
     if (!failed) {
         o.flush(op);
-        const uint32_t lastRun = n - anchor;
+        const uint32_t lastRun = pend - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
             failed = true;
         } else {
@@ -1134,19 +1184,23 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             op += lastRun;
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
     if (lane == 0) csize[blk] = failed ? 0u : op;
+    if (LINKED) __syncthreads();
+  }
 #ifdef SQY_LZ4_DIAG
-    if (lane == 0) { diag[blk * 16] = dacc; diag[blk * 16 + 1] = dcnt; for (int i = 0; i < 8; ++i) diag[blk * 16 + 8 + i] = dreason[i]; }
+    if (lane == 0) { diag[blockIdx.x * 16] = dacc; diag[blockIdx.x * 16 + 1] = dcnt; for (int i = 0; i < 8; ++i) diag[blockIdx.x * 16 + 8 + i] = dreason[i]; }
 #endif
 }
 
 // ------------------------------------------------------------------------------------------------
 // frame layout: exclusive scan of frame sizes, then scatter  [7 B header][u32 size][data][u32 0]
 // ------------------------------------------------------------------------------------------------
+// blocks == nullptr: every chunk is a single-block frame.  Otherwise block k of the list contributes its 4-byte size
+// field and body, plus the 7-byte frame header when it opens a frame and the 4-byte end mark when it closes one.
 __global__ __launch_bounds__(1024)
 void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                           uint64_t* __restrict__ frame_off /* nchunks + 1 */)
+                           uint64_t* __restrict__ frame_off /* nchunks + 1 */, const Lz4Block* __restrict__ blocks)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
@@ -1157,10 +1211,15 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
         const uint64_t k = base + tid;
         uint64_t sz = 0;
         if (k < nchunks) {
-            const uint64_t left = total - k * chunk;
-            const uint64_t nk = left < chunk ? left : chunk;
             const uint32_t c = csize[k];
-            sz = 7 + 4 + (c ? c : nk) + 4;
+            if (blocks) {
+                const Lz4Block bd = blocks[k];
+                sz = ((bd.flags & 1u) ? 7 : 0) + 4 + (c ? c : bd.n) + ((bd.flags & 2u) ? 4 : 0);
+            } else {
+                const uint64_t left = total - k * chunk;
+                const uint64_t nk = left < chunk ? left : chunk;
+                sz = 7 + 4 + (c ? c : nk) + 4;
+            }
         }
         // inclusive scan inside the wave
         uint64_t x = sz;
@@ -1190,36 +1249,44 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
                              const uint8_t* __restrict__ scratch, uint64_t stride,
                              const uint32_t* __restrict__ csize, const uint64_t* __restrict__ frame_off,
                              uint8_t* __restrict__ out, uint32_t bd_byte, uint32_t hc_byte, uint32_t slices_per_chunk,
-                             const uint64_t* __restrict__ fmap, uint64_t fbytes)
+                             const uint64_t* __restrict__ fmap, uint64_t fbytes, const Lz4Block* __restrict__ blocks)
 {
     const uint64_t k = blockIdx.x / slices_per_chunk;
     const uint32_t slice = blockIdx.x % slices_per_chunk;
-    const uint64_t left = total - k * chunk;
-    const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
+    uint32_t nk, flags = 3u;
+    uint64_t lin;
+    if (blocks) { const Lz4Block bd = blocks[k]; nk = bd.n; lin = bd.start; flags = bd.flags; }
+    else {
+        const uint64_t left = total - k * chunk;
+        nk = (uint32_t)(left < chunk ? left : chunk);
+        lin = k * chunk;
+    }
     const uint32_t c = csize[k];
     const uint32_t body = c ? c : nk;
-    const uint64_t lin = k * chunk;
     const uint8_t* __restrict__ s = c ? scratch + k * stride : (fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin);
     uint8_t* __restrict__ d = out + frame_off[k];
     const int tid = threadIdx.x;
+    const uint32_t hdr = (flags & 1u) ? 7u : 0u;                     // frame header in front of the block's size field
 
     if (slice == 0 && tid < 15) {
         const uint32_t field = c ? c : (nk | 0x80000000u);
         uint8_t v = 0;
         uint32_t o = tid;
+        bool on = true;
         switch (tid) {
             case 0: v = 0x04; break; case 1: v = 0x22; break; case 2: v = 0x4D; break; case 3: v = 0x18; break;
             case 4: v = 0x40; break; case 5: v = (uint8_t)bd_byte; break; case 6: v = (uint8_t)hc_byte; break;
             case 7: v = (uint8_t)field; break; case 8: v = (uint8_t)(field >> 8); break;
             case 9: v = (uint8_t)(field >> 16); break; case 10: v = (uint8_t)(field >> 24); break;
-            default: v = 0; o = 11 + body + (tid - 11); break;       // end mark
+            default: v = 0; o = 11 + body + (tid - 11); on = (flags & 2u) != 0; break;       // end mark
         }
-        d[o] = v;
+        if (tid < 7) on = hdr != 0;
+        if (on) d[o - (7u - hdr)] = v;
     }
     const uint32_t begin = slice * GATHER_SLICE;
     if (begin >= body) return;
     const uint32_t end = (begin + GATHER_SLICE < body) ? begin + GATHER_SLICE : body;
-    uint8_t* __restrict__ dd = d + 11 + begin;
+    uint8_t* __restrict__ dd = d + hdr + 4 + begin;
     const uint8_t* __restrict__ ss = s + begin;
     uint32_t len = end - begin;
     // head to 16-byte alignment of the destination
@@ -1878,6 +1945,8 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
         const uint32_t flg = w[1] & 0xffu;
         if ((flg >> 6) != 1 || (flg & 0x0D)) { err = 2; break; }       // only what sqeazy writes: no content size / checksum / dictID
         const bool block_checksum = (flg >> 4) & 1;
+        // frame_first has max_blocks + 2 entries; a stream of block-less frames must not run past it
+        if (nframes >= max_blocks) { err = 5; break; }
         frame_first[nframes] = nblocks;
         uint32_t field = (w[1] >> 24) | (w[2] << 8);                    // bytes 7..10
         off += 7;
@@ -2152,6 +2221,13 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         }
     }
     flush(true);
+    // a frame has to deliver exactly its share of the output: the whole stream when it is the only frame (serial layout),
+    // else one chunk (the last frame the remainder) -- short frames must not leave the destination half-written
+    {
+        const uint64_t room = frame_out < out_bytes ? out_bytes - frame_out : 0;
+        const uint64_t expect = (gridDim.x == 1 || room < frame_stride) ? room : frame_stride;
+        if ((uint64_t)pos != expect) bad = true;
+    }
     if (bad && lane == 0) atomicExch(errflag, 1u);
 }
 
@@ -2359,36 +2435,48 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
     return hipGetLastError();
 }
 
+#ifdef SQY_LZ4_DIAG
+#define SQY_DIAG_NULL , (unsigned long long*)nullptr
+#else
+#define SQY_DIAG_NULL
+#endif
+
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes)
 {
     if (nchunks == 0) return hipSuccess;
     if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
-#ifdef SQY_LZ4_DIAG
-    hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       frame_map, frame_bytes, (unsigned long long*)nullptr);
-#else
-    hipLaunchKernelGGL(lz4_chunks_kernel, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       frame_map, frame_bytes);
-#endif
+    hipLaunchKernelGGL(lz4_chunks_kernel<false>, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u SQY_DIAG_NULL);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const uint32_t* frame_first, uint64_t nframes,
+                             uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream)
+{
+    if (nframes == 0) return hipSuccess;
+    if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lz4_chunks_kernel<true>, dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, scratch, stride, csize,
+                       (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                                 uint64_t* frame_off, hipStream_t stream)
+                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks)
 {
-    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off);
+    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
-                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes)
+                                   uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
+                                   const Lz4Block* blocks)
 {
     if (nchunks == 0) return hipSuccess;
-    const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;
+    const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;      // (chunk = largest block of the list when `blocks`)
     hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(nchunks * slices)), dim3(256), 0, stream, in, total, chunk,
-                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes);
+                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes, blocks);
     return hipGetLastError();
 }
 

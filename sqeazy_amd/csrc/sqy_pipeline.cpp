@@ -161,6 +161,104 @@ uint64_t Lz4Params::max_encoded_size(uint64_t nbytes, unsigned nthreads) const
     return per_thread * (compress_bound(per_chunk, block_id) + hdr_max) * nthreads;
 }
 
+// ---- block-linked frames: liblz4 1.9.3's LZ4F buffer management, as far as it decides the bytes ----
+// LZ4F_compressUpdate compresses whole blocks straight from the caller's buffer and parks a remainder in tmpBuff; after an
+// update that compressed from the caller's buffer it copies the last 64 KiB of history into tmpBuff (LZ4F_localSaveDict,
+// stableSrc = 0).  LZ4_compress_fast_continue then runs a block in PREFIX mode when it follows its dictionary in memory
+// (lowLimit = start of the dictionary) and in EXTERNAL-DICTIONARY mode otherwise (lowLimit = block start for matches
+// inside the block, dictionary start for matches in the history).  Both see the same logical history; lowLimit bounds the
+// backward catch-up of a match and is what this model hands to the kernel per block.
+namespace {
+struct Lz4fModel {
+    enum Space { kNone, kCaller, kTmp };
+    // LZ4_stream_t: where the dictionary sits and how long it is, plus the index counter that triggers LZ4_renormDictT
+    Space dict_space = kNone;
+    uint64_t dict_addr = 0;
+    uint32_t dict_size = 0;
+    uint32_t current_offset = 0;
+    // LZ4F_cctx
+    uint64_t block_size, max_buffer;
+    uint64_t tmp_in = 0, tmp_fill = 0, tmp_stream_pos = 0;
+    Lz4Plan* plan;
+    bool* ok;
+
+    void compress_block(uint64_t stream_pos, uint64_t n, Space where, uint64_t addr)
+    {
+        if ((uint64_t)current_offset + n > 0x80000000ull) {          // LZ4_renormDictT: table rescaled (transparent), dictionary clipped
+            current_offset = 64u << 10;
+            if (dict_size > (64u << 10)) { dict_addr += dict_size - (64u << 10); dict_size = 64u << 10; }
+        }
+        bool follows = dict_space == where && dict_addr + dict_size == addr;
+        if (dict_size >= 1 && dict_size <= 3 && !follows) { dict_size = 0; dict_space = where; dict_addr = addr; follows = true; }
+        if (dict_size < (64u << 10) && dict_size < current_offset) *ok = false;      // liblz4's dictSmall variant: never reached with blocks >= 64 KiB
+        Lz4BlockPlan b;
+        b.start = stream_pos; b.n = (uint32_t)n; b.flags = 0;
+        b.low_dict = (int64_t)stream_pos - (int64_t)dict_size;
+        b.low_in = follows ? b.low_dict : (int64_t)stream_pos;
+        plan->blocks.push_back(b);
+        if (n > plan->max_block) plan->max_block = (uint32_t)n;
+        current_offset += (uint32_t)n;
+        if (follows) dict_size += (uint32_t)n;
+        else { dict_space = where; dict_addr = addr; dict_size = (uint32_t)n; }
+    }
+    uint64_t save_dict()                                             // LZ4_saveDict(stream, tmpBuff, 64 KB)
+    {
+        const uint32_t d = dict_size < (64u << 10) ? dict_size : (64u << 10);
+        dict_space = kTmp; dict_addr = 0; dict_size = d;
+        return d;
+    }
+    void update(uint64_t pos, uint64_t size)                         // LZ4F_compressUpdate(ctx, .., src + pos, size, NULL)
+    {
+        uint64_t p = pos;
+        const uint64_t end = pos + size;
+        bool from_caller = false;
+        if (tmp_fill > 0) {
+            const uint64_t to_copy = block_size - tmp_fill;
+            if (to_copy > size) { tmp_fill += size; p = end; }
+            else {
+                p += to_copy;
+                compress_block(tmp_stream_pos, block_size, kTmp, tmp_in);
+                tmp_in += block_size;
+                tmp_fill = 0;
+            }
+        }
+        while (end - p >= block_size) {
+            from_caller = true;
+            compress_block(p, block_size, kCaller, p);
+            p += block_size;
+        }
+        if (from_caller) tmp_in = save_dict();
+        if (tmp_in + block_size > max_buffer) tmp_in = save_dict();
+        if (p < end) { tmp_stream_pos = p; tmp_fill = end - p; }
+    }
+    void finish() { if (tmp_fill > 0) compress_block(tmp_stream_pos, tmp_fill, kTmp, tmp_in); tmp_fill = 0; }   // LZ4F_compressEnd -> LZ4F_flush
+};
+} // namespace
+
+Lz4Plan lz4_plan_blocks(uint64_t total, uint64_t step, uint64_t block_bytes, bool serial)
+{
+    Lz4Plan plan;
+    if (total == 0 || step == 0 || block_bytes == 0) { plan.frame_first.push_back(0); return plan; }
+    const uint64_t nframes = serial ? 1 : (total + step - 1) / step;
+    for (uint64_t f = 0; f < nframes; ++f) {
+        const uint64_t f_begin = serial ? 0 : f * step;
+        const uint64_t f_end = serial ? total : std::min(total, f_begin + step);
+        plan.frame_first.push_back((uint32_t)plan.blocks.size());
+        Lz4fModel m;
+        m.block_size = block_bytes; m.max_buffer = block_bytes + (128u << 10); m.plan = &plan; m.ok = &plan.ok;
+        // positions handed to the model are relative to the frame's first byte (its own LZ4 stream); `start` is made absolute below
+        const size_t first = plan.blocks.size();
+        for (uint64_t pos = f_begin; pos < f_end; pos += step) m.update(pos - f_begin, std::min(step, f_end - pos));
+        m.finish();
+        for (size_t i = first; i < plan.blocks.size(); ++i) {
+            plan.blocks[i].start += f_begin; plan.blocks[i].low_in += (int64_t)f_begin; plan.blocks[i].low_dict += (int64_t)f_begin;
+        }
+        if (plan.blocks.size() > first) { plan.blocks[first].flags |= 1u; plan.blocks.back().flags |= 2u; }
+    }
+    plan.frame_first.push_back((uint32_t)plan.blocks.size());
+    return plan;
+}
+
 // ---- stages ----
 static StageKind kind_of(const std::string& n)
 {
@@ -317,6 +415,7 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
             case StageKind::lz4:
                 if (i + 1 != p.stages.size()) return fail("lz4 must be the last stage on MI355X");
                 if (st.lz4.accel >= 3) return fail("lz4 accel >= 3 selects LZ4HC in liblz4; not implemented on MI355X");
+                if (st.lz4.accel < 0) return fail("lz4 accel < 0 raises liblz4's acceleration above 1; not implemented on MI355X");
                 break;
             case StageKind::pass_through:
             default:

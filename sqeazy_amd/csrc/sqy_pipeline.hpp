@@ -41,6 +41,25 @@ struct Lz4Params {
     static uint64_t compress_bound(uint64_t src, int block_id);            // LZ4F_compressBound, autoFlush = 0
 };
 
+// ---- block-linked LZ4 frames (lz4::encode_serial, encoders/lz4_utils.hpp:99-173) ----
+// One entry per LZ4 block in stream order; same layout as sqy::Lz4Block (sqy_kernels.h), which the kernels read.
+struct Lz4BlockPlan {
+    uint64_t start;          // byte offset of the block in the stream
+    uint32_t n;              // bytes
+    uint32_t flags;          // bit 0: opens a frame (fresh LZ4 stream), bit 1: closes it
+    int64_t low_in, low_dict;   // liblz4's lowLimit for matches that start inside the block / in the history in front of it
+};
+struct Lz4Plan {
+    std::vector<Lz4BlockPlan> blocks;
+    std::vector<uint32_t> frame_first;      // frame f = blocks [frame_first[f], frame_first[f+1])
+    uint32_t max_block = 0;
+    bool ok = true;                         // false: a case liblz4 would run in a mode the kernels do not model
+};
+// What liblz4 1.9.3's frame layer does with `total` bytes under sqeazy's preferences (block-linked, autoFlush 0, stableSrc 0):
+// serial = true : ONE frame, LZ4F_compressUpdate every `step` bytes (encode_serial, nthreads == 1)
+// serial = false: one frame per `step` bytes, each fed by a single update (encode_parallel -> encode_serial per chunk)
+Lz4Plan lz4_plan_blocks(uint64_t total, uint64_t step, uint64_t block_bytes, bool serial);
+
 struct Stage {
     std::string name;
     StageKind kind = StageKind::unsupported;

@@ -71,7 +71,7 @@ def test_compress_matches_oracle_and_round_trips(sqy_bin, tmp_path, oracle, dtyp
     write_tiff(tif, vol)
     rc, out, err = run(sqy_bin, "compress", "-p", pipeline, "-v", tif)
     assert rc == 0, err
-    want = oracle.pipeline_encode(pipeline, vol)
+    want = oracle.pipeline_encode(pipeline, vol, nthreads=1)      # the tool's default, as the reference's (src/sqy.cpp:190)
     assert open(sqy, "rb").read() == want
     rc, out, err = run(sqy_bin, "decompress", "-o", back, sqy)
     assert rc == 0, err
@@ -86,20 +86,23 @@ def test_compress_matches_oracle_and_round_trips(sqy_bin, tmp_path, oracle, dtyp
 
 
 @pytest.mark.gpu
-def test_raw_input_bench_and_serial_layout_refused(sqy_bin, tmp_path, oracle):
+def test_raw_input_bench_and_serial_layout(sqy_bin, tmp_path, oracle):
     vol = synth.stack((16, 32, 64), np.uint16)
     raw = tmp_path / "v.raw"
     raw.write_bytes(vol.tobytes())
     rc, _, err = run(sqy_bin, "enc", "-s", "16x32x64", "-t", "uint16", "-o", str(tmp_path / "v.sqy"), str(raw))
     assert rc == 0, err
-    assert (tmp_path / "v.sqy").read_bytes() == oracle.pipeline_encode("bitswap1->lz4", vol)
+    assert (tmp_path / "v.sqy").read_bytes() == oracle.pipeline_encode("bitswap1->lz4", vol, nthreads=1)
     rc, _, _ = run(sqy_bin, "dec", "-e", ".raw", "-o", str(tmp_path / "w.raw"), str(tmp_path / "v.sqy"))
     assert rc == 0 and (tmp_path / "w.raw").read_bytes() == vol.tobytes()
     rc, out, err = run(sqy_bin, "bench", "-r", "3", "-c", "-s", "16x32x64", str(raw))
     assert rc == 0, err
     lines = out.strip().splitlines()
     assert lines[0].startswith("id,shape,time_mus,final_bytes,ingest_bw_mbps") and len(lines) == 4
-    # nthreads = 1 asks for the serial block-linked frame: more than one chunk of input cannot be encoded that way here
+    # the reference's default (nthreads = 1, src/sqy.cpp:190): one block-linked frame over several blocks
     big = synth.stack((16, 128, 128), np.uint16)
     (tmp_path / "b.raw").write_bytes(big.tobytes())
-    assert run(sqy_bin, "enc", "-n", "1", "-s", "16x128x128", str(tmp_path / "b.raw"))[0] == 1
+    assert run(sqy_bin, "enc", "-s", "16x128x128", "-o", str(tmp_path / "b1.sqy"), str(tmp_path / "b.raw"))[0] == 0
+    assert (tmp_path / "b1.sqy").read_bytes() == oracle.pipeline_encode("bitswap1->lz4", big, nthreads=1)
+    assert run(sqy_bin, "enc", "-n", "0", "-s", "16x128x128", "-o", str(tmp_path / "b0.sqy"), str(tmp_path / "b.raw"))[0] == 0
+    assert (tmp_path / "b0.sqy").read_bytes() == oracle.pipeline_encode("bitswap1->lz4", big)

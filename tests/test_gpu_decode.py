@@ -120,3 +120,70 @@ def test_decode_truncated_and_damaged_chunked_streams(sqy, oracle):
     bad[mid:mid + 64] = bytes(64)
     rc, back = sqy.decode(bytes(bad))
     assert rc != 0 or not np.array_equal(back, vol)           # either refused or visibly different, never a crash
+
+
+def _blob(oracle, dtype, shape, pipename, payload):
+    return oracle.header_pack(dtype, shape, pipename, len(payload)) + payload
+
+
+LZ4_NAME = "lz4(accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0)"
+EMPTY_FRAME = bytes([0x04, 0x22, 0x4D, 0x18, 0x40, 0x50, 0x77, 0, 0, 0, 0])
+
+
+def test_decode_flood_of_empty_frames(sqy, oracle):
+    """a payload of nothing but 11-byte block-less frames must be refused, not walk the frame index off its buffer"""
+    payload = EMPTY_FRAME * 200000                            # 2.2 MB, far more frames than the volume can have blocks
+    blob = _blob(oracle, np.uint8, (1, 1, 1000), LZ4_NAME, payload)
+    rc, _ = sqy.decode(blob)
+    assert rc == 11                                           # the sink failed: code + 10 (dynamic_pipeline.hpp:822)
+
+
+def test_decode_header_arithmetic_is_checked(sqy, oracle):
+    """extents whose product wraps to something small, zero extents, absurd ranks, payload sizes beyond the blob"""
+    good = oracle.pipeline_encode("lz4", np.zeros((1, 1, 64), np.uint8))
+    h = oracle.header_unpack(good)
+    payload = good[h["size"]:]
+    for shape in ((1 << 33, 1 << 31, 1), (0, 4, 4), (1 << 31, 1, 1), (70000, 70000, 1)):
+        blob = _blob(oracle, np.uint8, shape, LZ4_NAME, payload)
+        out = np.zeros(64, np.uint8)
+        src = np.frombuffer(blob, np.uint8)
+        import ctypes
+        rc = sqy.lib().SQY_Decode_UI8(src.ctypes.data, ctypes.c_long(len(blob)), out.ctypes.data, ctypes.c_int(1))
+        assert rc == 1, shape
+    # payload_bytes larger than what is there
+    hdr = oracle.header_pack(np.uint8, (1, 1, 64), LZ4_NAME, len(payload) + 1000)
+    assert sqy.decode(hdr + payload)[0] == 1
+
+
+def test_decode_short_and_missing_frames(sqy, oracle):
+    """frames that decode to less than their share, or no frame at all, are errors -- never a silently half-written volume"""
+    vol = synth.stack((8, 64, 64), np.uint8)                  # 32 KiB: one frame
+    short = oracle.pipeline_encode("lz4", vol[:4])
+    hs = oracle.header_unpack(short)
+    blob = _blob(oracle, np.uint8, vol.shape, LZ4_NAME, short[hs["size"]:])
+    assert sqy.decode(blob)[0] == 11
+    blob = _blob(oracle, np.uint8, vol.shape, LZ4_NAME, b"")
+    assert sqy.decode(blob)[0] != 0
+    blob = _blob(oracle, np.uint8, vol.shape, LZ4_NAME, EMPTY_FRAME)
+    assert sqy.decode(blob)[0] == 11
+    # chunked layout where one frame is short: 3 chunks, the middle one re-encoded from fewer bytes
+    big = synth.stack((3, 512, 512), np.uint8)                # 3 x 256 KiB
+    frames = [oracle.lz4_encode_chunked(big[i].reshape(-1)) for i in range(3)]
+    frames[1] = oracle.lz4_encode_chunked(big[1].reshape(-1)[:1000])
+    blob = _blob(oracle, np.uint8, big.shape, LZ4_NAME, b"".join(f.tobytes() for f in frames))
+    assert sqy.decode(blob)[0] == 11
+
+
+def test_decode_composite_return_codes(sqy, oracle):
+    """dynamic_pipeline.hpp:795-846: sink failure = code + 10; with lz4 as a tail filter behind the quantiser sink its failure
+    is the plain code"""
+    vol = synth.stack((8, 64, 64))
+    blob = bytearray(oracle.pipeline_encode("bitswap1->lz4", vol))
+    h = oracle.header_unpack(bytes(blob))
+    blob[h["size"] + 1] ^= 0xff
+    assert sqy.decode(bytes(blob))[0] == 11
+    blob = bytearray(oracle.pipeline_encode("quantiser->lz4", vol))
+    h = oracle.header_unpack(bytes(blob))
+    blob[h["size"] + 1] ^= 0xff
+    assert sqy.decode(bytes(blob))[0] == 1
+    assert sqy.decode(b"no header here at all, just text" * 10)[0] == 1

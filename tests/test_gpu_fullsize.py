@@ -96,6 +96,9 @@ def test_config1_256cubed_u16_host_abi(sqy, oracle):
     rc, blob = sqy.encode("bitswap1->lz4", vol, nthreads=0)
     assert rc == 0
     _check(oracle, "bitswap1->lz4", vol, blob)
-    # the serial single-frame layout (nthreads=1) is not produced on MI355X: documented error, never silently different bytes
-    rc, _ = sqy.encode("bitswap1->lz4", vol, nthreads=1)
-    assert rc == 1
+    # nthreads = 1, what the reference's own C-ABI / Java tests and CLI pass: ONE block-linked frame of 128 blocks
+    rc, blob1 = sqy.encode("bitswap1->lz4", vol, nthreads=1)
+    assert rc == 0
+    assert blob1 == oracle.pipeline_encode("bitswap1->lz4", vol, nthreads=1)
+    rc, back = sqy.decode(blob1)
+    assert rc == 0 and np.array_equal(back, vol)

@@ -44,6 +44,19 @@ def test_lz4_frames_vs_liblz4_golden(oracle, case):
     assert np.array_equal(oracle.lz4_decode_frames(f, case["n"]), d)
 
 
+@pytest.mark.parametrize("case", G["lz4_linked"], ids=lambda c: "%s_%d_%s" % (c["kind"], c["n"], c["config"]))
+def test_lz4_linked_frames_vs_liblz4_golden(oracle, case):
+    """block-linked frames: the serial layout (nthreads == 1) and chunks of several LZ4 blocks, bytes from liblz4 1.9.3"""
+    d = gen_bytes(case["kind"], case["n"], case["seed"])
+    cfg = oracle.Lz4Config(case["config"])
+    f = oracle.lz4_encode_serial(d, cfg)
+    assert f.size == case["serial_bytes"] and sha(f.tobytes()) == case["serial_sha256"]
+    assert np.array_equal(oracle.lz4_decode_frames(f, case["n"]), d)
+    f = oracle.lz4_encode_chunked(d, cfg)
+    assert f.size == case["chunked_bytes"] and sha(f.tobytes()) == case["chunked_sha256"]
+    assert np.array_equal(oracle.lz4_decode_frames(f, case["n"]), d)
+
+
 @pytest.mark.parametrize("case", G["bitswap1_u16"], ids=lambda c: c["name"])
 def test_bitswap1_vs_reference_sse_golden(oracle, case):
     arr = {"ramp128": lambda: np.arange(128, dtype=np.uint16),
@@ -71,6 +84,11 @@ def test_pipeline_blobs_golden(oracle, case):
     back = oracle.pipeline_decode(blob)
     if "quantiser" not in case["pipeline"]:
         assert np.array_equal(back, vol)
+    # the layout the reference's default callers get (nthreads = 1: one block-linked frame)
+    blob1 = oracle.pipeline_encode(case["pipeline"], vol, nthreads=1)
+    assert len(blob1) == case["nthreads1_bytes"] and sha(blob1) == case["nthreads1_sha256"]
+    if "nthreads1_payload_sha256" in case:
+        assert sha(blob1[oracle.header_unpack(blob1)["size"]:]) == case["nthreads1_payload_sha256"]
 
 
 def test_raw_fixtures(oracle):
@@ -109,3 +127,18 @@ def test_live_liblz4_and_reference_sse(oracle):
     # liblz4's decoder accepts our frames
     d = synth.stack((8, 64, 64)).reshape(-1).view(np.uint8)
     assert np.array_equal(ref.lz4_decode_frames(oracle.lz4_encode_chunked(d), d.size), d)
+
+
+def test_live_liblz4_linked_blocks(oracle):
+    """the oracle's model of liblz4's linked-block mode (external-dictionary / prefix modes, LZ4F's tmp buffer) against
+    liblz4 itself on update sizes that are not multiples of the block size"""
+    ref = _ref()
+    rng = np.random.default_rng(321)
+    n = 1_000_000
+    streams = [gen_bytes(k, n, 9) for k in ("sparse", "farrep", "8level", "rawmix", "periodic")]
+    for d in streams:
+        for kb, bid in ((256, 5), (64, 4)):
+            cfg = oracle.Lz4Config("blocksize_kb=%d" % kb)
+            for step in (100000, 300001, 65536, 262145, 999999, 5_000_000, int(rng.integers(1000, 700000))):
+                want = ref.lz4_encode_serial(d, framestep=step, block_id=bid)
+                assert np.array_equal(oracle.lz4_encode_serial(d, cfg, framestep=step), want), (kb, step)
