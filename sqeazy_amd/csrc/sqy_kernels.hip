@@ -652,7 +652,12 @@ constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positio
 // LINKED = true: wavefront f walks the blocks [frame_first[f], frame_first[f+1]) of one frame in order; the table lives on
 // across blocks (positions are re-based by the previous block's size, entries that fall more than 64 KiB behind the new
 // block die), candidates may sit in the 64 KiB in front of the block (far fetches from global memory).
-template <bool LINKED>
+// DENSE = false: the first pass over every chunk.  A chunk that turns out to be a stream of short sequences (32 matches
+// of less than 16 bytes in a row) is given up -- csize = LZ4_REDO -- and parsed again by the DENSE = true kernel, launched
+// right behind over the same chunks (every other wavefront exits at once), which resolves several sequences per batch.
+// Two kernels instead of one keep the lean loop of the first pass free of the dense batches' registers.
+constexpr uint32_t LZ4_REDO = 0xffffffffu;
+template <bool LINKED, bool DENSE>
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
@@ -667,6 +672,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
+    if (DENSE && csize[blockIdx.x] != LZ4_REDO) return;         // (uniform) only the chunks the first pass gave up
     const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : blockIdx.x;
     const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
     uint32_t n_prev = 0;
@@ -739,6 +745,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     const uint32_t olimit = n - 1;       // capacity n-1 (LZ4F_makeBlock); offsets into dst
     uint32_t op = 0, anchor = p0;
     bool failed = false;
+    bool redo_dense = false;             // first pass: this chunk is left to the DENSE kernel
 
     if (n >= LZ4_MINLENGTH) {
         const uint32_t mflimitPlusOne = pend - LZ4_MFLIMIT + 1;
@@ -754,6 +761,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
         // A sequence found by the lean path is written out one iteration LATER, between the issue of the next batch's
         // ring reads and their first use: its ~70 instructions then run in the shadow of that LDS round trip.
+        // dense batches (several short sequences resolved from one batch of 64 probes, see below): switched on by the lean
+        // loop after two short matches in a row, off again by anything a dense batch does not handle
+        bool dense_next = DENSE;
+        uint32_t shorts = 0;
         bool pend = false;
         uint32_t pe_lit = 0, pe_mcode = 0, pe_off = 0;
         uint32_t pe_litv = 0;            // per lane: literal byte k-1 for lane k
@@ -798,6 +809,130 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // generic path below, which redoes the batch from P.
             // ---------------------------------------------------------------------------------------
             bool finished = false;
+            bool redo = false;               // the lean loop handed over to the dense batches: start the round again
+            // ---------------------------------------------------------------------------------------
+            // dense batches: streams of SHORT sequences (a few literals, a match of less than 16 bytes -- noisy bit
+            // planes, quantised data) spend one lean iteration per 5..10 bytes.  Here all 64 lanes probe P .. P+63 against
+            // the table as it stands, every lane judges its own candidate (16 bytes forward, 4 back), and a scalar walk over
+            // the two ballots then resolves sequence after sequence without touching the LDS: first hit at or behind the
+            // cursor -> literals, catch-up, match length from that lane's registers -> cursor behind the match.  Probes
+            // that share a bucket with an EARLIER lane of the batch (their true candidate may be that lane) end the batch
+            // in front of them; so do long matches, long literal runs and long catch-ups, which the lean / generic paths
+            // take over.  The sequences found are written in one go (lane k writes sequence k), the probes the walk passed
+            // over enter the table with one ds_max.  Not used inside block-linked frames.
+            // ---------------------------------------------------------------------------------------
+            if (DENSE && U == 0 && dense_next) {
+                for (;;) {
+                    if (!(P >= w.wlo + 4u && P + 112u <= w.hi_valid() && P + 112u <= matchlimit)) { dense_next = false; break; }
+                    if (pend) { emit_pending(); if (failed) break; }
+                    const uint32_t pos = P + (uint32_t)lane;
+                    const uint32_t wlo4 = w.wlo + 4u;
+                    const uint4 s16 = w.lds128(pos);
+                    const uint32_t b4 = w.lds32(pos - 4u);
+                    // LZ4_putPosition(P - 2) of the match in front: its five bytes sit in lane 0's b4 / s16
+                    {
+                        const uint32_t lo2 = (b4 >> 16) | (s16.x << 16);
+                        const uint32_t h2 = lz4_hash5_32(lo2, s16.x >> 16);
+                        if (lane == 0) atomicMax(&table[h2], ((P - 2u) << tsh) | tag_of(lo2));
+                        wave_lds_sync();
+                        put2 = 0xffffffffu;
+                    }
+                    const uint32_t h = lz4_hash5_32(s16.x, s16.y);
+                    const uint32_t mytag = tag_of(s16.x);
+                    const uint32_t mine = (pos << tsh) | mytag;
+                    const uint32_t oe = table[h];
+                    // lanes that are not the first of their bucket inside this batch (flagged ds_max through the table, then restored)
+                    atomicMax(&table[h], 0x80000000u | (uint32_t)(63 - lane));
+                    const uint32_t fl = table[h];
+                    table[h] = oe;
+                    wave_lds_sync();
+                    const bool dup = (63u - (fl & 63u)) != (uint32_t)lane;
+                    const uint32_t old = oe >> tsh;
+                    const bool near = (pos - old) <= LZ4_MAXD && (oe & tmask) == mytag;
+                    const bool cin = near && old >= wlo4;
+                    uint4 c16 = w.lds128(old);
+                    uint32_t cb4 = w.lds32(old - 4u);
+                    if (ballot(near && !cin)) {
+                        if (near && !cin) {                                             // candidates behind the ring: one round trip for all of them
+                            c16 = glb_ld_u128(w.src + old);                             // old + 16 <= pos + 15 < matchlimit
+                            cb4 = old >= 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src) << (8u * (4u - old)));
+                        }
+                    }
+                    const uint32_t d = first_diff16(s16, c16);                          // 0..16 equal bytes forward
+                    const uint32_t xb = b4 ^ cb4;
+                    const uint32_t bkv = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;  // equal bytes in front, 4 = maybe more
+                    const uint32_t offv = pos - old;
+                    const uint64_t M = ballot(near && d >= 4u);
+                    const uint64_t D = ballot(dup);
+                    // ---- the walk: uniform, registers only ----
+                    uint32_t cur = 0, anc = 0, nseq = 0;                                // lane units; anchor == P on entry
+                    uint64_t ins = 0;                                                   // probes the parse passed over (they enter the table)
+                    uint32_t q_lit = 0, q_mc = 0, q_off = 0, q_anc = 0;                 // lane k: sequence k
+                    bool keep_dense = true;
+                    while (cur < 64u && nseq < 16u) {
+                        const uint64_t ev = (M | D) & (~0ull << cur);
+                        if (!ev) break;                                                 // nothing more in this batch
+                        const uint32_t fq = ctz64(ev);
+                        if ((D >> fq) & 1ull) break;                                    // a probe whose true candidate may be an earlier lane
+                        const uint32_t lit = fq - anc;
+                        const uint32_t df = lane_read(d, fq);
+                        const uint32_t bkf = lane_read(bkv, fq);
+                        const uint32_t rm = lane_read(old, fq);                         // room on the match side (chunk start = 0)
+                        const uint32_t lim = lit < rm ? lit : rm;
+                        if (lit >= 15u || df == 16u || (bkf == 4u && lim > 4u)) { keep_dense = false; break; }
+                        const uint32_t back = bkf < lim ? bkf : lim;
+                        const uint32_t ml = df - 4u;
+                        const uint32_t ofs = lane_read(offv, fq);
+                        if ((uint32_t)lane == nseq) { q_lit = lit - back; q_mc = ml + back; q_off = ofs; q_anc = anc; }
+                        ins |= ((2ull << fq) - 1ull) & (~0ull << cur);                  // probes cur .. fq
+                        const uint32_t ipn = fq + 4u + ml;                              // behind the match (may lie beyond the batch)
+                        if (ipn - 2u < 64u) ins |= 1ull << (ipn - 2u);                  // LZ4_putPosition(ip - 2)
+                        nseq += 1; anc = ipn; cur = ipn;
+                    }
+                    if (nseq == 0) { dense_next = false; break; }                       // (P - 2 is in the table: put2 stays empty)
+                    if ((ins >> lane) & 1ull) atomicMax(&table[h], mine);
+                    wave_lds_sync();
+                    // ---- write the sequences: lane k = sequence k ----
+                    {
+                        const bool on = (uint32_t)lane < nseq;
+                        const uint32_t ext = q_mc >= 15u ? 1u : 0u;                     // match code <= 15: at most one extension byte (0)
+                        const uint32_t sb = on ? 1u + q_lit + 2u + ext : 0u;
+                        uint32_t inc = sb;                                              // inclusive prefix sum over the first 16 lanes (one DPP row)
+                        inc += __builtin_amdgcn_update_dpp(0u, inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+                        inc += __builtin_amdgcn_update_dpp(0u, inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+                        inc += __builtin_amdgcn_update_dpp(0u, inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+                        inc += __builtin_amdgcn_update_dpp(0u, inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+                        const uint32_t total = lane_read(inc, nseq - 1u);
+                        const uint32_t my_op = op + inc - sb;
+                        // upstream's two limit checks per sequence (no literal-length extension below 15 literals)
+                        const bool bad = on && (my_op + 1u + q_lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
+                                                my_op + 1u + q_lit + 2u + (1 + LZ4_LASTLITERALS) + ext > olimit);
+                        if (ballot(bad)) { failed = true; break; }
+                        o.reserve(op, total);
+                        const uint4 l16 = w.lds128(P + q_anc);                          // the literals start at the sequence's anchor
+                        const uint32_t tok = (q_lit << 4) | (q_mc < 15u ? q_mc : 15u);
+                        const uint32_t lw[4] = {l16.x, l16.y, l16.z, l16.w};
+                        lds_u8* const my = o.at(my_op);
+#pragma unroll
+                        for (uint32_t j = 0; j < 18u; ++j) {
+                            uint32_t v;
+                            if (j == 0) v = tok;
+                            else {
+                                const uint32_t lb = j <= 14u ? ((lw[(j - 1u) >> 2] >> (8u * ((j - 1u) & 3u))) & 0xffu) : 0u;
+                                v = j <= q_lit ? lb : (j == q_lit + 1u ? (q_off & 0xffu) : (j == q_lit + 2u ? (q_off >> 8) : 0u));
+                            }
+                            if (j < sb) my[j] = (uint8_t)v;
+                        }
+                        op += total;
+                    }
+                    anchor = P + cur;
+                    put2 = anchor - 2u;                                                 // (already in the table when it lay inside the batch: harmless)
+                    P = anchor;
+                    w.ensure(P);
+                    if (!keep_dense) { dense_next = false; break; }
+                }
+                if (failed) break;
+            }
             if (U == 0) {
                 // Enter the loop with no load of the compiler's own in flight (results the generic path left unused
                 // count): otherwise its waitcnt pass puts a vmcnt(0) in front of the loop's first ring read, and that
@@ -905,8 +1040,18 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     P = ipn;
                     SQY_STAMP(9);
                     w.ensure(P);
+                    if (DENSE) {
+                        // two matches of less than 16 bytes in a row: back to the dense batches
+                        shorts = ml < 12u ? shorts + 1u : 0u;
+                        if (shorts >= 2u) { shorts = 0; dense_next = true; redo = true; break; }
+                    } else if (!LINKED) {
+                        // 32 in a row: a stream of short sequences, this chunk goes to the DENSE kernel
+                        shorts = ml < 12u ? shorts + 1u : 0u;
+                        if (shorts >= 32u) { redo_dense = true; break; }
+                    }
                 }
-                if (finished || failed) break;
+                if (finished || failed || redo_dense) break;
+                if (redo) continue;
             }
 
             // ---------------------------------------------------------------------------------------
@@ -1163,7 +1308,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         if (pend && !failed) emit_pending();
     }
 
-    if (!failed) {
+    if (!failed && !redo_dense) {
         o.flush(op);
         const uint32_t lastRun = pend - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
@@ -1185,7 +1330,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
-    if (lane == 0) csize[blk] = failed ? 0u : op;
+    if (lane == 0) csize[blk] = redo_dense ? LZ4_REDO : (failed ? 0u : op);
     if (LINKED) __syncthreads();
   }
 #ifdef SQY_LZ4_DIAG
@@ -2446,7 +2591,10 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
 {
     if (nchunks == 0) return hipSuccess;
     if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lz4_chunks_kernel<false>, dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+    hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u SQY_DIAG_NULL);
+    // second pass: the chunks the first one gave up as streams of short sequences (every other wavefront exits at once)
+    hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
                        frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u SQY_DIAG_NULL);
     return hipGetLastError();
 }
@@ -2456,7 +2604,7 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
 {
     if (nframes == 0) return hipSuccess;
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lz4_chunks_kernel<true>, dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, scratch, stride, csize,
+    hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, scratch, stride, csize,
                        (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block SQY_DIAG_NULL);
     return hipGetLastError();
 }

@@ -25,11 +25,26 @@ int main(int argc, char** argv)
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
-        hipLaunchKernelGGL(sqy::lz4_chunks_kernel, dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0, ddg);
+        hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, false>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
+                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, ddg);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
         if (ms < best) best = ms;
+    }
+    // checksum of what the kernel produced (sizes and bytes): a quick "did the output change" check between builds
+    {
+        std::vector<uint32_t> cs(nch);
+        std::vector<uint8_t> scr(nch * (size_t)chunk);
+        CK(hipMemcpy(cs.data(), dcs, nch * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(scr.data(), dscr, nch * (size_t)chunk, hipMemcpyDeviceToHost));
+        unsigned long long hsh = 1469598103934665603ull, tot = 0;
+        for (uint64_t k = 0; k < nch; ++k) {
+            tot += cs[k];
+            hsh = (hsh ^ cs[k]) * 1099511628211ull;
+            for (uint32_t i = 0; i < cs[k]; ++i) hsh = (hsh ^ scr[k * (size_t)chunk + i]) * 1099511628211ull;
+        }
+        std::printf("output: %llu compressed bytes in %llu chunks, fnv %016llx\n", tot, (unsigned long long)nch, hsh);
     }
     std::vector<unsigned long long> dg(nch * 16);
     CK(hipMemcpy(dg.data(), ddg, nch * 16 * 8, hipMemcpyDeviceToHost));

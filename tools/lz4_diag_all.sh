@@ -1,7 +1,7 @@
 #!/bin/bash
 # builds tools/lz4_diag_<A>_<B> for the usual regions (here, no GPU needed) or runs them all on a chunk file (GPU box)
 #   tools/lz4_diag_all.sh build        |   tools/lz4_diag_all.sh run tools/_plane11.bin
-REGIONS="1_9 0_10"
+REGIONS=${REGIONS:-"0_1 1_2 2_3 3_4 4_5 5_6 6_7 7_8 8_9 9_1 1_9"}
 cd "$(dirname "$0")/.."
 if [ "$1" = build ]; then
   for r in $REGIONS; do
