@@ -451,9 +451,13 @@ __device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
 // flight (vmcnt(0)) and the prefetch hides nothing.  commit() waits for it explicitly when ip gets within AHEAD
 // bytes of whi, one refill later.  (The compiler's own vmcnt(N) waits only become stricter by the extra
 // outstanding operation, never too weak: VMEM operations retire in order.)
-constexpr uint32_t LZ4_WIN = 8192, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
+// The first pass keeps the ring at 8 KiB (26 KiB of LDS per chunk wave = 6 waves per CU).  The DENSE kernel, which only
+// runs the chunks the first pass gave up, takes 32 KiB: with 64 probes per batch nearly every batch would otherwise have
+// a candidate behind the ring, i.e. a global round trip per batch.
+constexpr uint32_t LZ4_WIN_LEAN = 8192, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
-struct Lz4Window {
+template <uint32_t LZ4_WIN>
+struct Lz4WindowT {
     glb_u8* src;           // chunk source (global)
     lds_u8* win;           // LDS ring (WIN + MIRROR bytes)
     uint32_t n;            // chunk bytes
@@ -543,6 +547,7 @@ struct Lz4Window {
 };
 
 // copy `len` bytes (uniform) of the chunk starting at position `from` to d, any alignment; all 64 lanes call it
+template <class Lz4Window>
 __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const Lz4Window& w, uint32_t from, uint32_t len, int lane)
 {
     if (len <= 64) {
@@ -577,6 +582,7 @@ __device__ __forceinline__ uint32_t first_diff16(uint4 x, uint4 y)
 }
 
 // number of equal leading bytes of chunk[a..a+maxlen) and chunk[b..b+maxlen), maxlen <= 16, b < a
+template <class Lz4Window>
 __device__ __forceinline__ uint32_t common16(const Lz4Window& w, uint32_t a, uint32_t b, uint32_t maxlen)
 {
     if (a + 16u <= w.n) {
@@ -665,10 +671,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
-    unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
     bool darmed = false;
 #endif
     __shared__ uint32_t table[4096];
+    constexpr uint32_t LZ4_WIN = DENSE ? LZ4_WIN_DENSE : LZ4_WIN_LEAN;
+    typedef Lz4WindowT<LZ4_WIN> Lz4Window;
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
@@ -861,40 +869,69 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     const uint32_t d = first_diff16(s16, c16);                          // 0..16 equal bytes forward
                     const uint32_t xb = b4 ^ cb4;
                     const uint32_t bkv = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;  // equal bytes in front, 4 = maybe more
-                    const uint32_t offv = pos - old;
+                    // what the walk needs of a lane in one word: forward bytes | bytes in front << 5 | "candidate within 15 bytes of
+                    // the chunk start" << 8 (the catch-up limit then needs care: left to the other paths) | offset << 16
+                    const uint32_t info = d | (bkv << 5) | (old < 16u ? 0x100u : 0u) | ((pos - old) << 16);
                     const uint64_t M = ballot(near && d >= 4u);
                     const uint64_t D = ballot(dup);
                     // ---- the walk: uniform, registers only ----
                     uint32_t cur = 0, anc = 0, nseq = 0;                                // lane units; anchor == P on entry
                     uint64_t ins = 0;                                                   // probes the parse passed over (they enter the table)
-                    uint32_t q_lit = 0, q_mc = 0, q_off = 0, q_anc = 0;                 // lane k: sequence k
+                    uint32_t q_rec = 0;                                                 // lane k: sequence k, packed
                     bool keep_dense = true;
+                    uint64_t evm = M | D;                                               // lanes the walk has to look at
                     while (cur < 64u && nseq < 16u) {
-                        const uint64_t ev = (M | D) & (~0ull << cur);
+                        const uint64_t ev = evm & (~0ull << cur);
                         if (!ev) break;                                                 // nothing more in this batch
                         const uint32_t fq = ctz64(ev);
-                        if ((D >> fq) & 1ull) break;                                    // a probe whose true candidate may be an earlier lane
+                        bool is_hit = (M >> fq) & 1ull;
+                        uint32_t inf = lane_read(info, fq);
+                        if ((D >> fq) & 1ull) {
+                            // an earlier lane of this batch hashes to the same bucket.  If one of them has entered the table by
+                            // now (a probe the parse passed over, or an ip - 2), the LATEST such lane is this probe's true
+                            // candidate -- both sequences sit in registers, compare them right here
+                            const uint32_t hf = lane_read(h, fq);
+                            const uint64_t passed = ins | (((1ull << fq) - 1ull) & (~0ull << cur));
+                            const uint64_t mates = ballot(h == hf) & ((1ull << fq) - 1ull) & passed;
+                            if (mates) {
+                                const uint32_t qm = 63u - (uint32_t)__builtin_clzll(mates);
+                                const uint32_t x0 = lane_read(s16.x, fq) ^ lane_read(s16.x, qm);
+                                const uint32_t x1 = lane_read(s16.y, fq) ^ lane_read(s16.y, qm);
+                                const uint32_t x2 = lane_read(s16.z, fq) ^ lane_read(s16.z, qm);
+                                const uint32_t x3 = lane_read(s16.w, fq) ^ lane_read(s16.w, qm);
+                                const uint32_t xbq = lane_read(b4, fq) ^ lane_read(b4, qm);
+                                is_hit = x0 == 0;
+                                const uint32_t dq = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
+                                                  : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+                                const uint32_t bq = xbq ? ((uint32_t)__builtin_clz(xbq) >> 3) : 4u;
+                                inf = dq | (bq << 5) | (P + qm < 16u ? 0x100u : 0u) | ((fq - qm) << 16);
+                                SQY_REASON(10);
+                            }
+                        }
+                        if (!is_hit) { evm &= ~(1ull << fq); continue; }                 // (a same-bucket lane that is no match: one more probe passed)
+                        const uint32_t df = inf & 31u, bkf = (inf >> 5) & 7u;
                         const uint32_t lit = fq - anc;
-                        const uint32_t df = lane_read(d, fq);
-                        const uint32_t bkf = lane_read(bkv, fq);
-                        const uint32_t rm = lane_read(old, fq);                         // room on the match side (chunk start = 0)
-                        const uint32_t lim = lit < rm ? lit : rm;
-                        if (lit >= 15u || df == 16u || (bkf == 4u && lim > 4u)) { keep_dense = false; break; }
-                        const uint32_t back = bkf < lim ? bkf : lim;
+                        if (lit >= 15u || df == 16u || (bkf == 4u && lit > 4u) || (inf & 0x100u)) { keep_dense = false; SQY_REASON(11); break; }
+                        const uint32_t back = bkf < lit ? bkf : lit;
                         const uint32_t ml = df - 4u;
-                        const uint32_t ofs = lane_read(offv, fq);
-                        if ((uint32_t)lane == nseq) { q_lit = lit - back; q_mc = ml + back; q_off = ofs; q_anc = anc; }
+                        // sequence k in lane k: literals | match code << 4 | anchor (lane units) << 8 | offset << 16
+                        if ((uint32_t)lane == nseq) q_rec = (lit - back) | ((ml + back) << 4) | (anc << 8) | (inf & 0xffff0000u);
                         ins |= ((2ull << fq) - 1ull) & (~0ull << cur);                  // probes cur .. fq
                         const uint32_t ipn = fq + 4u + ml;                              // behind the match (may lie beyond the batch)
                         if (ipn - 2u < 64u) ins |= 1ull << (ipn - 2u);                  // LZ4_putPosition(ip - 2)
                         nseq += 1; anc = ipn; cur = ipn;
                     }
-                    if (nseq == 0) { dense_next = false; break; }                       // (P - 2 is in the table: put2 stays empty)
+                    SQY_REASON(8);
+#ifdef SQY_LZ4_DIAG
+                    dreason[9] += nseq;
+#endif
+                    if (nseq == 0) { dense_next = false; SQY_REASON(12); break; }        // (P - 2 is in the table: put2 stays empty)
                     if ((ins >> lane) & 1ull) atomicMax(&table[h], mine);
                     wave_lds_sync();
                     // ---- write the sequences: lane k = sequence k ----
                     {
                         const bool on = (uint32_t)lane < nseq;
+                        const uint32_t q_lit = q_rec & 15u, q_mc = (q_rec >> 4) & 15u, q_anc = (q_rec >> 8) & 0xffu, q_off = q_rec >> 16;
                         const uint32_t ext = q_mc >= 15u ? 1u : 0u;                     // match code <= 15: at most one extension byte (0)
                         const uint32_t sb = on ? 1u + q_lit + 2u + ext : 0u;
                         uint32_t inc = sb;                                              // inclusive prefix sum over the first 16 lanes (one DPP row)
@@ -910,18 +947,33 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         if (ballot(bad)) { failed = true; break; }
                         o.reserve(op, total);
                         const uint4 l16 = w.lds128(P + q_anc);                          // the literals start at the sequence's anchor
-                        const uint32_t tok = (q_lit << 4) | (q_mc < 15u ? q_mc : 15u);
-                        const uint32_t lw[4] = {l16.x, l16.y, l16.z, l16.w};
+                        // the sequence as five little-endian words: token, literals, offset, (extension byte 0), exact length sb;
+                        // whole words leave as (unaligned) word stores, the 0..3 bytes behind them as byte stores
+                        const uint32_t tok = (q_lit << 4) | q_mc;                       // (q_mc <= 15 is its own token nibble)
+                        uint32_t wv[6];
+                        wv[0] = tok | (l16.x << 8);
+                        wv[1] = __builtin_amdgcn_alignbyte(l16.y, l16.x, 3);
+                        wv[2] = __builtin_amdgcn_alignbyte(l16.z, l16.y, 3);
+                        wv[3] = __builtin_amdgcn_alignbyte(l16.w, l16.z, 3);
+                        wv[4] = l16.w >> 24;
+                        wv[5] = 0;
+                        const uint32_t hb = 1u + q_lit;                                 // the offset sits behind token + literals
+                        const uint32_t hw = hb >> 2, hs = (hb & 3u) * 8u;
+                        const uint64_t hdr = (uint64_t)q_off << hs;                     // (extension byte, when present, is 0)
+                        const uint32_t keep = (1u << hs) - 1u;
+#pragma unroll
+                        for (uint32_t i = 0; i < 6u; ++i)
+                            wv[i] = i < hw ? wv[i] : (i == hw ? ((wv[i] & keep) | (uint32_t)hdr) : (i == hw + 1u ? (uint32_t)(hdr >> 32) : 0u));
                         lds_u8* const my = o.at(my_op);
 #pragma unroll
-                        for (uint32_t j = 0; j < 18u; ++j) {
-                            uint32_t v;
-                            if (j == 0) v = tok;
-                            else {
-                                const uint32_t lb = j <= 14u ? ((lw[(j - 1u) >> 2] >> (8u * ((j - 1u) & 3u))) & 0xffu) : 0u;
-                                v = j <= q_lit ? lb : (j == q_lit + 1u ? (q_off & 0xffu) : (j == q_lit + 2u ? (q_off >> 8) : 0u));
-                            }
-                            if (j < sb) my[j] = (uint8_t)v;
+                        for (uint32_t i = 0; i < 4u; ++i)
+                            if (4u * (i + 1u) <= sb) reinterpret_cast<SQY_LDS pk_u32*>(my + 4u * i)->v = wv[i];
+                        {
+                            const uint32_t tw = sb >> 2, tb = sb & 3u;                  // first word that is not stored whole, its bytes
+                            const uint32_t tv = tw == 0 ? wv[0] : tw == 1 ? wv[1] : tw == 2 ? wv[2] : tw == 3 ? wv[3] : wv[4];
+                            if (tb >= 1u) my[4u * tw] = (uint8_t)tv;
+                            if (tb >= 2u) my[4u * tw + 1u] = (uint8_t)(tv >> 8);
+                            if (tb >= 3u) my[4u * tw + 2u] = (uint8_t)(tv >> 16);
                         }
                         op += total;
                     }
@@ -1334,7 +1386,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     if (LINKED) __syncthreads();
   }
 #ifdef SQY_LZ4_DIAG
-    if (lane == 0) { diag[blockIdx.x * 16] = dacc; diag[blockIdx.x * 16 + 1] = dcnt; for (int i = 0; i < 8; ++i) diag[blockIdx.x * 16 + 8 + i] = dreason[i]; }
+    if (lane == 0) { diag[blockIdx.x * 32] = dacc; diag[blockIdx.x * 32 + 1] = dcnt; for (int i = 0; i < 16; ++i) diag[blockIdx.x * 32 + 8 + i] = dreason[i]; }
 #endif
 }
 

@@ -46,6 +46,26 @@ body = planes[hdr:hdr + vol.numel() * 2].clone()
 for p in ((3, 4, 5, 6, 7, 15) if not full else range(16)):
     run("C2 plane bit %d" % (15 - p), body[p * seg:(p + 1) * seg])
 del planes, body, vol
+def planes_of(pipeline, v, shape, dtype, elem_out):
+    cap = sqeazy_amd.max_compressed_length(pipeline, shape, dtype)
+    buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+    rc, m = sqeazy_amd.encode_device(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+    assert rc == 0
+    nbytes = int(np.prod(shape)) * elem_out
+    return buf[m - nbytes:m].clone(), nbytes
+
+
+if "--c3planes" in sys.argv or "--c5planes" in sys.argv:
+    v = synth.stack_torch((256, 2048, 2048), np.uint16, dev)
+    if "--c3planes" in sys.argv:
+        body, nb = planes_of("diff3x3x1->bitswap1", v, (256, 2048, 2048), np.uint16, 2)
+        for p in range(16):
+            run("C3 plane bit %d" % (15 - p), body[p * (nb // 16):(p + 1) * (nb // 16)], reps=2)
+    if "--c5planes" in sys.argv:
+        body, nb = planes_of("quantiser->bitswap1", v, (256, 2048, 2048), np.uint16, 1)
+        for p in range(8):
+            run("C5 plane bit %d" % (7 - p), body[p * (nb // 8):(p + 1) * (nb // 8)], reps=2)
+    del v
 if full or "--slabs" in sys.argv:
     v = synth.stack_torch((256, 2048, 2048), np.uint16, dev)
     run("C3 slab", v, "diff3x3x1->bitswap1->lz4", (256, 2048, 2048), np.uint16, reps=2)

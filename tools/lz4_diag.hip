@@ -19,13 +19,15 @@ int main(int argc, char** argv)
     const uint32_t chunk = argc > 2 ? std::atoi(argv[2]) : 262144;
     const uint64_t nch = (n + chunk - 1) / chunk;
     uint8_t *din, *dscr; uint32_t* dcs; unsigned long long* ddg;
-    CK(hipMalloc(&din, n + 64)); CK(hipMalloc(&dscr, nch * chunk)); CK(hipMalloc(&dcs, nch * 4)); CK(hipMalloc(&ddg, nch * 16 * 8));
+    CK(hipMalloc(&din, n + 64)); CK(hipMalloc(&dscr, nch * chunk)); CK(hipMalloc(&dcs, nch * 4)); CK(hipMalloc(&ddg, nch * 32 * 8)); CK(hipMemset(ddg, 0, nch * 32 * 8));
     CK(hipMemcpy(din, h.data(), n, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
         hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, false>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
+                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, ddg);
+        hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, true>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
                            (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, ddg);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
@@ -46,10 +48,12 @@ int main(int argc, char** argv)
         }
         std::printf("output: %llu compressed bytes in %llu chunks, fnv %016llx\n", tot, (unsigned long long)nch, hsh);
     }
-    std::vector<unsigned long long> dg(nch * 16);
-    CK(hipMemcpy(dg.data(), ddg, nch * 16 * 8, hipMemcpyDeviceToHost));
-    unsigned long long acc = 0, cnt = 0, rs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (uint64_t k = 0; k < nch; ++k) { acc += dg[k * 16]; cnt += dg[k * 16 + 1]; for (int i = 0; i < 8; ++i) rs[i] += dg[k * 16 + 8 + i]; }
+    std::vector<unsigned long long> dg(nch * 32);
+    CK(hipMemcpy(dg.data(), ddg, nch * 32 * 8, hipMemcpyDeviceToHost));
+    unsigned long long acc = 0, cnt = 0, rs[16] = {0};
+    for (uint64_t k = 0; k < nch; ++k) { acc += dg[k * 32]; cnt += dg[k * 32 + 1]; for (int i = 0; i < 16; ++i) rs[i] += dg[k * 32 + 8 + i]; }
+    if (std::getenv("SQY_DIAG_DENSE")) std::printf("dense: batches %llu, sequences %llu, ended by dup %llu, by long/lit/catch-up %llu, empty %llu | lean->generic U!=0 %llu U==0 %llu\n",
+                rs[8] / nch, rs[9] / nch, rs[10] / nch, rs[11] / nch, rs[12] / nch, rs[6] / nch, rs[7] / nch);
     std::printf("region %2d -> %2d: kernel %.3f ms, %llu passes/chunk, avg %.0f cycles, total %.0f cycles/chunk | events/chunk: no-hit %llu f0>14 %llu far-fetch %llu hazard %llu long %llu slow-back %llu genericU!=0 %llu genericU==0 %llu\n",
                 SQY_DIAG_A, SQY_DIAG_B, best, cnt / nch, cnt ? (double)acc / cnt : 0.0, (double)acc / nch,
                 rs[0] / nch, rs[1] / nch, rs[2] / nch, rs[3] / nch, rs[4] / nch, rs[5] / nch, rs[6] / nch, rs[7] / nch);
