@@ -1,25 +1,44 @@
 #!/usr/bin/env python3
 """bench.py -- encode GB/s (input voxels) for the 'bitswap1->lz4' uint16 pipeline on N x MI355X.
 
-Contract (driver):  python bench.py --gpus N --steps K --warmup W   (N>1: launched by torch.distributed.run,
-one rank per GPU).  A "step" is one pass of the hot path over one z-slab: every rank encodes a
-1024x1024x512 uint16 synthetic stack (BASELINE.json configs[1]; 1 GiB, already resident in HBM) with ONE
-C-ABI call; the slab blobs are independent sqeazy blobs and stay on their GPUs, only their sizes (the index of
-the sharded container) are all_gathered over RCCL (N>1 only; --gather-to-root also moves the blobs to rank 0).
-Weak scaling: per-GPU work is fixed.  value = (N * input bytes * K) / max-over-ranks wall time, GB = 1e9 bytes.
+Contract (driver):  python bench.py --gpus N --steps K --warmup W.  For N > 1 the driver starts one rank per GPU with
+torch.distributed.run; called WITHOUT that launcher and N > 1 this script starts the ranks itself (a torchrun child
+process, before anything here touches the GPU) and exits with the child's code.
+
+A "step" is one pass of the hot path over one z-slab: every rank encodes a 1024x1024x512 uint16 synthetic stack
+(BASELINE.json configs[1]; 1 GiB, already resident in HBM) with ONE C-ABI call.  Weak scaling: per-GPU work is fixed.
+W warm-up steps, then blocks of EXACTLY K steps, each bracketed by barrier + torch.cuda.synchronize() on both sides, MAX
+over ranks per block; blocks are repeated until >= 1 s has been timed and the MEDIAN block is reported (`ms_per_step`,
+`value`; min / max next to it).  value = (N * input bytes * K) / block time, GB = 1e9 bytes.
+
+N > 1: slabs are independent sqeazy blobs.  `value` is measured with the blobs left on the GPUs that made them (a sharded
+container; only the 8-byte sizes -- its index -- are all_gathered over RCCL per step).  `with_gather` is the same run with
+north_star's final RCCL gather of the compressed slabs to rank 0 inside every step, posted from a gather thread so that it
+overlaps the next steps' encodes (double-buffered root ingress).
 
 The JSON line also carries
-  roofline      the dominant kernel (largest share of device time, timed with HIP events on the launch
-                stream inside the timed region) priced at the path's ALGORITHMIC bytes per call
-                (2 B per voxel read once + payload bytes written once: SURVEY.md 8(d)) against 8 TB/s.
-  cpu_baseline  the same pipeline on the host cores: the reference's own SSE bit-plane gather + liblz4
-                1.9.3 frames (oracle/_ref, "reference") when that library loads, else our C restatement
-                ("port"); bounded sample, rank 0, N=1 only.
+  roofline      the dominant kernel (largest share of device time, HIP events on the launch stream inside the timed
+                region) priced at the path's ALGORITHMIC bytes per call (2 B per voxel read once + payload bytes written
+                once: SURVEY.md 8(d)) against 8 TB/s; `alone_*` = the same with one call at a time; `traffic` = PMC bytes
+                per launch from the committed rocprofv3 passes of THIS library build (profiles/, matched by sha256), else null
+  cpu_baseline  the reference's own SSE bit-plane gather + liblz4 1.9.3 frames (oracle/_ref) on the host cores, the two
+                C calls alone on the full 1 GiB stack: one thread and all cores
+  host_abi      the same stack through the reference-protocol entry point SQY_PipelineEncode_UI16 (host pointers, PCIe)
+  config.secondary   device time and roofline fraction of the other BASELINE configs and of north_star's target
+                (2048^3 uint16 as 8 sequential 2048x2048x256 slab calls on this GPU); N = 1 only
+  build         sha256 and compile flags of libsqeazy_amd.so
 """
 import argparse
+import ctypes
+import hashlib
 import json
 import os
+import queue
+import socket
+import statistics
+import subprocess
 import sys
+import threading
 import time
 
 import numpy as np
@@ -32,32 +51,168 @@ SHAPE = (512, 1024, 1024)          # {z,y,x}: 1024x1024x512 voxels, uint16 -> 1 
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 
 
-def cpu_baseline(sample_frames=96, reps=3):
-    """bitswap1->lz4 on the host cores over the first `sample_frames` frames of the same synthetic stack"""
-    from sqeazy_amd import synth
+def lib_identity():
+    import sqeazy_amd
+    from sqeazy_amd import build
+    h = hashlib.sha256()
+    with open(sqeazy_amd.LIB_PATH, "rb") as f:
+        for blk in iter(lambda: f.read(1 << 20), b""):
+            h.update(blk)
+    return {"library": os.path.relpath(sqeazy_amd.LIB_PATH, ROOT), "sha256": h.hexdigest(),
+            "hipcc_flags": "--offload-arch=%s %s" % (build.ARCH, " ".join(build.FLAGS))}
+
+
+def measured_traffic(sha, kernel):
+    """PMC bytes per launch of `kernel` from the newest profiles/*_pmc_hbm.json that was collected on this very build"""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
+        if name.endswith("_pmc_hbm.json"):
+            try:
+                j = json.load(open(os.path.join(pdir, name)))
+            except Exception:
+                continue
+            if j.get("library_sha256") == sha and kernel in j.get("traffic", {}):
+                best = {"bytes_per_launch": j["traffic"][kernel], "per_call_all_kernels": sum(j["traffic"].values()), "source": "profiles/" + name}
+    return best
+
+
+def cpu_baseline(vol_host):
+    """the reference's SSE bit-plane gather + liblz4 frames on the host, the two C calls alone (no Python staging in the timed part)"""
     from oracle import ref, sqy_oracle
     cores = os.cpu_count() or 1
-    vol = synth.stack((sample_frames, SHAPE[1], SHAPE[2]), np.uint16)
-    nbytes = vol.nbytes
-    use_ref = ref.available()
-    best = None
-    for _ in range(reps):
+    flat = np.ascontiguousarray(vol_host).reshape(-1)
+    nbytes = flat.nbytes
+    if not ref.available():
         t0 = time.perf_counter()
-        if use_ref:
-            planes = ref.bitswap1_encode_u16(vol, nthreads=min(cores, 16))
-            enc = ref.lz4_encode_parallel(planes.view(np.uint8), nthreads=cores)
-        else:
-            planes = sqy_oracle.bitswap1_encode_planes(vol, nthreads=min(cores, 16))
-            enc = sqy_oracle.lz4_encode_chunked(planes.view(np.uint8))
+        planes = sqy_oracle.bitswap1_encode_planes(flat, nthreads=min(cores, 16))
+        enc = sqy_oracle.lz4_encode_chunked(planes.view(np.uint8))
         dt = time.perf_counter() - t0
+        return {"value": round(nbytes / dt / 1e9, 4), "unit": "GB/s", "cores": min(cores, 16), "kind": "port",
+                "sample": "full %d MiB stack, C restatement (oracle/_ref not loadable)" % (nbytes >> 20), "payload_ratio": round(nbytes / enc.size, 3)}
+    L = ref.lib()
+    u16p, chp = ctypes.POINTER(ctypes.c_uint16), ctypes.c_char_p
+    # 16-byte aligned source / plane buffers, output sized as encode_parallel wants it; all touched before the clock starts
+    raw = np.zeros(flat.size + 8, np.uint16)
+    src = raw[(-raw.ctypes.data % 16) // 2:][:flat.size]
+    src[:] = flat
+    planes = np.zeros(flat.size, np.uint16)
+    chunk = 256 << 10
+    stride = L.ref_lz4f_compress_bound(ctypes.c_size_t(chunk), ctypes.c_int(1), ctypes.c_int(5)) + 19
+    cap = ((nbytes + chunk - 1) // chunk) * stride + 64
+    dst = np.zeros(cap, np.uint8)
+    rows = {}
+    for label, nt_bsw, nt_lz4, reps in (("1_thread", 1, 1, 1), ("all_cores", min(cores, 16), cores, 3)):
+        best, nout = None, 0
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            rc = L.ref_bitswap1_encode_u16(src.ctypes.data_as(u16p), planes.ctypes.data_as(u16p), ctypes.c_size_t(flat.size), ctypes.c_int(nt_bsw))
+            t1 = time.perf_counter()
+            # one thread: the layout a 1-thread reference run produces (encode_serial); else encode_parallel
+            if nt_lz4 == 1:
+                nout = L.ref_lz4_encode_serial(planes.ctypes.data_as(chp), ctypes.c_size_t(nbytes), dst.ctypes.data_as(chp), ctypes.c_size_t(cap),
+                                               ctypes.c_size_t(chunk), ctypes.c_int(1), ctypes.c_int(5))
+            else:
+                nout = L.ref_lz4_encode_parallel(planes.ctypes.data_as(chp), ctypes.c_size_t(nbytes), dst.ctypes.data_as(chp), ctypes.c_size_t(cap),
+                                                 ctypes.c_size_t(chunk), ctypes.c_int(1), ctypes.c_int(5), ctypes.c_int(nt_lz4))
+            t2 = time.perf_counter()
+            if rc or not nout:
+                raise RuntimeError("reference pieces failed (rc %d, %d bytes)" % (rc, nout))
+            if best is None or t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0, t2 - t1)
+        rows[label] = {"value": round(nbytes / best[0] / 1e9, 4), "bitswap_s": round(best[1], 3), "lz4_s": round(best[2], 3),
+                       "threads": nt_lz4, "payload_bytes": int(nout)}
+    return {"value": rows["all_cores"]["value"], "unit": "GB/s", "cores": cores, "kind": "reference",
+            "sample": "the full %dx%dx%d uint16 bench stack (%d MiB); timed: simd_segment_broadcast (reference SSE, <= 16 threads) + "
+                      "liblz4 1.9.3 frames through sqeazy's call sequence, the two C calls only; best of 3 (all cores), 1 run (1 thread)" % (
+                          SHAPE[2], SHAPE[1], SHAPE[0], nbytes >> 20),
+            "one_thread": rows["1_thread"], "all_cores": rows["all_cores"]}
+
+
+def host_abi(vol_host, shape):
+    """SQY_PipelineEncode_UI16 on caller memory (pageable, touched): H2D + kernels + D2H, as a C caller sees it"""
+    import sqeazy_amd
+    L = sqeazy_amd.lib()
+    cap = sqeazy_amd.max_compressed_length(PIPELINE, shape, np.uint16)
+    dst = np.zeros(cap, np.uint8)
+    shp = (ctypes.c_long * 3)(*shape)
+    n = ctypes.c_long(0)
+    best = None
+    for _ in range(4):
+        t0 = time.perf_counter()
+        rc = L.SQY_PipelineEncode_UI16(PIPELINE.encode(), ctypes.c_void_p(vol_host.ctypes.data), shp, 3, ctypes.c_void_p(dst.ctypes.data), ctypes.byref(n), 0)
+        dt = time.perf_counter() - t0
+        if rc:
+            raise RuntimeError("SQY_PipelineEncode_UI16 returned %d" % rc)
         best = dt if best is None else min(best, dt)
-    return {"value": round(nbytes / best / 1e9, 4), "unit": "GB/s", "cores": cores if use_ref else min(cores, 16),
-            "kind": "reference" if use_ref else "port",
-            "sample": "%dx%dx%d uint16 (first frames of the bench stack, %.0f MiB), best of %d, %s" % (
-                SHAPE[2], SHAPE[1], sample_frames, nbytes / 2**20, reps,
-                "reference SSE bitswap + liblz4 1.9.3 frames, OpenMP all cores" if use_ref
-                else "C restatement: 16-plane bitswap OpenMP + serial LZ4 frames"),
-            "payload_ratio": round(nbytes / enc.size, 3)}
+    return {"value": round(vol_host.nbytes / best / 1e9, 3), "unit": "GB/s", "ms_per_call": round(best * 1e3, 2),
+            "entry_point": "SQY_PipelineEncode_UI16 (host pointers: %.2f GB up, kernels, %.2f GB down), best of 4" % (vol_host.nbytes / 1e9, n.value / 1e9)}
+
+
+def secondary_configs(dev):
+    """device time of one call for the other BASELINE configs and north_star's target, roofline fraction of the whole call"""
+    import torch
+    import sqeazy_amd
+    from sqeazy_amd import synth
+    out = {}
+
+    def one(pipeline, shape, dtype, algo_per_voxel, vol=None, reps=3, extra=0):
+        v = vol if vol is not None else synth.stack_torch(shape, dtype, dev)
+        cap = sqeazy_amd.max_compressed_length(pipeline, shape, dtype) + extra
+        buf = torch.empty(cap, dtype=torch.uint8, device=dev)
+        rc, m = sqeazy_amd.encode_device(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+        if rc:
+            raise RuntimeError("%s returned %d" % (pipeline, rc))
+        best, prof = None, {}
+        for _ in range(reps):
+            sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            rc, m = sqeazy_amd.encode_device(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+            sqeazy_amd.profile_enable(False)
+            if best is None or dt < best:
+                best, prof = dt, sqeazy_amd.profile_get()
+        nvox = int(np.prod(shape))
+        hdr = sqeazy_amd.header_size(bytes(buf[:65536].cpu().numpy().tobytes()))
+        algo = algo_per_voxel * nvox + (m - hdr)
+        res = {"ms_per_call": round(best * 1e3, 3), "input_GBps": round(nvox * np.dtype(dtype).itemsize / best / 1e9, 1),
+               "algorithmic_bytes": int(algo), "roofline_frac": round(algo / best / 1e9 / HBM_PEAK_GBS, 5), "blob_bytes": int(m),
+               "kernels_ms": {k: round(a / max(c, 1), 3) for k, (a, c) in prof.items()}}
+        del buf
+        if vol is None:
+            del v
+        torch.cuda.empty_cache()
+        return res, best
+
+    out["C3_slab 2048x2048x256 u16 diff3x3x1->bitswap1->lz4"], _ = one("diff3x3x1->bitswap1->lz4", (256, 2048, 2048), np.uint16, 2)
+    out["C4 1024x1024x1024 u8 frame_shuffle->lz4"], _ = one("frame_shuffle->lz4", (1024, 1024, 1024), np.uint8, 2, extra=1 << 16)
+    out["C5_slab 2048x2048x256 u16 quantiser->bitswap1->lz4"], _ = one("quantiser->bitswap1->lz4", (256, 2048, 2048), np.uint16, 4)
+    # north_star's target on one GPU: 2048^3 uint16, bitswap1->lz4, eight sequential 2 GiB slab calls (inputs resident when each call starts)
+    total_t, total_algo, total_in, slabs = 0.0, 0, 0, []
+    for i in range(8):
+        v = synth.stack_torch((256, 2048, 2048), np.uint16, dev, z_offset=256 * i, z_total=2048)
+        r, t = one(PIPELINE, (256, 2048, 2048), np.uint16, 2, vol=v, reps=2)
+        del v
+        torch.cuda.empty_cache()
+        total_t += t; total_algo += r["algorithmic_bytes"]; total_in += 2 * 256 * 2048 * 2048
+        slabs.append(r["ms_per_call"])
+    out["north_star 2048^3 u16 bitswap1->lz4, 8 sequential 2048x2048x256 calls"] = {
+        "ms_total": round(total_t * 1e3, 2), "ms_per_slab": slabs, "input_GBps": round(total_in / total_t / 1e9, 1),
+        "algorithmic_bytes": int(total_algo), "roofline_frac": round(total_algo / total_t / 1e9 / HBM_PEAK_GBS, 5)}
+    return out
+
+
+def spawn_ranks(n, argv):
+    """--gpus N without a launcher: start the N ranks as a torchrun child (nothing in this process has touched the GPU yet)"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + argv
+    return subprocess.call(cmd, env=env)
 
 
 def main():
@@ -66,15 +221,19 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--quick", action="store_true", help="main measurement only (no CPU baseline, host ABI, secondary configs): profiling runs")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="keep timing blocks of --steps steps until this much has been timed")
     ap.add_argument("--frames", type=int, default=SHAPE[0], help="z extent per GPU (default: the BASELINE config)")
-    ap.add_argument("--gather-to-root", action="store_true",
-                    help="N>1: also move every rank's compressed blob to rank 0 inside the step (default: blobs stay sharded, only "
-                         "their sizes -- the container index -- are exchanged)")
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the second measurement with the RCCL gather to rank 0 inside the step")
     ap.add_argument("--inflight", type=int, default=2,
                     help="C-ABI calls in flight per GPU (host threads, one stream + workspace each; the C-ABI is re-entrant like "
                          "the reference's).  1 = strictly one call after the other.  Two already keep the GPU busy (the LZ4 parse "
                          "of one call overlaps the HBM-bound kernels of the other); more only stretch each kernel's duration")
     args = ap.parse_args()
+
+    # (SQY_BENCH_FORCE_SPAWN=1: rehearsal of the self-launch on a one-GPU box)
+    if (args.gpus > 1 or os.environ.get("SQY_BENCH_FORCE_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -88,7 +247,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    # rehearsal of the N > 1 code path (RCCL init, size exchange, barrier, max-reduce) on a one-GPU box: a group of one
+    # rehearsal of the N > 1 code path (RCCL init, size exchange, gather, barrier, max-reduce) on a one-GPU box: a group of one
     dist_on = world > 1 or os.environ.get("SQY_BENCH_FORCE_DIST") == "1"
     if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -98,40 +257,40 @@ def main():
     dev = torch.device("cuda", local_rank)
     if dist_on:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    if args.gpus != world and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+        world = dist.get_world_size()          # the ranks RCCL actually sees
 
     shape = (args.frames, SHAPE[1], SHAPE[2])
     # rank r holds frames [r*Z, (r+1)*Z) of an (N*Z, Y, X) synthetic stack
     vol = synth.stack_torch(shape, np.uint16, dev, z_offset=rank * shape[0], z_total=world * shape[0])
     nbytes = vol.numel() * 2
     cap = sqeazy_amd.max_compressed_length(PIPELINE, shape, np.uint16)
-    gather_buf = torch.empty(world * cap, dtype=torch.uint8, device=dev) if (dist_on and rank == 0 and args.gather_to_root) else None
     index_rows = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(8)] if dist_on else []   # container index of the last steps
-    import queue
-    import threading
     sys.setswitchinterval(1e-4)      # caller threads hand the GIL over promptly (default 5 ms would show up as whole milliseconds per step)
     inflight = max(1, args.inflight)
     # every caller thread owns a stream and two output buffers (the gather of step s may still read one while s+inflight encodes)
     streams = [torch.cuda.Stream(device=dev) for _ in range(inflight)]
     outs = [[torch.empty(cap, dtype=torch.uint8, device=dev) for _ in range(2)] for _ in range(inflight)]
-    out = outs[0][0]
+    gatherer = multi.SlabGatherer(world * cap, dev) if (dist_on and not args.no_gather) else None
     torch.cuda.synchronize()
 
-    def run_steps(k):
-        """k steps: thread t encodes steps t, t+inflight, ...; the main thread gathers the blobs in step order"""
+    def run_steps(k, gather=False):
+        """k steps: thread t encodes steps t, t+inflight, ...; the main thread takes them in step order and either exchanges the
+        sizes (sharded container) or hands the blob to the gatherer (overlapped gather to rank 0), then recycles the buffer"""
         done_q = queue.Queue()
         free_q = [queue.Queue() for _ in range(inflight)]
         for fq in free_q:
             fq.put(0)
             fq.put(1)
         errors = []
+        stop = threading.Event()
 
         def worker(t):
             try:
                 torch.cuda.set_device(local_rank)
                 for s_ in range(t, k, inflight):
                     b = free_q[t].get()
+                    if b is None or stop.is_set():
+                        return
                     rc, n = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[t][b].data_ptr(), cap, nthreads=0,
                                                      stream=streams[t].cuda_stream)
                     if rc:
@@ -145,7 +304,6 @@ def main():
         for th in threads:
             th.start()
         pending, nxt, last_n = {}, 0, 0
-        t_start = time.perf_counter()
         while nxt < k:
             s_, t, b, n = done_q.get()
             if s_ < 0:
@@ -153,19 +311,23 @@ def main():
             pending[s_] = (t, b, n)
             while nxt in pending:
                 t2, b2, n2 = pending.pop(nxt)
-                if dist_on:
-                    if args.gather_to_root:
-                        multi.gather_blobs(outs[t2][b2], n2, dst_buffer=gather_buf)
-                        torch.cuda.current_stream().synchronize()
-                    else:
+                if dist_on and gather:
+                    # posted, not waited for: the buffer goes back to its caller thread when the gather of this step is done
+                    gatherer.post(outs[t2][b2], n2, on_done=lambda q=free_q[t2], bb=b2: q.put(bb))
+                else:
+                    if dist_on:
                         multi.exchange_sizes(n2, dev, out=index_rows[nxt % len(index_rows)], sync=False)   # enqueued; the closing fence waits for it
-                free_q[t2].put(b2)
+                    free_q[t2].put(b2)
                 last_n = n2
                 nxt += 1
-                if os.environ.get("SQY_BENCH_TRACE"):
-                    print("step %d done at %.2f ms (thread %d)" % (nxt - 1, (time.perf_counter() - t_start) * 1e3, t2), file=sys.stderr)
+        if errors:
+            stop.set()
+            for fq in free_q:                    # wake every caller thread that waits for a buffer, then fail loudly
+                fq.put(None)
         for th in threads:
             th.join()
+        if dist_on and gather:
+            gatherer.drain()
         if errors:
             raise errors[0]
         return last_n
@@ -176,77 +338,121 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def timed_blocks(gather):
+        """blocks of exactly --steps steps, each fenced on both sides, max over ranks per block, until --min-seconds are timed"""
+        times, payload = [], 0
+        while sum(times) < args.min_seconds and len(times) < 200:
+            fence()
+            t0 = time.perf_counter()
+            payload = run_steps(args.steps, gather)
+            fence()
+            dt = time.perf_counter() - t0
+            if dist_on:
+                t = torch.tensor([dt], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t.item())
+            times.append(dt)
+        return times, payload
+
     run_steps(inflight)          # untimed priming: every caller thread's context allocates its HBM workspace once
-    payload = run_steps(args.warmup) if args.warmup else 0
+    if args.warmup:
+        run_steps(args.warmup)
     sqeazy_amd.profile_reset()
     sqeazy_amd.profile_enable(True)
-    fence()
-    t0 = time.perf_counter()
-    payload = run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
+    times, payload = timed_blocks(False)
     sqeazy_amd.profile_enable(False)
     prof = sqeazy_amd.profile_get()
+    nblocks = len(times)
+
+    gather_times = None
+    if gatherer is not None:
+        run_steps(max(2, inflight), True)
+        gather_times, _ = timed_blocks(True)
 
     # one call at a time (nothing else in flight), for the record: latency of the call and the kernels' undisturbed durations
     fence()
     sqeazy_amd.profile_reset()
     sqeazy_amd.profile_enable(True)
-    single_call_ms = None
-    for _ in range(3):
+    single = []
+    for _ in range(5):
         tl = time.perf_counter()
         rc, _n = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[0][0].data_ptr(), cap, nthreads=0,
                                           stream=streams[0].cuda_stream)
         torch.cuda.synchronize()
-        ms = (time.perf_counter() - tl) * 1e3
-        single_call_ms = ms if single_call_ms is None else min(single_call_ms, ms)
+        single.append((time.perf_counter() - tl) * 1e3)
     sqeazy_amd.profile_enable(False)
     prof_alone = sqeazy_amd.profile_get()
-
-    if dist_on:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    fence()
 
     if rank == 0:
-        total_in = world * nbytes * args.steps
-        hdr = sqeazy_amd.header_size(bytes(out[:4096].cpu().numpy().tobytes()))
+        dt = statistics.median(times)
+        hdr = sqeazy_amd.header_size(bytes(outs[0][0][:4096].cpu().numpy().tobytes()))
         payload_bytes = payload - hdr
-        # dominant kernel by device time
+        # dominant kernel by device time; per-launch average over every launch of the timed blocks
         dom, (dom_ms, dom_n) = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
         avg_ms = dom_ms / max(dom_n, 1)
         algo_bytes = nbytes + payload_bytes                  # 2 B/voxel read once + payload written once
         achieved = (algo_bytes / 1e9) / (avg_ms / 1e3) if avg_ms else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(dom)
-            except Exception:
-                traffic = None
+        ident = lib_identity()
+        alone_ms = prof_alone[dom][0] / max(prof_alone[dom][1], 1) if dom in prof_alone else None
+        single_ms = min(single)
+        mode = "%d calls in flight" % inflight
         line = {
             "metric": "encode GB/s (input voxels) for bitswap1->lz4 uint16 volume",
-            "value": round(total_in / dt / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(world * nbytes * args.steps / dt / 1e9, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "%dx%dx%d uint16 synthetic microscopy stack per GPU, pipeline '%s', one C-ABI call per step, %d calls in flight%s" % (
-                shape[2], shape[1], shape[0], PIPELINE, inflight, (", RCCL gather of the compressed slabs to rank 0" if args.gather_to_root else ", slab blobs stay sharded, sizes all_gathered over RCCL") if world > 1 else ""),
+            "timing": {"blocks": nblocks, "steps_per_block": args.steps, "seconds_timed": round(sum(times), 3), "reported": "median block",
+                       "ms_per_step_min": round(min(times) / args.steps * 1e3, 4), "ms_per_step_max": round(max(times) / args.steps * 1e3, 4)},
+            "config": {"workload": "%dx%dx%d uint16 synthetic microscopy stack per GPU, pipeline '%s', one C-ABI call per step, %s%s" % (
+                shape[2], shape[1], shape[0], PIPELINE, mode,
+                ", slab blobs stay sharded on their GPUs, sizes all_gathered over RCCL" if world > 1 else ""),
                 "input_bytes_per_gpu": nbytes, "payload_bytes": payload_bytes, "blob_bytes": payload, "calls_in_flight_per_gpu": inflight,
-                "single_call_latency_ms": round(single_call_ms, 4)},
+                "single_call_latency_ms": round(single_ms, 4),
+                "one_call_at_a_time": {"value": round(nbytes / (single_ms / 1e3) / 1e9, 1), "unit": "GB/s",
+                                       "roofline_frac_whole_call": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 4),
+                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": dom_n,
                          # the same kernel with the GPU to itself (one call at a time, measured right after the timed region)
-                         "alone_launch_ms": round(prof_alone[dom][0] / max(prof_alone[dom][1], 1), 4) if dom in prof_alone else None,
-                         "alone_frac": round((algo_bytes / 1e9) / (prof_alone[dom][0] / max(prof_alone[dom][1], 1) / 1e3) / HBM_PEAK_GBS, 5)
-                         if dom in prof_alone and prof_alone[dom][0] else None,
-                         "kernels_ms_per_step": {k: round(v[0] / max(args.steps, 1), 4) for k, v in prof.items()}},
+                         "alone_launch_ms": round(alone_ms, 4) if alone_ms else None,
+                         "alone_frac": round((algo_bytes / 1e9) / (alone_ms / 1e3) / HBM_PEAK_GBS, 5) if alone_ms else None,
+                         "kernels_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}},
+            "build": ident,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        tr = measured_traffic(ident["sha256"], dom)
+        if tr:
+            line["roofline"]["traffic"] = tr["bytes_per_launch"]
+            line["roofline"]["traffic_all_kernels_per_call"] = tr["per_call_all_kernels"]
+            line["roofline"]["traffic_source"] = tr["source"]
+        else:
+            line["roofline"]["traffic_source"] = "no rocprofv3 PMC pass of this build under profiles/ (tools/profile_run.sh)"
+        if gather_times:
+            gdt = statistics.median(gather_times)
+            line["with_gather"] = {"value": round(world * nbytes * args.steps / gdt / 1e9, 3), "unit": "GB/s",
+                                   "ms_per_step": round(gdt / args.steps * 1e3, 4), "blocks": len(gather_times),
+                                   "what": "the same steps with the compressed slab of every rank gathered to rank 0 over RCCL (sizes all_gather + "
+                                           "ncclSend/ncclRecv) inside the step, posted from a gather thread and overlapped with the next encodes"}
+        if world == 1 and not args.quick:
+            vol_host = vol.cpu().numpy()
+            if not args.no_cpu_baseline:
+                try:
+                    line["cpu_baseline"] = cpu_baseline(vol_host)
+                except Exception as e:   # the baseline is reported, never required
+                    line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
             try:
-                line["cpu_baseline"] = cpu_baseline()
-            except Exception as e:   # the baseline is reported, never required
-                line["cpu_baseline"] = {"value": None, "unit": "GB/s", "cores": os.cpu_count(), "kind": "port", "sample": "failed: %r" % (e,)}
+                line["host_abi"] = host_abi(vol_host, shape)
+            except Exception as e:
+                line["host_abi"] = {"value": None, "error": repr(e)}
+            del vol_host
+            del vol
+            outs.clear()
+            torch.cuda.empty_cache()
+            sqeazy_amd.lib().SQYAMD_Release_Workspace()
+            try:
+                line["config"]["secondary"] = secondary_configs(dev)
+            except Exception as e:
+                line["config"]["secondary"] = {"error": repr(e)}
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

@@ -456,10 +456,20 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     if (ws->lz4_scratch.ensure(std::max<uint64_t>(lz4_nchunks * lz4_stride, 16))) return 1;
                     if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
                     if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
+                    if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
+                    uint32_t* d_redo = static_cast<uint32_t*>(ws->plan.p);       // chunks the first pass leaves to the dense batches
                     {
                         ProfScope ps("lz4_chunks", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes));
+                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo));
+                    }
+                    SQY_HIP(hipMemcpyAsync(ws->pinned, d_redo, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    SQY_HIP(hipStreamSynchronize(stream));
+                    const uint32_t n_redo = *static_cast<uint32_t*>(ws->pinned);
+                    if (n_redo) {
+                        ProfScope ps("lz4_chunks_dense", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_chunks_dense(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
+                                                             static_cast<uint32_t*>(ws->csize.p), d_redo, n_redo, stream, lz4_frame_map, lz4_frame_bytes));
                     }
                 } else if (lz4_total) {
                     // block-linked frames: the serial layout (nthreads == 1) or chunks that span several LZ4 blocks.  The table

@@ -18,9 +18,14 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 // csize[k] = compressed bytes, 0 when the chunk has to be stored raw.
 // frame_map != nullptr: the stream is frame frame_map[f] of `in` for f = 0, 1, .. (frame_bytes each, a multiple of chunk),
 // read in place (frame_shuffle directly in front of lz4)
+// redo != nullptr (nchunks + 1 words): chunks that turn out to be streams of short sequences are not finished but listed
+// there (redo[0] = count, redo[1..] = chunk numbers); launch_lz4_chunks_dense then parses exactly those
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                             uint64_t frame_bytes = 0);
+                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr);
+hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
+                                   uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
+                                   const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0);
 // One block of a block-linked LZ4 frame (liblz4's LZ4F_blockLinked, what lz4::encode_serial produces: lz4_utils.hpp:99-173):
 // where it sits in the stream and how far liblz4's backward catch-up may move a match that starts inside the block
 // (low_in) or in the history in front of it (low_dict); stream offsets, may lie below `start - 64 KiB`.

@@ -659,16 +659,17 @@ constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positio
 // across blocks (positions are re-based by the previous block's size, entries that fall more than 64 KiB behind the new
 // block die), candidates may sit in the 64 KiB in front of the block (far fetches from global memory).
 // DENSE = false: the first pass over every chunk.  A chunk that turns out to be a stream of short sequences (32 matches
-// of less than 16 bytes in a row) is given up -- csize = LZ4_REDO -- and parsed again by the DENSE = true kernel, launched
-// right behind over the same chunks (every other wavefront exits at once), which resolves several sequences per batch.
-// Two kernels instead of one keep the lean loop of the first pass free of the dense batches' registers.
-constexpr uint32_t LZ4_REDO = 0xffffffffu;
+// of less than 16 bytes in a row) is given up -- it is appended to the redo list (redo[0] = count, redo[1..] = chunks) --
+// and parsed again by the DENSE = true kernel, which resolves several sequences per batch; the host launches that one over
+// exactly the listed chunks, and only when there are any.  Two kernels instead of one keep the lean loop of the first pass
+// free of the dense batches' registers (and the dense batches free to use a larger window).
 template <bool LINKED, bool DENSE>
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
-                       const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block SQY_DIAG_ARG)
+                       const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
+                       uint32_t* __restrict__ redo_list SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
@@ -680,8 +681,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
-    if (DENSE && csize[blockIdx.x] != LZ4_REDO) return;         // (uniform) only the chunks the first pass gave up
-    const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : blockIdx.x;
+    const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : (DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x);
     const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
     uint32_t n_prev = 0;
   for (uint32_t bi = b_first; bi < b_last; ++bi) {
@@ -1099,7 +1099,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     } else if (!LINKED) {
                         // 32 in a row: a stream of short sequences, this chunk goes to the DENSE kernel
                         shorts = ml < 12u ? shorts + 1u : 0u;
-                        if (shorts >= 32u) { redo_dense = true; break; }
+                        if (shorts >= 32u && redo_list) { redo_dense = true; break; }
                     }
                 }
                 if (finished || failed || redo_dense) break;
@@ -1382,7 +1382,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
-    if (lane == 0) csize[blk] = redo_dense ? LZ4_REDO : (failed ? 0u : op);
+    if (lane == 0) {
+        if (!DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
+        else csize[blk] = failed ? 0u : op;
+    }
     if (LINKED) __syncthreads();
   }
 #ifdef SQY_LZ4_DIAG
@@ -2639,15 +2642,27 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 #endif
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
-                             uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes)
+                             uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
+                             uint32_t* redo)
 {
     if (nchunks == 0) return hipSuccess;
     if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
+    if (redo) {
+        const hipError_t e = hipMemsetAsync(redo, 0, sizeof(uint32_t), stream);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u SQY_DIAG_NULL);
-    // second pass: the chunks the first one gave up as streams of short sequences (every other wavefront exits at once)
-    hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u SQY_DIAG_NULL);
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo SQY_DIAG_NULL);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
+                                   uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
+                                   const uint64_t* frame_map, uint64_t frame_bytes)
+{
+    if (redo_count == 0) return hipSuccess;
+    hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -2657,7 +2672,7 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
     if (nframes == 0) return hipSuccess;
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, scratch, stride, csize,
-                       (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block SQY_DIAG_NULL);
+                       (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr SQY_DIAG_NULL);
     return hipGetLastError();
 }
 

@@ -75,6 +75,66 @@ def gather_blobs(blob, nbytes, dst_buffer=None, group=None, root=0):
     return sizes, None
 
 
+class SlabGatherer:
+    """north_star's "final RCCL gather", overlapped: every rank posts its finished slab blob, a gather thread moves it to
+    rank 0 (`gather_blobs`: sizes all_gather + ncclSend / ncclRecv on RCCL) while the caller threads already encode the next
+    slabs.  Root ingress is double-buffered (`depth` buffers of `capacity_bytes`), so the container of step s stays readable
+    while step s+1 arrives.  Every rank must post in the same order (the gather thread works first in, first out); no other
+    collective may be issued while posts are outstanding -- `drain()` first."""
+
+    def __init__(self, capacity_bytes, device, group=None, root=0, depth=2):
+        import queue
+        import threading
+        import torch
+        import torch.distributed as dist
+        self.group, self.root, self.device = group, root, device
+        self.is_root = dist.get_rank(group) == root
+        self.bufs = [torch.empty(int(capacity_bytes), dtype=torch.uint8, device=device) for _ in range(depth)] if self.is_root else []
+        self.done = 0                    # gathers completed
+        self.last = None                 # (sizes, flat view into one of the ingress buffers) of the newest completed gather, on root
+        self.error = None
+        self._q = queue.Queue()
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        import torch
+        if getattr(self.device, "type", "cpu") == "cuda":
+            torch.cuda.set_device(self.device)
+        while True:
+            item = self._q.get()
+            try:
+                if item is None:
+                    return
+                blob, nbytes, on_done = item
+                if self.error is None:
+                    try:
+                        dst = self.bufs[self.done % len(self.bufs)] if self.is_root else None
+                        self.last = gather_blobs(blob, nbytes, dst_buffer=dst, group=self.group, root=self.root)
+                    except Exception as e:      # pragma: no cover
+                        self.error = e
+                self.done += 1
+                if on_done is not None:
+                    on_done()
+            finally:
+                self._q.task_done()
+
+    def post(self, blob, nbytes, on_done=None):
+        """queue `blob[:nbytes]` (must stay untouched until on_done runs) for the gather; returns at once"""
+        self._q.put((blob, int(nbytes), on_done))
+
+    def drain(self):
+        """wait until every posted gather is complete (raises what the gather thread hit)"""
+        self._q.join()
+        if self.error is not None:
+            e, self.error = self.error, None
+            raise e
+
+    def close(self):
+        self._q.put(None)
+        self._t.join()
+
+
 def pack_container(sizes, flat):
     """u64 count | u64 sizes | blobs, as bytes (host side convenience for tests / file output)"""
     head = np.array([len(sizes)] + list(sizes), dtype=np.uint64).tobytes()

@@ -18,6 +18,57 @@ def _free_port():
     return p
 
 
+def _worker_gatherer(rank, world, port, q):
+    """the overlapped gather bench.py uses at N > 1 (multi.SlabGatherer), several steps in flight, uneven z split, and the
+    pipeline whose slab geometry is part of the contract (diff3x3x1: every slab is encoded as its own volume)"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import sqy_oracle as o
+    from sqeazy_amd import multi, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        Z, Y, X = 17, 12, 16
+        pipe = "diff3x3x1->bitswap1->lz4"
+        steps = 4
+        fulls = [synth.stack((Z, Y, X), seed=100 + s) for s in range(steps)]
+        z0, nz = multi.slab_range(Z, rank, world)
+        cap = 1 << 16
+        g = multi.SlabGatherer(world * cap, torch.device("cpu"))
+        released = []
+        seen = []
+        bufs = []
+        for s in range(steps):
+            blob = o.pipeline_encode(pipe, fulls[s][z0:z0 + nz])
+            t = torch.zeros(cap, dtype=torch.uint8)
+            t[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            bufs.append(t)
+            g.post(t, len(blob), on_done=lambda s=s: released.append(s))
+            if s % 2 == 1:                                   # look at the newest container every other step, like a consumer would
+                g.drain()
+                if rank == 0:
+                    sizes, flat = g.last
+                    seen.append((s, multi.unpack_container(multi.pack_container(sizes, flat))))
+        g.drain()
+        g.close()
+        assert released == list(range(steps)) and g.done == steps
+        if rank == 0:
+            for s, blobs in seen:
+                assert len(blobs) == world
+                for r, b in enumerate(blobs):
+                    a0, an = multi.slab_range(Z, r, world)
+                    assert b == o.pipeline_encode(pipe, fulls[s][a0:a0 + an]), (s, r)      # = one reference call on that slab
+                    assert np.array_equal(o.pipeline_decode(b), fulls[s][a0:a0 + an])
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:   # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
 def _worker(rank, world, port, q):
     sys.path.insert(0, ROOT)
     import torch
@@ -84,3 +135,18 @@ def test_variable_length_gather_world2():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_gather_diff_pipeline(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gatherer, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res

@@ -18,17 +18,19 @@ int main(int argc, char** argv)
     std::fclose(f);
     const uint32_t chunk = argc > 2 ? std::atoi(argv[2]) : 262144;
     const uint64_t nch = (n + chunk - 1) / chunk;
-    uint8_t *din, *dscr; uint32_t* dcs; unsigned long long* ddg;
-    CK(hipMalloc(&din, n + 64)); CK(hipMalloc(&dscr, nch * chunk)); CK(hipMalloc(&dcs, nch * 4)); CK(hipMalloc(&ddg, nch * 32 * 8)); CK(hipMemset(ddg, 0, nch * 32 * 8));
+    uint8_t *din, *dscr; uint32_t *dcs, *dredo; unsigned long long* ddg;
+    CK(hipMalloc(&din, n + 64)); CK(hipMalloc(&dscr, nch * chunk)); CK(hipMalloc(&dcs, nch * 4)); CK(hipMalloc(&dredo, (nch + 1) * 4)); CK(hipMalloc(&ddg, nch * 32 * 8)); CK(hipMemset(ddg, 0, nch * 32 * 8));
     CK(hipMemcpy(din, h.data(), n, hipMemcpyHostToDevice));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     float best = 1e9f;
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
+        CK(hipMemset(dredo, 0, 4));
         hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, false>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
-                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, ddg);
-        hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, true>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
-                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, ddg);
+                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, ddg);
+        uint32_t nredo = 0; CK(hipMemcpy(&nredo, dredo, 4, hipMemcpyDeviceToHost));
+        if (nredo) hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, true>), dim3(nredo), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
+                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, ddg);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));

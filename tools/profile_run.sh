@@ -7,9 +7,10 @@ export TMPDIR=/tmp
 P=gpurun_out/prof
 rm -rf $P; mkdir -p $P
 B="bench.py"
-timeout -k 10 300 python3 $B > $P/bench_plain.log 2>&1 || exit 1
+timeout -k 10 500 python3 $B > $P/bench_plain.log 2>&1 || exit 1
 tail -1 $P/bench_plain.log | cut -c1-400
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 $B --no-cpu-baseline > $P/bench_trace.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -- python3 $B --no-cpu-baseline > $P/bench_fetch.log 2>&1 || exit 1
-timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -- python3 $B --no-cpu-baseline > $P/bench_write.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $P/trace -- python3 $B --quick > $P/bench_trace.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $P/pmc_fetch -- python3 $B --quick > $P/bench_fetch.log 2>&1 || exit 1
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $P/pmc_write -- python3 $B --quick > $P/bench_write.log 2>&1 || exit 1
+sha256sum sqeazy_amd/lib/libsqeazy_amd.so | cut -d" " -f1 > $P/library_sha256.txt
 echo profile passes done

@@ -21,7 +21,7 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-SHORT = {"sqy::lz4_chunks_kernel": "lz4_chunks", "sqy::bitswap1_u16_tiles": "bitswap1_u16", "sqy::bitswap1_u16_regs": "bitswap1_u16",
+SHORT = {"sqy::lz4_chunks_kernel": "lz4_chunks", "void sqy::lz4_chunks_kernel<false, false>": "lz4_chunks", "void sqy::lz4_chunks_kernel<false, true>": "lz4_chunks_dense", "sqy::bitswap1_u16_tiles": "bitswap1_u16", "sqy::bitswap1_u16_regs": "bitswap1_u16",
          "sqy::lz4_frame_gather_kernel": "lz4_frame_gather", "sqy::lz4_frame_scan_kernel": "lz4_frame_scan",
          "sqy::bitswap1_u16_generic": "bitswap1_u16_generic"}
 
@@ -37,7 +37,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         if r["Name"].startswith("sqy::"):
             rows.append(r)
 with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline  (defaults: 30 steps, 5 warm-up, 2 calls in flight)   (sqy:: kernels only)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick  (defaults: 30 steps, 5 warm-up, 2 calls in flight)   (sqy:: kernels only)\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
@@ -61,7 +61,12 @@ with open(os.path.join(dst, "%s_pmc_hbm.csv" % tag), "w") as f:
         hbm = int((2 * fe + wr) * 1024)
         traffic[k] = hbm
         w.writerow([k, len(c["FETCH_SIZE"]), "%.1f" % fe, "%.1f" % wr, hbm])
-json.dump(traffic, open(os.path.join(dst, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
+sha_file = os.path.join(src, "library_sha256.txt")
+sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
+# bench.py reports `roofline.traffic` from this file only when it was collected on the very library build it is running
+json.dump({"library_sha256": sha, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --quick",
+           "hbm_bytes": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch, mean over launches", "traffic": traffic},
+          open(os.path.join(dst, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
 for n in ("bench_plain.log", "bench_trace.log"):
     p = os.path.join(src, n)
     if os.path.exists(p):
