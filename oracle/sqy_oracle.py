@@ -76,6 +76,27 @@ def bitswap1_encode(a):
     return out.reshape(a.shape)
 
 
+def setbits(destination, source, at, numbits, bits=16):
+    """detail::setbits_of_integertype<T> (encoders/scalar_utils.hpp:75-80): `numbits` bits of `destination` from bit `at` on are
+    replaced by the low bits of `source`; everything is truncated to the integer type (`bits` wide)"""
+    m = (1 << bits) - 1
+    ones = (((1 << numbits) - 1) << at) & m
+    return ((ones | destination) ^ ((((~source) & m) << at) & ones)) & m
+
+
+def remove_blanks(payload, n_bytes, stride):
+    """lz4::remove_blanks (encoders/lz4_utils.hpp:175-190): chunk k was written at payload[k * stride, +n_bytes[k]); the
+    chunks are moved together in place.  returns the number of bytes that are valid afterwards"""
+    value = int(n_bytes[0])
+    src = stride
+    for n in n_bytes[1:]:
+        n = int(n)
+        payload[value:value + n] = payload[src:src + n].copy()
+        value += n
+        src += stride
+    return value
+
+
 def bitswap1_encode_planes(a, nthreads=1):
     flat = _c(a, np.uint16).reshape(-1)
     out = np.empty_like(flat)

@@ -102,3 +102,28 @@ def test_config1_256cubed_u16_host_abi(sqy, oracle):
     assert blob1 == oracle.pipeline_encode("bitswap1->lz4", vol, nthreads=1)
     rc, back = sqy.decode(blob1)
     assert rc == 0 and np.array_equal(back, vol)
+
+
+@pytest.mark.parametrize("pipeline", ["diff3x3x1->bitswap1->lz4", "quantiser->bitswap1->lz4"])
+def test_every_slab_of_the_sharded_volumes(sqy, oracle, pipeline):
+    """configs[2] / configs[4] are encoded as z-slabs of 256 frames, one per rank: EVERY slab index (not only slab 0) against
+    the oracle, at the full z geometry (2048 frames, 8 slabs; the shell sweeps through them) and a reduced 256 x 256 plane"""
+    import torch
+    dev = torch.device("cuda", 0)
+    Y = X = 256
+    for slab in range(8):
+        vol = synth.stack_torch((256, Y, X), np.uint16, dev, z_offset=256 * slab, z_total=2048)
+        cap = sqy.max_compressed_length(pipeline, (256, Y, X), np.uint16)
+        out = torch.empty(cap, dtype=torch.uint8, device=dev)
+        rc, n = sqy.encode_device(pipeline, vol.data_ptr(), (256, Y, X), np.uint16, out.data_ptr(), cap, nthreads=0)
+        assert rc == 0, slab
+        host = vol.cpu().numpy()
+        assert np.array_equal(host, synth.stack((2048, Y, X))[256 * slab:256 * (slab + 1)]) if slab == 3 else True
+        blob = out[:n].cpu().numpy().tobytes()
+        assert blob == oracle.pipeline_encode(pipeline, host), "slab %d differs from the oracle" % slab
+        rc, back = sqy.decode(blob)
+        assert rc == 0
+        if pipeline.startswith("diff"):
+            assert np.array_equal(back, host), slab
+        else:
+            assert np.array_equal(back, oracle.pipeline_decode(blob)), slab
