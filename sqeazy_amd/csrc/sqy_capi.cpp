@@ -104,12 +104,12 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan;
+    DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan, dedupe;
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
     void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
-        io_src.release(); io_dst.release(); small.release(); plan.release();
+        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release();
     }
 };
 
@@ -307,6 +307,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     uint64_t lz4_total = 0, lz4_nchunks = 0, lz4_chunk = 0, lz4_stride = 0;
     const uint64_t* lz4_frame_map = nullptr;     // frame_shuffle directly in front of lz4: frames are read through the map
     uint64_t lz4_frame_bytes = 0;
+    const uint32_t* lz4_piece_hash = nullptr;    // left by a 16-bit bitswap1 directly in front of lz4: hashes of the 1 KiB pieces of the plane stream
+    const uint32_t* lz4_dup_of = nullptr;        // chunks that are byte-identical to an earlier chunk share its frame
     const sqy::Lz4Block* lz4_blocks = nullptr;   // block-linked frames (nthreads == 1, or chunks of several LZ4 blocks): the block list in HBM
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
@@ -316,9 +318,24 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
             case StageKind::bitswap1: {
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
+                // lz4 right behind: leave piece hashes for its duplicate-chunk detection (bit planes of small values repeat)
+                uint32_t* ph = nullptr;
+                if (cur_elem == 2 && si + 1 < pipe.stages.size() && pipe.stages[si + 1].kind == StageKind::lz4) {
+                    const uint64_t words = sqy::bitswap1_piece_hash_words(cur, out, cur_len);
+                    const uint64_t total = cur_len * 2;
+                    const uint64_t chunk = pipe.stages[si + 1].lz4.bytes_per_chunk(total);
+                    const bool chunked = chunk <= pipe.stages[si + 1].lz4.block_bytes() && !(pipe.nthreads == 1 && total > chunk);
+                    if (words && chunked && chunk % 1024 == 0 && total > chunk) {
+                        const uint64_t nch = (total + chunk - 1) / chunk;
+                        const uint64_t ph_bytes = (words * 4 + 63) & ~(uint64_t)63;
+                        if (ws->dedupe.ensure(ph_bytes + sqy::lz4_dedupe_work_bytes(nch) + nch * 4)) return 1;
+                        ph = static_cast<uint32_t*>(ws->dedupe.p);
+                        lz4_piece_hash = ph;
+                    }
+                }
                 ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
                 if (cur_elem == 2)
-                    SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream));
+                    SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream, ph));
                 else
                     SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
                 cur = out;
@@ -456,12 +473,21 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     if (ws->lz4_scratch.ensure(std::max<uint64_t>(lz4_nchunks * lz4_stride, 16))) return 1;
                     if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
                     if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
+                    if (lz4_piece_hash && si > 0 && pipe.stages[si - 1].kind == StageKind::bitswap1) {
+                        const uint64_t words = sqy::bitswap1_piece_hash_words(cur, cur, cur_len);     // (same count as when they were made)
+                        const uint64_t ph_bytes = (words * 4 + 63) & ~(uint64_t)63;
+                        uint8_t* base = static_cast<uint8_t*>(ws->dedupe.p) + ph_bytes;
+                        uint32_t* d_dup = reinterpret_cast<uint32_t*>(base + sqy::lz4_dedupe_work_bytes(lz4_nchunks));
+                        ProfScope ps("lz4_dedupe", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream));
+                        lz4_dup_of = d_dup;
+                    }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
                     uint32_t* d_redo = static_cast<uint32_t*>(ws->plan.p);       // chunks the first pass leaves to the dense batches
                     {
                         ProfScope ps("lz4_chunks", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo));
+                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo, lz4_dup_of));
                     }
                     SQY_HIP(hipMemcpyAsync(ws->pinned, d_redo, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     SQY_HIP(hipStreamSynchronize(stream));
@@ -503,7 +529,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 {
                     ProfScope ps("lz4_frame_scan", stream, pend);
                     SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
-                                                       static_cast<uint64_t*>(ws->frame_off.p), stream, lz4_blocks));
+                                                       static_cast<uint64_t*>(ws->frame_off.p), stream, lz4_blocks, lz4_dup_of));
                 }
                 payload_is_lz4 = true;
                 break;
@@ -554,7 +580,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
             ProfScope ps("lz4_frame_gather", stream, pend);
             SQY_HIP(sqy::launch_lz4_frame_gather(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                  static_cast<uint32_t*>(ws->csize.p), static_cast<uint64_t*>(ws->frame_off.p),
-                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, lz4_blocks));
+                                                 out + hdr.size(), fd[1], hc, lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, lz4_blocks, lz4_dup_of));
         }
     } else {
         ProfScope ps("payload_copy", stream, pend);

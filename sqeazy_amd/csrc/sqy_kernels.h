@@ -8,7 +8,15 @@
 namespace sqy {
 
 // bitswap1: bit-plane transpose of `len` elements (encoders/bitswap_scheme_impl.hpp:97-145)
-hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream);
+// piece_hash != nullptr (bitswap1_piece_hash_words(..) words, only offered when that is non-zero): a hash of every 1 KiB piece of
+// plane data is left there for launch_lz4_dedupe
+hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash = nullptr);
+uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len);
+// duplicate chunks of a plane stream (chunk a multiple of 1 KiB): dup_of[k] = the earliest chunk with the same bytes (k itself when
+// there is none); the hashes only nominate, a byte compare decides.  work: lz4_dedupe_work_bytes(nchunks) bytes
+uint64_t lz4_dedupe_work_bytes(uint64_t nchunks);
+hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
+                             uint32_t* dup_of, hipStream_t stream);
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
 
 // diff3x3x1 on a {Z,Y,X} volume of 1- or 2-byte unsigned voxels (encoders/diff_scheme_impl.hpp:78-139)
@@ -22,7 +30,7 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 // there (redo[0] = count, redo[1..] = chunk numbers); launch_lz4_chunks_dense then parses exactly those
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr);
+                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr);
 hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                                    uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
                                    const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0);
@@ -43,12 +51,13 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
 // (blocks != nullptr: offset of what block k contributes -- frame header if it opens a frame, size field, body, end mark
 // if it closes one)
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks = nullptr);
+                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks = nullptr,
+                                 const uint32_t* dup_of = nullptr);
 // writes [04 22 4D 18 | 40 | BD | HC][u32 size][data][00 00 00 00] per chunk at out + frame_off[k]
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
                                    uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                                   uint64_t frame_bytes = 0, const Lz4Block* blocks = nullptr);
+                                   uint64_t frame_bytes = 0, const Lz4Block* blocks = nullptr, const uint32_t* dup_of = nullptr);
 
 // quantiser: 65536-bin histogram of u16 voxels (histo is zeroed by the launcher), and out[i] = lut[in[i]]
 hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);

@@ -94,9 +94,6 @@ __device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__built
 // Output word of plane b (segment 15-b) for voxels 16w..16w+15 carries voxel 16w+j at bit 15-j.
 // ------------------------------------------------------------------------------------------------
 constexpr int BSW_TILE_VOX = 8192;
-constexpr int BSW_ROW_PITCH = 272;                // 256 B of payload + 16 B pad
-constexpr int BSW_LDS_PER_WAVE = 64 * BSW_ROW_PITCH;
-constexpr int BSW_WAVES = 4;
 
 // rows r[i] = (voxel i of group A) | (voxel i of group B) << 16, i = 0..15, voxel order REVERSED by the
 // caller (r[i] holds voxel 15-i) so that a plain transpose yields msb-first plane words.
@@ -136,74 +133,15 @@ __device__ __forceinline__ void transpose16x16_pairs(uint32_t r[16])
     }
 }
 
-__global__ __launch_bounds__(64 * BSW_WAVES)
-void bitswap1_u16_tiles(const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                        uint64_t n_tiles, uint64_t seg_words /* S */)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
-    const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
-    uint8_t* lds = lds_raw + wave * BSW_LDS_PER_WAVE;
-
-    const uint64_t wave_global = (uint64_t)blockIdx.x * BSW_WAVES + wave;
-    const uint64_t wave_stride = (uint64_t)gridDim.x * BSW_WAVES;
-
-    for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
-        const v4u* src = reinterpret_cast<const v4u*>(in + tile * BSW_TILE_VOX);
-        v4u v[16];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v[j] = __builtin_nontemporal_load(src + j * 64 + lane);
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int row = j * 4 + (lane >> 4);
-            *reinterpret_cast<v4u*>(lds + row * BSW_ROW_PITCH + (lane & 15) * 16) = v[j];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-        // plane words for this lane: pl[b][q], q = 0..3 -> (group 2q | group 2q+1 << 16)
-        uint32_t pl[16][4];
-        const uint8_t* rowp = lds + lane * BSW_ROW_PITCH;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            // groups 2q (voxels 32q..32q+15) and 2q+1 (voxels 32q+16..32q+31) of this lane's row
-            const uint4 a0 = *reinterpret_cast<const uint4*>(rowp + q * 64);
-            const uint4 a1 = *reinterpret_cast<const uint4*>(rowp + q * 64 + 16);
-            const uint4 b0 = *reinterpret_cast<const uint4*>(rowp + q * 64 + 32);
-            const uint4 b1 = *reinterpret_cast<const uint4*>(rowp + q * 64 + 48);
-            const uint32_t ga[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}; // voxel pairs of group A
-            const uint32_t gb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
-            uint32_t r[16];
-#pragma unroll
-            for (int k = 0; k < 8; ++k) {
-                // voxel 2k -> row 15-2k, voxel 2k+1 -> row 14-2k
-                r[15 - 2 * k] = __builtin_amdgcn_perm(gb[k], ga[k], 0x05040100u); // lo16(A) | lo16(B) << 16
-                r[14 - 2 * k] = __builtin_amdgcn_perm(gb[k], ga[k], 0x07060302u); // hi16(A) | hi16(B) << 16
-            }
-            transpose16x16_pairs(r);
-#pragma unroll
-            for (int b = 0; b < 16; ++b) pl[b][q] = r[b];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-
-        // plane b lives in segment 15-b; this tile contributes 512 words (1 KiB) per segment
-#pragma unroll
-        for (int b = 0; b < 16; ++b) {
-            v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
-            const v4u val = {pl[b][0], pl[b][1], pl[b][2], pl[b][3]};
-            __builtin_nontemporal_store(val, dst + lane);
-        }
-    }
-}
-
-// Same tile, no LDS: every lane loads its own 256 contiguous bytes (16 x 16 B at a lane stride of 256 B; the eight
-// loads that share a 128-byte line are issued back to back, so the line is fetched once and hit in L1 after that).
-// Needs no LDS allocation at all, which matters when the CUs' LDS is held by resident LZ4 chunk waves of other calls
-// in flight: this kernel then still finds room (wave slots and registers only).
+// No LDS: every lane loads its own 256 contiguous bytes (16 x 16 B at a lane stride of 256 B; the eight loads that share
+// a 128-byte line are issued back to back, so the line is fetched once and hit in L1 after that).  Needs no LDS allocation
+// at all, which matters when the CUs' LDS is held by resident LZ4 chunk waves of other calls in flight: this kernel then
+// still finds room (wave slots and registers only).
+// piece_hash != nullptr: a 32-bit hash of every 1 KiB piece of plane data the wave writes goes to piece_hash (four partial
+// sums per piece, one per 16-lane row) -- what the LZ4 stage's duplicate-chunk detection is built on (lz4_dedupe_*).
 __global__ __launch_bounds__(256)
-void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words)
+void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words,
+                       uint32_t* __restrict__ piece_hash)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -235,7 +173,114 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
             const v4u val = {pl[b][0], pl[b][1], pl[b][2], pl[b][3]};
             __builtin_nontemporal_store(val, dst + lane);
         }
+        if (piece_hash) {
+            const uint32_t pm = 2u * (uint32_t)lane + 1u;                // position inside the piece
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                uint32_t a = pl[b][0] * 0x9E3779B1u + pl[b][1] * 0x85EBCA77u + pl[b][2] * 0xC2B2AE3Du + pl[b][3] * 0x27D4EB2Fu;
+                a = (a ^ (a >> 15)) * pm;
+                // EXACT zero marker: a row of 16 lanes stores 0 if and only if all its 256 bytes are zero (its hash terms are
+                // all 0 then; a row with any non-zero word gets bit 0 forced on) -- all-zero chunks need no byte compare
+                const uint64_t nzm = ballot((pl[b][0] | pl[b][1] | pl[b][2] | pl[b][3]) != 0u);
+                const bool row_nz = ((nzm >> (lane & 48)) & 0xffffull) != 0ull;
+                a += __builtin_amdgcn_update_dpp(0u, a, 0x111, 0xf, 0xf, false);      // row_shr:1  (sum over the 16-lane row ends in its last lane)
+                a += __builtin_amdgcn_update_dpp(0u, a, 0x112, 0xf, 0xf, false);
+                a += __builtin_amdgcn_update_dpp(0u, a, 0x114, 0xf, 0xf, false);
+                a += __builtin_amdgcn_update_dpp(0u, a, 0x118, 0xf, 0xf, false);
+                // piece = 1 KiB of segment 15-b: (byte offset of the piece in the plane stream) / 1024
+                const uint64_t piece = ((uint64_t)(15 - b) * seg_words * 2u + tile * 1024u) >> 10;
+                if ((lane & 15) == 15) piece_hash[piece * 4u + (uint32_t)(lane >> 4)] = row_nz ? (a | 1u) : 0u;
+            }
+        }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Duplicate chunks in front of LZ4.  Bit planes of small-magnitude data repeat: the planes above the largest value are all
+// zero, the sign-extension planes of a residual (diff3x3x1) are copies of each other -- whole 256 KiB chunks of the plane
+// stream are byte-identical, and identical chunks compress to identical frames (every chunk starts from a fresh table).
+// key kernel: chunk key from the piece hashes the bit-plane transpose left behind, inserted into an open-addressing table
+// that keeps the SMALLEST chunk number per key.  verify kernel: a chunk whose key belongs to an earlier chunk is compared
+// with it byte for byte; only then is it marked dup_of[k] = that chunk.  The LZ4 kernel skips marked chunks, scan and gather
+// take size and bytes from the chunk they duplicate.  Exact by construction: the hash only nominates, the compare decides.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64)
+void lz4_dedupe_key_kernel(const uint32_t* __restrict__ piece_hash, uint32_t pieces_per_chunk, uint64_t nchunks_full,
+                           uint64_t* __restrict__ chunk_key, uint64_t* __restrict__ tab_key, uint32_t* __restrict__ tab_val, uint32_t tab_mask)
+{
+    const uint64_t k = blockIdx.x;
+    const int lane = threadIdx.x;
+    const uint32_t* ph = piece_hash + k * pieces_per_chunk * 4u;
+    uint32_t h1 = 0, h2 = 0, any = 0;
+    for (uint32_t i = lane; i < pieces_per_chunk; i += 64) {
+        const uint4 q = *reinterpret_cast<const uint4*>(ph + i * 4u);
+        any |= q.x | q.y | q.z | q.w;
+        const uint32_t s_ = q.x + q.y + q.z + q.w;
+        h1 += s_ * ((2u * i + 1u) * 0x9E3779B1u);
+        h2 += ((s_ << 13) | (s_ >> 19)) * ((2u * i + 3u) * 0x85EBCA77u);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { h1 += __shfl_xor(h1, d); h2 += __shfl_xor(h2, d); }
+    const bool some = ballot(any != 0u) != 0ull;
+    if (lane == 0) {
+        // key 1 = "every byte of the chunk is zero" (exact, see the piece hashes); other keys have bit 1 set; 0 = empty slot
+        const uint64_t key = some ? ((((uint64_t)h2 << 32) | h1) | 3ull) : 1ull;
+        chunk_key[k] = key;
+        uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & tab_mask;
+        for (uint32_t tries = 0; tries <= tab_mask; ++tries, slot = (slot + 1u) & tab_mask) {
+            const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&tab_key[slot]), 0ull, (unsigned long long)key);
+            if (prev == 0ull || prev == key) { atomicMin(&tab_val[slot], (uint32_t)k); break; }
+        }
+    }
+}
+
+constexpr uint32_t DEDUPE_THREADS = 256;
+__global__ __launch_bounds__(DEDUPE_THREADS)
+void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, uint64_t nchunks_full, uint64_t nchunks,
+                              const uint64_t* __restrict__ chunk_key, const uint64_t* __restrict__ tab_key,
+                              const uint32_t* __restrict__ tab_val, uint32_t tab_mask, uint32_t* __restrict__ dup_of)
+{
+    const uint64_t k = blockIdx.x;
+    __shared__ uint32_t s_rep;
+    __shared__ uint32_t s_diff;
+    if (threadIdx.x == 0) {
+        uint32_t r = (uint32_t)k;
+        if (k < nchunks_full) {
+            const uint64_t key = chunk_key[k];
+            uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & tab_mask;
+            for (uint32_t tries = 0; tries <= tab_mask; ++tries, slot = (slot + 1u) & tab_mask) {
+                const uint64_t tk = tab_key[slot];
+                if (tk == key) { r = tab_val[slot]; break; }
+                if (tk == 0) break;
+            }
+        }
+        s_rep = r;
+        s_diff = 0;
+    }
+    __syncthreads();
+    const uint32_t r = s_rep;
+    if (r >= k) { if (threadIdx.x == 0) dup_of[k] = (uint32_t)k; return; }     // (uniform) first of its kind
+    if (chunk_key[k] == 1ull) { if (threadIdx.x == 0) dup_of[k] = r; return; } // all zero, exactly: equal to the first all-zero chunk
+    // compare chunk k with chunk r (chunk is a multiple of 1 KiB here; plane streams are 16-byte aligned)
+    const uint4* a = reinterpret_cast<const uint4*>(in + k * chunk);
+    const uint4* b = reinterpret_cast<const uint4*>(in + (uint64_t)r * chunk);
+    const uint32_t nvec = chunk >> 4;
+    uint32_t diff = 0;
+    for (uint32_t i = threadIdx.x; i < nvec; i += DEDUPE_THREADS * 4u) {
+        // four independent 16-byte pairs in flight per thread
+        uint4 x[4], y[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t j = i + u * DEDUPE_THREADS;
+            x[u] = j < nvec ? a[j] : make_uint4(0, 0, 0, 0);
+            y[u] = j < nvec ? b[j] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) diff |= (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y) | (x[u].z ^ y[u].z) | (x[u].w ^ y[u].w);
+    }
+    if (diff) atomicOr(&s_diff, 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) dup_of[k] = s_diff ? (uint32_t)k : r;
 }
 
 // generic (any length / alignment) path: one thread per output word, used for the part of the buffer
@@ -669,7 +714,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
-                       uint32_t* __restrict__ redo_list SQY_DIAG_ARG)
+                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
@@ -681,6 +726,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
+    if (!LINKED && !DENSE && dup_of && dup_of[blockIdx.x] != blockIdx.x) return;     // byte-identical to an earlier chunk (lz4_dedupe_*): its frame is that chunk's
     const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : (DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x);
     const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
     uint32_t n_prev = 0;
@@ -1400,7 +1446,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 // field and body, plus the 7-byte frame header when it opens a frame and the 4-byte end mark when it closes one.
 __global__ __launch_bounds__(1024)
 void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                           uint64_t* __restrict__ frame_off /* nchunks + 1 */, const Lz4Block* __restrict__ blocks)
+                           uint64_t* __restrict__ frame_off /* nchunks + 1 */, const Lz4Block* __restrict__ blocks,
+                           const uint32_t* __restrict__ dup_of)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
@@ -1411,7 +1458,7 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
         const uint64_t k = base + tid;
         uint64_t sz = 0;
         if (k < nchunks) {
-            const uint32_t c = csize[k];
+            const uint32_t c = csize[dup_of ? dup_of[k] : k];
             if (blocks) {
                 const Lz4Block bd = blocks[k];
                 sz = ((bd.flags & 1u) ? 7 : 0) + 4 + (c ? c : bd.n) + ((bd.flags & 2u) ? 4 : 0);
@@ -1449,7 +1496,8 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
                              const uint8_t* __restrict__ scratch, uint64_t stride,
                              const uint32_t* __restrict__ csize, const uint64_t* __restrict__ frame_off,
                              uint8_t* __restrict__ out, uint32_t bd_byte, uint32_t hc_byte, uint32_t slices_per_chunk,
-                             const uint64_t* __restrict__ fmap, uint64_t fbytes, const Lz4Block* __restrict__ blocks)
+                             const uint64_t* __restrict__ fmap, uint64_t fbytes, const Lz4Block* __restrict__ blocks,
+                             const uint32_t* __restrict__ dup_of)
 {
     const uint64_t k = blockIdx.x / slices_per_chunk;
     const uint32_t slice = blockIdx.x % slices_per_chunk;
@@ -1461,9 +1509,10 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
         nk = (uint32_t)(left < chunk ? left : chunk);
         lin = k * chunk;
     }
-    const uint32_t c = csize[k];
+    const uint64_t ks = dup_of ? dup_of[k] : k;                      // the chunk whose compressed bytes this one shares
+    const uint32_t c = csize[ks];
     const uint32_t body = c ? c : nk;
-    const uint8_t* __restrict__ s = c ? scratch + k * stride : (fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin);
+    const uint8_t* __restrict__ s = c ? scratch + ks * stride : (fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin);
     uint8_t* __restrict__ d = out + frame_off[k];
     const int tid = threadIdx.x;
     const uint32_t hdr = (flags & 1u) ? 7u : 0u;                     // frame header in front of the block's size field
@@ -2563,7 +2612,7 @@ static inline int num_cus()
     return cus;
 }
 
-hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream)
+hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash)
 {
     if (len == 0) return hipSuccess;
     const uint64_t seg_words = len / 16;
@@ -2571,21 +2620,15 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
     const bool aligned = (seg_words % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
                          ((reinterpret_cast<uintptr_t>(out) & 15) == 0);
     if (aligned) n_tiles = (seg_words * 16) / BSW_TILE_VOX;
-    // default: the register-tile kernel, 16 blocks per CU.  It needs no LDS, so it runs next to the LZ4 chunk waves of
-    // other calls in flight (those hold nearly all of a CU's LDS); alone it is as fast as the LDS-tile kernel.
-    // SQY_BSW_MODE (tools/bsw_modes.sh): 0 = LDS tiles, n >= 2 = register tiles with n blocks per CU
-    static const int bsw_mode = std::getenv("SQY_BSW_MODE") ? std::atoi(std::getenv("SQY_BSW_MODE")) : 16;
-    if (n_tiles && bsw_mode >= 1) {
+    // piece hashes only when the tile kernel covers the whole buffer (see bitswap1_piece_hash_words)
+    if (piece_hash && n_tiles * BSW_TILE_VOX != len) return hipErrorInvalidValue;
+    // the register-tile kernel, 16 blocks per CU.  It needs no LDS, so it runs next to the LZ4 chunk waves of other calls
+    // in flight (those hold nearly all of a CU's LDS)
+    if (n_tiles) {
         const uint64_t want = (n_tiles + 3) / 4;
-        const uint64_t cap = (uint64_t)num_cus() * (uint64_t)(bsw_mode >= 2 ? bsw_mode : 8);
+        const uint64_t cap = (uint64_t)num_cus() * 16;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
-        hipLaunchKernelGGL(bitswap1_u16_regs, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words);
-    } else if (n_tiles) {
-        const uint64_t want = (n_tiles + BSW_WAVES - 1) / BSW_WAVES;
-        const uint64_t cap = (uint64_t)num_cus() * 2 * 4;   // 2 workgroups resident per CU (LDS), a few rounds each
-        const unsigned grid = (unsigned)(want < cap ? want : cap);
-        hipLaunchKernelGGL(bitswap1_u16_tiles, dim3(grid), dim3(64 * BSW_WAVES), BSW_WAVES * BSW_LDS_PER_WAVE, stream,
-                           in, out, n_tiles, seg_words);
+        hipLaunchKernelGGL(bitswap1_u16_regs, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words, piece_hash);
     }
     const uint64_t first_word = n_tiles * (BSW_TILE_VOX / 16);
     const uint64_t rest_words = seg_words - first_word;
@@ -2596,6 +2639,44 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         hipLaunchKernelGGL(bitswap1_u16_generic, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, len, first_word, seg_words);
     }
     return hipGetLastError();
+}
+
+uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len)
+{
+    // one 1 KiB piece per plane and tile, four words each; 0 when the tile kernel does not cover the buffer exactly
+    if (len == 0 || len % BSW_TILE_VOX != 0) return 0;
+    if ((reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(out) & 15)) return 0;
+    return (len / BSW_TILE_VOX) * 16 * 4;
+}
+
+hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
+                             uint32_t* dup_of, hipStream_t stream)
+{
+    const uint64_t nchunks = (total + chunk - 1) / chunk, nfull = total / chunk;
+    if (nchunks == 0) return hipSuccess;
+    if (chunk % 1024 != 0 || (reinterpret_cast<uintptr_t>(in) & 15)) return hipErrorInvalidValue;
+    uint32_t tab = 64;
+    while (tab < 2 * nchunks) tab <<= 1;
+    uint64_t* chunk_key = static_cast<uint64_t*>(work);
+    uint64_t* tab_key = chunk_key + nchunks;
+    uint32_t* tab_val = reinterpret_cast<uint32_t*>(tab_key + tab);
+    hipError_t e = hipMemsetAsync(tab_key, 0, (size_t)tab * 8, stream);
+    if (e != hipSuccess) return e;
+    e = hipMemsetAsync(tab_val, 0xff, (size_t)tab * 4, stream);
+    if (e != hipSuccess) return e;
+    if (nfull)
+        hipLaunchKernelGGL(lz4_dedupe_key_kernel, dim3((unsigned)nfull), dim3(64), 0, stream, piece_hash, chunk / 1024u, nfull, chunk_key, tab_key,
+                           tab_val, tab - 1u);
+    hipLaunchKernelGGL(lz4_dedupe_verify_kernel, dim3((unsigned)nchunks), dim3(DEDUPE_THREADS), 0, stream, in, chunk, nfull, nchunks, chunk_key,
+                       tab_key, tab_val, tab - 1u, dup_of);
+    return hipGetLastError();
+}
+
+uint64_t lz4_dedupe_work_bytes(uint64_t nchunks)
+{
+    uint64_t tab = 64;
+    while (tab < 2 * nchunks) tab <<= 1;
+    return nchunks * 8 + tab * 8 + tab * 4 + 64;
 }
 
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream)
@@ -2643,7 +2724,7 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                             uint32_t* redo)
+                             uint32_t* redo, const uint32_t* dup_of)
 {
     if (nchunks == 0) return hipSuccess;
     if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
@@ -2652,7 +2733,7 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo SQY_DIAG_NULL);
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -2662,7 +2743,7 @@ hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t c
 {
     if (redo_count == 0) return hipSuccess;
     hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo SQY_DIAG_NULL);
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -2672,26 +2753,26 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
     if (nframes == 0) return hipSuccess;
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
     hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, scratch, stride, csize,
-                       (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr SQY_DIAG_NULL);
+                       (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks)
+                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks, const uint32_t* dup_of)
 {
-    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks);
+    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
                                    uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                                   const Lz4Block* blocks)
+                                   const Lz4Block* blocks, const uint32_t* dup_of)
 {
     if (nchunks == 0) return hipSuccess;
     const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;      // (chunk = largest block of the list when `blocks`)
     hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(nchunks * slices)), dim3(256), 0, stream, in, total, chunk,
-                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes, blocks);
+                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes, blocks, dup_of);
     return hipGetLastError();
 }
 
