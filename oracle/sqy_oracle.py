@@ -336,6 +336,136 @@ def raster_reorder(a, tile_size=None, decode=False):
     return out
 
 
+def _tiles_full(a, ts):
+    """(ntiles, ts^3) view-copy of a volume whose extents are multiples of ts: tiles in (z,y,x) tile order, row-major inside"""
+    Z, Y, X = a.shape
+    return a.reshape(Z // ts, ts, Y // ts, ts, X // ts, ts).transpose(0, 2, 4, 1, 3, 5).reshape(-1, ts ** 3)
+
+
+def _untile_full(tiles, shape, ts):
+    Z, Y, X = shape
+    return tiles.reshape(Z // ts, Y // ts, X // ts, ts, ts, ts).transpose(0, 3, 1, 4, 2, 5).reshape(shape)
+
+
+def _tiled_offsets(shape, ts):
+    """output offset of every voxel for 'tiles of ts^3 (smaller at the high ends) appended in (z,y,x) tile order, row-major
+    inside each tile' -- the layout of zcurve_reorder (and of raster_reorder where that one is defined)"""
+    Z, Y, X = shape
+    z, y, x = np.indices(shape, dtype=np.int64)
+    tz, ty, tx = z // ts, y // ts, x // ts
+    ez = np.minimum(ts, Z - tz * ts)
+    ey = np.minimum(ts, Y - ty * ts)
+    ex = np.minimum(ts, X - tx * ts)
+    tile_off = tz * ts * Y * X + ez * (ty * ts * X + ey * tx * ts)
+    return tile_off + (z % ts) * ey * ex + (y % ts) * ex + (x % ts)
+
+
+def zcurve_tile_ok(shape, ts):
+    """geometries for which detail::zcurve is defined.  The 'Morton' code it applies inside a tile is
+    morton_at_ct<log2(tile)>::from (zcurve_reorder_utils.hpp:30-67, morton.hpp:103-123): bit groups of log2(tile) bits are
+    interleaved, and coordinates inside a tile have only ONE such group -- the in-tile order is plain row-major.  Tile sizes
+    that are not 2..128 powers of two fall back to 1-bit Morton codes that run past the tile: undefined.  Shapes without
+    remainder against their common power of two take encode_full, which needs tile_size to divide every extent."""
+    if ts not in (2, 4, 8, 16, 32, 64, 128) or len(shape) != 3:
+        return False
+    common = 1 << min(int(d).bit_length() - 1 for d in shape)
+    if all(d % common == 0 for d in shape) and any(d % ts for d in shape):
+        return False
+    return True
+
+
+def zcurve_reorder(a, tile_size=2, decode=False):
+    """zcurve_reorder_scheme (encoders/zcurve_reorder_scheme_impl.hpp:36-117, zcurve_reorder_utils.hpp:79-475)"""
+    a = np.ascontiguousarray(a)
+    ts = int(tile_size)
+    if not zcurve_tile_ok(a.shape, ts):
+        raise ValueError("zcurve_reorder: geometry the reference leaves undefined (shape %r, tile %d)" % (a.shape, ts))
+    off = _tiled_offsets(a.shape, ts).reshape(-1)
+    flat = a.reshape(-1)
+    out = np.empty_like(flat)
+    if decode:
+        out[:] = flat[off]
+    else:
+        out[off] = flat
+    return out.reshape(a.shape)
+
+
+def tile_shuffle_encode(a, tile_size=32):
+    """detail::tile_shuffle::encode_full (encoders/tile_shuffle_utils.hpp:104-224): tiles of tile^3 voxels, the metric of a
+    tile is its SEQUENTIAL binary32 sum divided by the voxel count and CONVERTED TO THE VOXEL TYPE, tiles are appended in the
+    order of the sorted metrics, slot i taking the FIRST tile whose metric equals sorted[i] (tiles with equal metrics all map
+    to the first of them).  Shapes with a remainder take the reference's encode_with_remainder (Boost P^2 median over tiles
+    read past their end, a thread-timing dependent map): not restated.  returns (volume-shaped output, decode_map)"""
+    a = np.ascontiguousarray(a)
+    ts = int(tile_size)
+    if a.ndim != 3 or ts <= 0 or any(d % ts for d in a.shape) or any(d < ts for d in a.shape):
+        raise ValueError("tile_shuffle: only shapes that are whole multiples of the tile are restated")
+    tiles = _tiles_full(a, ts)
+    sums = np.cumsum(tiles.astype(np.float32), axis=1, dtype=np.float32)[:, -1]          # accumulate = strictly sequential
+    metric = (sums / np.float32(ts ** 3)).astype(a.dtype)
+    order = np.sort(metric, kind="stable")
+    first = {}
+    for i, m in enumerate(metric.tolist()):
+        first.setdefault(m, i)
+    dmap = np.array([first[m] for m in order.tolist()], dtype=np.uint64)
+    return tiles[dmap.astype(np.int64)].reshape(a.shape), dmap
+
+
+def tile_shuffle_decode(a, dmap, tile_size=32):
+    """detail::tile_shuffle::decode_with_remainder (:405-560): encoded tile i goes to slot decode_map[i] (a later i wins),
+    slots nobody names stay zero"""
+    a = np.ascontiguousarray(a)
+    ts = int(tile_size)
+    enc = a.reshape(-1, ts ** 3)
+    tiles = np.zeros_like(enc)
+    for i, t in enumerate(np.asarray(dmap).astype(np.int64).tolist()):
+        tiles[t] = enc[i]
+    return _untile_full(tiles, a.shape, ts)
+
+
+def bitshuffle_block_elems(elem_size, block_size=0):
+    """bshuf_default_block_size (bitshuffle_core.c): 8192 / elem_size rounded down to a multiple of 8, at least 128"""
+    if block_size:
+        return int(block_size)
+    return max((8192 // elem_size) // 8 * 8, 128)
+
+
+def bitshuffle(a, block_size=0, decode=False):
+    """bitshuffle_scheme (encoders/bitshuffle_scheme_impl.hpp:91-100) = bshuf_bitshuffle(in, out, n, sizeof(T), block_size) of
+    kiyo-masui/bitshuffle (the reference downloads psteinb's fork at configure time, src/cpp/CMakeLists.txt:361-367; the
+    sources are NOT in the tree: restated from the published algorithm, PARITY UNPINNED).  Per block of `block_size` elements
+    (default 8192 bytes worth; the last one rounded down to a multiple of 8 elements, the up to 7 elements behind it copied):
+    bit r = 8 * byte + bit of every element, packed 8 elements per byte (element 8k+j at bit j), row after row."""
+    a = np.ascontiguousarray(a)
+    E = a.dtype.itemsize
+    flat = a.reshape(-1).view(np.uint8)
+    n = a.size
+    bs = bitshuffle_block_elems(E, block_size)
+    if bs % 8:
+        raise ValueError("bitshuffle: block_size must be a multiple of 8")
+    out = np.empty_like(flat)
+    pos = 0
+
+    def one(lo, cnt):
+        seg = flat[lo * E:(lo + cnt) * E]
+        if decode:
+            rows = np.unpackbits(seg.reshape(E * 8, cnt // 8), axis=1, bitorder="little")      # (E*8, cnt)
+            out[lo * E:(lo + cnt) * E] = np.packbits(rows.T, axis=1, bitorder="little").reshape(-1)
+        else:
+            bits = np.unpackbits(seg.reshape(cnt, E), axis=1, bitorder="little")               # (cnt, E*8)
+            out[lo * E:(lo + cnt) * E] = np.packbits(bits.T, axis=1, bitorder="little").reshape(-1)
+
+    while n - pos >= bs:
+        one(pos, bs)
+        pos += bs
+    last = (n - pos) - (n - pos) % 8
+    if last:
+        one(pos, last)
+        pos += last
+    out[pos * E:] = flat[pos * E:]
+    return out.view(a.dtype).reshape(a.shape)
+
+
 def frame_shuffle_encode(a):
     a = np.ascontiguousarray(a)
     if a.ndim != 3:
@@ -419,10 +549,10 @@ def parse_minors(cfg):
     return out
 
 
-HEAD_FILTERS = ("diff3x3x1", "bitswap1", "remove_background", "rmbkrd_neighbor5x5x5", "rmestbkrd", "raster_reorder",
+HEAD_FILTERS = ("diff3x3x1", "bitswap1", "bitshuffle", "remove_background", "rmbkrd_neighbor5x5x5", "rmestbkrd", "raster_reorder",
                 "tile_shuffle", "frame_shuffle", "zcurve_reorder")
 SINKS = ("pass_through", "quantiser", "lz4")
-TAIL_FILTERS = ("diff3x3x1", "bitswap1", "lz4", "raster_reorder", "tile_shuffle", "frame_shuffle", "zcurve_reorder")
+TAIL_FILTERS = ("diff3x3x1", "bitswap1", "bitshuffle", "lz4", "raster_reorder", "tile_shuffle", "frame_shuffle", "zcurve_reorder")
 
 
 def can_be_built_from(pipeline):
@@ -554,6 +684,16 @@ class _Stage:
         if name == "raster_reorder":
             m = parse_minors(cfg)
             self.tile = int(m["tile_size"]) if "tile_size" in m else None      # None: 16 / sizeof(T), known at encode time
+        if name == "zcurve_reorder":
+            m = parse_minors(cfg)
+            self.tile = int(m["tile_size"]) if "tile_size" in m else 2         # zcurve_reorder_scheme_impl.hpp:40-55
+        if name == "tile_shuffle":
+            m = parse_minors(cfg)
+            self.tile = int(m["tile_size"]) if "tile_size" in m else 32        # tile_shuffle_scheme_impl.hpp:26-46
+            self.map = m.get("reorder_map", "")
+        if name == "bitshuffle":
+            m = parse_minors(cfg)
+            self.block = int(m["block_size"]) if "block_size" in m else 0      # bitshuffle_scheme_impl.hpp:44-58
 
     def config(self):
         if self.name == "bitswap1":
@@ -566,8 +706,12 @@ class _Stage:
             return ",".join("%s=%s" % kv for kv in sorted(self.cmap.items()))
         if self.name == "frame_shuffle":
             return "frame_chunk_size=%d,reorder_map=%s" % (self.chunk, self.map)
-        if self.name == "raster_reorder":
+        if self.name in ("raster_reorder", "zcurve_reorder"):
             return "tile_size=%d" % self.tile
+        if self.name == "tile_shuffle":
+            return "tile_size=%d,reorder_map=%s" % (self.tile, self.map)
+        if self.name == "bitshuffle":
+            return "block_size=%d" % self.block
         raise NotImplementedError(self.name)
 
     def full_name(self):
@@ -634,6 +778,17 @@ def pipeline_encode(pipeline, vol, nthreads=2):
             if s.tile is None:
                 s.tile = 16 // cur.dtype.itemsize
             cur = raster_reorder(cur, s.tile)
+        elif s.name == "zcurve_reorder":
+            if seen_sink:
+                raise NotImplementedError("zcurve_reorder as a tail filter is not restated")
+            cur = zcurve_reorder(cur, s.tile)
+        elif s.name == "tile_shuffle":
+            if seen_sink:
+                raise NotImplementedError("tile_shuffle as a tail filter is not restated")
+            cur, dmap = tile_shuffle_encode(cur, s.tile)
+            s.map = to_verbatim(dmap)
+        elif s.name == "bitshuffle":
+            cur = bitshuffle(cur, s.block)
         elif s.name == "quantiser":
             cur, dec = quantiser_encode(cur)
             s.cmap["decode_lut_string"] = to_verbatim(dec)
@@ -684,6 +839,16 @@ def pipeline_decode(blob):
             cur = dec[np.ascontiguousarray(cur).view(np.uint8)]
         elif s.name == "raster_reorder":
             cur = raster_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
+        elif s.name == "zcurve_reorder":
+            cur = zcurve_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
+        elif s.name == "tile_shuffle":
+            import base64
+            m = s.map[len("<verbatim>"):-len("</verbatim>")]
+            dmap = np.frombuffer(base64.b64decode(m), dtype=np.uint64)
+            cur = tile_shuffle_decode(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), dmap, s.tile)
+        elif s.name == "bitshuffle":
+            t = np.uint8 if after_sink else dtype
+            cur = bitshuffle(np.ascontiguousarray(cur).view(t), s.block, decode=True)
         elif s.name == "frame_shuffle":
             import base64
             m = s.map[len("<verbatim>"):-len("</verbatim>")]

@@ -360,6 +360,85 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 cur = out;
                 break;
             }
+            case StageKind::zcurve_reorder: {
+                if (dims.size() != 3) {
+                    std::fprintf(stderr, "[sqeazy::detail::zcurve::encode] received non-3D shape which is currently unsupported!\n");
+                    return 1;
+                }
+                auto t = st.cfg.find("tile_size");
+                const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 2;
+                if (!sqy::zcurve_geometry_defined(dims[0], dims[1], dims[2], ts)) {
+                    std::fprintf(stderr, "[sqeazy]\t zcurve_reorder: the reference's result is undefined for shape %llux%llux%llu at tile_size=%llu "
+                                         "(tile sizes other than 2..128 powers of two, or a tile that does not divide a power-of-two shape); refused\n",
+                                 (unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2], (unsigned long long)ts);
+                    return 1;
+                }
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                ProfScope ps("zcurve_reorder", stream, pend);
+                // (inside a tile the reference's morton_at_ct<log2(tile)> code is row-major: the tiled raster kernel is the stage)
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, dims[0], dims[1], dims[2], ts, cur_elem, false, stream));
+                cur = out;
+                break;
+            }
+            case StageKind::bitshuffle: {
+                auto b = st.cfg.find("block_size");
+                const uint64_t be = sqy::bitshuffle_block_elems(cur_elem, b != st.cfg.end() ? (uint64_t)std::atoi(b->second.c_str()) : 0);
+                if (!be) { std::fprintf(stderr, "[sqeazy]\t bitshuffle: block_size must be a multiple of 8\n"); return 1; }
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                ProfScope ps("bitshuffle", stream, pend);
+                SQY_HIP(sqy::launch_bitshuffle(cur, out, cur_len, cur_elem, be, false, stream));
+                cur = out;
+                break;
+            }
+            case StageKind::tile_shuffle: {
+                if (dims.size() != 3) {
+                    std::fprintf(stderr, "[sqeazy::detail::tile_shuffle::encode] received non-3D shape which is currently unsupported!\n");
+                    return 1;
+                }
+                auto t = st.cfg.find("tile_size");
+                const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 32;
+                if (!sqy::tile_shuffle_geometry_defined(dims[0], dims[1], dims[2], ts)) {
+                    std::fprintf(stderr, "[sqeazy]\t tile_shuffle: shape %llux%llux%llu is not a whole multiple of tile_size=%llu; the reference's remainder "
+                                         "path (P^2 median over tiles read past their end, thread-timing dependent map) is not reproduced; refused\n",
+                                 (unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2], (unsigned long long)ts);
+                    return 1;
+                }
+                const uint64_t per_tile = ts * ts * ts, ntiles = cur_len / per_tile, tile_bytes = per_tile * (uint64_t)cur_elem;
+                // 1. tiles made contiguous (tile-major copy), 2. their sequential binary32 sums, 3. order on the host, 4. tiles appended in that order
+                uint8_t* tiled = next_buf(cur_len * cur_elem);
+                if (!tiled) return 1;
+                {
+                    ProfScope ps("tile_gather", stream, pend);
+                    SQY_HIP(sqy::launch_raster_reorder(cur, tiled, dims[0], dims[1], dims[2], ts, cur_elem, false, stream));
+                }
+                if (ws->small.ensure(std::max<uint64_t>(ntiles * 16, 4096))) return 1;
+                float* d_sums = static_cast<float*>(ws->small.p);
+                uint64_t* d_map = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(ws->small.p) + ((ntiles * 4 + 15) & ~(uint64_t)15));
+                {
+                    const uint64_t fm_bytes = sqy::frame_metric_scratch_bytes(ntiles, per_tile, cur_elem);
+                    if (ws->lz4_scratch.ensure(std::max<uint64_t>(fm_bytes, 16))) return 1;
+                    ProfScope ps("tile_metric", stream, pend);
+                    SQY_HIP(sqy::launch_frame_metric(tiled, ntiles, per_tile, cur_elem, d_sums, stream, ws->lz4_scratch.p, fm_bytes));
+                }
+                std::vector<float> sums(ntiles);
+                std::vector<uint64_t> map(ntiles);
+                SQY_HIP(hipMemcpyAsync(sums.data(), d_sums, ntiles * sizeof(float), hipMemcpyDeviceToHost, stream));
+                SQY_HIP(hipStreamSynchronize(stream));
+                sqy::tile_shuffle_order(sums.data(), ntiles, per_tile, cur_elem, map.data());
+                SQY_HIP(hipMemcpyAsync(d_map, map.data(), ntiles * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
+                uint8_t* out = next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                {
+                    ProfScope ps("tile_shuffle", stream, pend);
+                    SQY_HIP(sqy::launch_frame_gather(tiled, out, ntiles, tile_bytes, d_map, stream));
+                }
+                SQY_HIP(hipStreamSynchronize(stream));                     // `map` (host) is read by the async copy above
+                st.cfg["reorder_map"] = sqy::to_verbatim(map.data(), ntiles * sizeof(uint64_t));   // tile_shuffle_scheme_impl.hpp:88
+                cur = out;
+                break;
+            }
             case StageKind::diff3x3x1: {
                 if (dims.size() != 3) {
                     // diff_scheme_impl.hpp:84-87 returns the output pointer unmoved -> the chain throws
@@ -792,6 +871,73 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (!out) return 1;
                 ProfScope ps("raster_reorder_decode", stream, pend);
                 SQY_HIP(sqy::launch_raster_reorder(cur, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            case StageKind::zcurve_reorder: {
+                if (h.shape.size() != 3) return stage_error(si);
+                auto t = st.cfg.find("tile_size");
+                const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 2;
+                if (!sqy::zcurve_geometry_defined(h.shape[0], h.shape[1], h.shape[2], ts)) {
+                    std::fprintf(stderr, "[sqeazy]\t zcurve_reorder: tile_size %llu does not fit the shape\n", (unsigned long long)ts);
+                    return stage_error(si);
+                }
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                ProfScope ps("zcurve_reorder_decode", stream, pend);
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            case StageKind::bitshuffle: {
+                const int e_here = (sink_index >= 0 && (int)si > sink_index) ? 1 : e_in;      // tail filters work on the sink's bytes
+                auto b = st.cfg.find("block_size");
+                const uint64_t be = sqy::bitshuffle_block_elems(e_here, b != st.cfg.end() ? (uint64_t)std::atoi(b->second.c_str()) : 0);
+                if (!be) return stage_error(si);
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                ProfScope ps("bitshuffle_decode", stream, pend);
+                SQY_HIP(sqy::launch_bitshuffle(cur, out, stage_in_bytes / (uint64_t)e_here, e_here, be, true, stream));
+                cur = out; cur_bytes = stage_in_bytes;
+                break;
+            }
+            case StageKind::tile_shuffle: {
+                if (h.shape.size() != 3) return stage_error(si);
+                auto t = st.cfg.find("tile_size");
+                const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 32;
+                if (!sqy::tile_shuffle_geometry_defined(h.shape[0], h.shape[1], h.shape[2], ts)) {
+                    std::fprintf(stderr, "[sqeazy]\t tile_shuffle: tile_size %llu does not divide the shape\n", (unsigned long long)ts);
+                    return stage_error(si);
+                }
+                auto it = st.cfg.find("reorder_map");
+                const uint64_t per_tile = ts * ts * ts, ntiles = n / per_tile, tile_bytes = per_tile * (uint64_t)e_in;
+                if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t tile_shuffle: no reorder_map in the header\n"); return stage_error(si); }
+                const std::vector<unsigned char> mapb = sqy::base64_decode(it->second.substr(10, it->second.size() - 21));
+                if (mapb.size() != ntiles * 8) { std::fprintf(stderr, "[sqeazy]\t tile_shuffle: malformed reorder_map\n"); return stage_error(si); }
+                // tile_shuffle_utils.hpp:473-482: encoded tile i goes to slot map[i], a later i wins, unnamed slots stay zero:
+                // as a gather, slot t takes the LAST i that names it
+                std::vector<uint64_t> src_of(ntiles, ~0ull);
+                for (uint64_t i = 0; i < ntiles; ++i) {
+                    uint64_t v; std::memcpy(&v, mapb.data() + 8 * i, 8);
+                    if (v >= ntiles) { std::fprintf(stderr, "[sqeazy]\t tile_shuffle: reorder_map out of range\n"); return stage_error(si); }
+                    src_of[v] = i;
+                }
+                if (ws->small.ensure(std::max<uint64_t>(ntiles * 8, 4096))) return 1;
+                SQY_HIP(hipMemcpyAsync(ws->small.p, src_of.data(), ntiles * 8, hipMemcpyHostToDevice, stream));
+                DevBuf& tb = use_ping ? ws->ping : ws->pong;                    // tile-major intermediate
+                use_ping = !use_ping;
+                if (tb.ensure(std::max<uint64_t>(stage_in_bytes, 16))) return 1;
+                {
+                    ProfScope ps("tile_unshuffle", stream, pend);
+                    SQY_HIP(sqy::launch_frame_gather(cur, tb.p, ntiles, tile_bytes, static_cast<const uint64_t*>(ws->small.p), stream));
+                }
+                SQY_HIP(hipStreamSynchronize(stream));                          // src_of (host) is read by the async copy above
+                uint8_t* out = out_buf(si, stage_in_bytes);
+                if (!out) return 1;
+                {
+                    ProfScope ps("tile_scatter", stream, pend);
+                    SQY_HIP(sqy::launch_raster_reorder(tb.p, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                }
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }

@@ -68,6 +68,10 @@ hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t
 hipError_t launch_raster_reorder(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size, int elem_size,
                                  bool decode, hipStream_t stream);
 
+// bitshuffle (bshuf_bitshuffle / bshuf_bitunshuffle of kiyo-masui/bitshuffle) of n_elems elements of 1 or 2 bytes in blocks of
+// block_elems elements (a multiple of 8)
+hipError_t launch_bitshuffle(const void* in, void* out, uint64_t n_elems, int elem_size, uint64_t block_elems, bool decode, hipStream_t stream);
+
 // frame_shuffle: per-frame mean in the reference's sequential binary32 order; frame gather out[i] = in[map[i]]
 hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream,
                                void* scratch = nullptr, uint64_t scratch_bytes = 0);

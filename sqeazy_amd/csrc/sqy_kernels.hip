@@ -1994,9 +1994,13 @@ void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ o
 {
     const uint64_t f = blockIdx.x / blocks_per_frame;
     const uint32_t part = blockIdx.x % blocks_per_frame;
-    const uint8_t* s = in + map[f] * frame_bytes;
     uint8_t* d = out + f * frame_bytes;
     const uint64_t nvec = frame_bytes / 16;
+    if (map[f] == ~0ull) {                                       // (tile_shuffle decode: a slot no encoded tile maps to stays zero)
+        for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < frame_bytes; i += (uint64_t)blocks_per_frame * 256) d[i] = 0;
+        return;
+    }
+    const uint8_t* s = in + map[f] * frame_bytes;
     if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
         for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < nvec; v += (uint64_t)blocks_per_frame * 256)
             reinterpret_cast<uint4*>(d)[v] = reinterpret_cast<const uint4*>(s)[v];
@@ -2004,6 +2008,121 @@ void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ o
             for (uint64_t i = nvec * 16 + threadIdx.x; i < frame_bytes; i += 256) d[i] = s[i];
     } else {
         for (uint64_t i = (uint64_t)part * 256 + threadIdx.x; i < frame_bytes; i += (uint64_t)blocks_per_frame * 256) d[i] = s[i];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// bitshuffle (encoders/bitshuffle_scheme_impl.hpp:91-100 -> bshuf_bitshuffle of kiyo-masui/bitshuffle, which the reference
+// fetches at configure time; not in its tree -- written from the published algorithm).  Per block of `bs` elements: bit row
+// r = 8 * (byte of the element) + (bit of that byte) holds that bit of every element, 8 elements per byte, element 8k+j at
+// bit j; rows follow each other, bs / 8 bytes each.  The last block is rounded down to a multiple of 8 elements, up to 7
+// elements behind it are copied.
+// Fast kernels: 16-bit elements, blocks of 4096 (the default): one wavefront per block, lane L owns elements 64L..64L+63
+// (128 contiguous bytes in, 8 bytes of every row out); two 16x16 bit transposes on pairs of 16-element groups.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256)
+void bitshuffle_u16_4096_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t nblocks, bool decode)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
+    for (uint64_t blk = wave_global; blk < nblocks; blk += wave_stride) {
+        const uint16_t* src = in + blk * 4096;
+        uint16_t* dst = out + blk * 4096;
+        uint32_t ra[16], rb[16];                                 // element pairs of groups (0,1) and (2,3) / row words
+        if (!decode) {
+            const v4u* p = reinterpret_cast<const v4u*>(src) + lane * 8;
+            v4u v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = p[j];
+            // group g = elements 16g..16g+15 = v[2g], v[2g+1]; r[i] = element i of the first group | element i of the second << 16
+            const uint32_t g0[8] = {v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w};
+            const uint32_t g1[8] = {v[2].x, v[2].y, v[2].z, v[2].w, v[3].x, v[3].y, v[3].z, v[3].w};
+            const uint32_t g2[8] = {v[4].x, v[4].y, v[4].z, v[4].w, v[5].x, v[5].y, v[5].z, v[5].w};
+            const uint32_t g3[8] = {v[6].x, v[6].y, v[6].z, v[6].w, v[7].x, v[7].y, v[7].z, v[7].w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ra[2 * k] = __builtin_amdgcn_perm(g1[k], g0[k], 0x05040100u);
+                ra[2 * k + 1] = __builtin_amdgcn_perm(g1[k], g0[k], 0x07060302u);
+                rb[2 * k] = __builtin_amdgcn_perm(g3[k], g2[k], 0x05040100u);
+                rb[2 * k + 1] = __builtin_amdgcn_perm(g3[k], g2[k], 0x07060302u);
+            }
+            transpose16x16_pairs(ra);
+            transpose16x16_pairs(rb);
+            // row b: 512 bytes per block, this lane's 8 bytes = groups 0..3 (2 bytes each)
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                uint2 w;
+                w.x = ra[b];
+                w.y = rb[b];
+                *reinterpret_cast<uint2*>(reinterpret_cast<uint8_t*>(dst) + b * 512 + lane * 8) = w;
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < 16; ++b) {
+                const uint2 w = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint8_t*>(src) + b * 512 + lane * 8);
+                ra[b] = w.x;
+                rb[b] = w.y;
+            }
+            transpose16x16_pairs(ra);                            // (its own inverse)
+            transpose16x16_pairs(rb);
+            v4u v[8];
+            uint32_t g0[8], g1[8], g2[8], g3[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                // ra[2k] = elem 2k of g0 | elem 2k of g1 << 16 ; ra[2k+1] likewise -> dword k of g0 = elem 2k | elem 2k+1 << 16
+                g0[k] = __builtin_amdgcn_perm(ra[2 * k + 1], ra[2 * k], 0x05040100u);
+                g1[k] = __builtin_amdgcn_perm(ra[2 * k + 1], ra[2 * k], 0x07060302u);
+                g2[k] = __builtin_amdgcn_perm(rb[2 * k + 1], rb[2 * k], 0x05040100u);
+                g3[k] = __builtin_amdgcn_perm(rb[2 * k + 1], rb[2 * k], 0x07060302u);
+            }
+            v[0] = v4u{g0[0], g0[1], g0[2], g0[3]}; v[1] = v4u{g0[4], g0[5], g0[6], g0[7]};
+            v[2] = v4u{g1[0], g1[1], g1[2], g1[3]}; v[3] = v4u{g1[4], g1[5], g1[6], g1[7]};
+            v[4] = v4u{g2[0], g2[1], g2[2], g2[3]}; v[5] = v4u{g2[4], g2[5], g2[6], g2[7]};
+            v[6] = v4u{g3[0], g3[1], g3[2], g3[3]}; v[7] = v4u{g3[4], g3[5], g3[6], g3[7]};
+            v4u* p = reinterpret_cast<v4u*>(dst) + lane * 8;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = v[j];
+        }
+    }
+}
+
+// any element size (1, 2), any block size (multiple of 8), partial last block, copied tail: one thread per byte of the
+// shuffled side (it collects / scatters the bit of its 8 elements)
+__global__ __launch_bounds__(256)
+void bitshuffle_generic_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t first_elem, uint64_t n_elems,
+                               uint32_t elem_size, uint64_t bs, bool decode)
+{
+    // elements [first_elem, n_elems): whole blocks of bs, then one block of the remainder rounded down to 8, then the copied tail
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;            // byte index inside [first_elem * E, n_elems * E)
+    const uint64_t total_bytes = (n_elems - first_elem) * elem_size;
+    if (t >= total_bytes) return;
+    const uint64_t rel_elems = n_elems - first_elem;
+    const uint64_t full = rel_elems / bs;
+    const uint64_t last = (rel_elems - full * bs) / 8 * 8;
+    const uint64_t shuffled_bytes = (full * bs + last) * elem_size;
+    const uint8_t* ib = in + first_elem * elem_size;
+    uint8_t* ob = out + first_elem * elem_size;
+    if (t >= shuffled_bytes) { ob[t] = ib[t]; return; }                            // tail: up to 7 elements, verbatim
+    const uint64_t blk = t / (bs * elem_size);
+    const uint64_t cnt = blk < full ? bs : last;                                   // elements of this block
+    const uint64_t base = blk * bs * elem_size;                                    // byte offset of the block
+    const uint64_t o = t - base;                                                   // byte inside the block, shuffled side
+    const uint64_t row = o / (cnt / 8), col = o % (cnt / 8);                       // bit row, byte in the row
+    const uint32_t byte_of = (uint32_t)(row >> 3), bit = (uint32_t)(row & 7);
+    if (!decode) {
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) v |= ((uint32_t)(ib[base + (col * 8 + j) * elem_size + byte_of] >> bit) & 1u) << j;
+        ob[t] = (uint8_t)v;
+    } else {
+        // decode: thread t owns plain byte t of the block: element e = o / E, byte b = o % E; its 8 bits come from 8 rows
+        const uint64_t e = o / elem_size;
+        const uint32_t b = (uint32_t)(o % elem_size);
+        uint32_t v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; ++k) v |= ((uint32_t)(ib[base + (uint64_t)(b * 8 + k) * (cnt / 8) + e / 8] >> (e & 7)) & 1u) << k;
+        ob[t] = (uint8_t)v;
     }
 }
 
@@ -2877,6 +2996,30 @@ hipError_t launch_raster_reorder(const void* in, void* out, uint64_t Z, uint64_t
     else
         hipLaunchKernelGGL((raster_reorder_kernel<uint8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out,
                            Z, Y, X, tile_size, TX, decode);
+    return hipGetLastError();
+}
+
+hipError_t launch_bitshuffle(const void* in, void* out, uint64_t n_elems, int elem_size, uint64_t block_elems, bool decode, hipStream_t stream)
+{
+    if (n_elems == 0) return hipSuccess;
+    if (block_elems == 0 || block_elems % 8) return hipErrorInvalidValue;
+    uint64_t done = 0;
+    const bool aligned = ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    if (elem_size == 2 && block_elems == 4096 && aligned && n_elems >= 4096) {
+        const uint64_t nblocks = n_elems / 4096;
+        const uint64_t want = (nblocks + 3) / 4;
+        const uint64_t cap = (uint64_t)num_cus() * 16;
+        hipLaunchKernelGGL(bitshuffle_u16_4096_kernel, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, (const uint16_t*)in,
+                           (uint16_t*)out, nblocks, decode);
+        done = nblocks * 4096;
+    }
+    if (done < n_elems) {
+        const uint64_t bytes = (n_elems - done) * (uint64_t)elem_size;
+        const uint64_t blocks = (bytes + 255) / 256;
+        if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(bitshuffle_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, done, n_elems,
+                           (uint32_t)elem_size, block_elems, decode);
+    }
     return hipGetLastError();
 }
 

@@ -266,6 +266,9 @@ static StageKind kind_of(const std::string& n)
     if (n == "bitswap1") return StageKind::bitswap1;
     if (n == "frame_shuffle") return StageKind::frame_shuffle;
     if (n == "raster_reorder") return StageKind::raster_reorder;
+    if (n == "zcurve_reorder") return StageKind::zcurve_reorder;
+    if (n == "tile_shuffle") return StageKind::tile_shuffle;
+    if (n == "bitshuffle") return StageKind::bitshuffle;
     if (n == "quantiser") return StageKind::quantiser;
     if (n == "lz4") return StageKind::lz4;
     if (n == "pass_through") return StageKind::pass_through;
@@ -292,6 +295,19 @@ std::string Stage::config() const
             auto t = cfg.find("tile_size");
             return "tile_size=" + std::to_string(t != cfg.end() ? std::atoi(t->second.c_str()) : 0);
         }
+        case StageKind::zcurve_reorder: {                                        // zcurve_reorder_scheme_impl.hpp:68-74 (default tile 2)
+            auto t = cfg.find("tile_size");
+            return "tile_size=" + std::to_string(t != cfg.end() ? std::atoi(t->second.c_str()) : 2);
+        }
+        case StageKind::tile_shuffle: {                                          // tile_shuffle_scheme_impl.hpp:57-66 (default tile 32)
+            auto t = cfg.find("tile_size");
+            auto m = cfg.find("reorder_map");
+            return "tile_size=" + std::to_string(t != cfg.end() ? std::atoi(t->second.c_str()) : 32) + ",reorder_map=" + (m != cfg.end() ? m->second : "");
+        }
+        case StageKind::bitshuffle: {                                            // bitshuffle_scheme_impl.hpp:75-81 (default block 0 = library default)
+            auto b = cfg.find("block_size");
+            return "block_size=" + std::to_string(b != cfg.end() ? std::atoi(b->second.c_str()) : 0);
+        }
         case StageKind::frame_shuffle: {                                         // frame_shuffle_scheme_impl.hpp:58-66
             auto c = cfg.find("frame_chunk_size");
             auto m = cfg.find("reorder_map");
@@ -316,7 +332,8 @@ static bool in_list(const std::string& n, const char* const* list, size_t cnt)
 
 bool known_head_filter(const std::string& n)
 {
-    static const char* const l[] = {"diff3x3x1", "bitswap1", "remove_background", "rmbkrd_neighbor5x5x5", "rmestbkrd",
+    // (bitshuffle: present when the reference is built with USE_BITSHUFFLE, its default: CMakeLists.txt:47, sqeazy_pipelines.hpp:35-37)
+    static const char* const l[] = {"diff3x3x1", "bitswap1", "bitshuffle", "remove_background", "rmbkrd_neighbor5x5x5", "rmestbkrd",
                                     "raster_reorder", "tile_shuffle", "frame_shuffle", "zcurve_reorder"};
     return in_list(n, l, sizeof(l) / sizeof(l[0]));
 }
@@ -327,7 +344,7 @@ bool known_sink(const std::string& n)
 }
 bool known_tail_filter(const std::string& n)
 {
-    static const char* const l[] = {"diff3x3x1", "bitswap1", "lz4", "raster_reorder", "tile_shuffle", "frame_shuffle",
+    static const char* const l[] = {"diff3x3x1", "bitswap1", "bitshuffle", "lz4", "raster_reorder", "tile_shuffle", "frame_shuffle",
                                     "zcurve_reorder"};
     return in_list(n, l, sizeof(l) / sizeof(l[0]));
 }
@@ -396,6 +413,22 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
                 auto c = st.cfg.find("frame_chunk_size");
                 if (c != st.cfg.end() && std::atoi(c->second.c_str()) != 1)
                     return fail("frame_shuffle: only frame_chunk_size=1 is implemented on MI355X");
+                break;
+            }
+            case StageKind::zcurve_reorder: {
+                if (after_sink) return fail("zcurve_reorder as a tail filter is not implemented on MI355X");
+                break;
+            }
+            case StageKind::tile_shuffle: {
+                if (after_sink) return fail("tile_shuffle as a tail filter is not implemented on MI355X");
+                auto t = st.cfg.find("tile_size");
+                if (t != st.cfg.end() && std::atoi(t->second.c_str()) <= 0) return fail("tile_shuffle: tile_size must be positive");
+                break;
+            }
+            case StageKind::bitshuffle: {
+                auto b = st.cfg.find("block_size");
+                if (b != st.cfg.end() && (std::atoi(b->second.c_str()) < 0 || std::atoi(b->second.c_str()) % 8))
+                    return fail("bitshuffle: block_size must be a non-negative multiple of 8");
                 break;
             }
             case StageKind::raster_reorder: {
@@ -637,6 +670,49 @@ void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lu
         importanceIntegral += importance[raw_idx];
     }
     lut_decode[comp_idx] = static_cast<uint16_t>(index_weighted_mean_importance);
+}
+
+bool zcurve_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t ts)
+{
+    if (Z == 0 || Y == 0 || X == 0) return false;
+    if (ts < 2 || ts > 128 || (ts & (ts - 1))) return false;                  // zcurve_reorder_utils.hpp:30-67: other sizes get 1-bit Morton codes that leave the tile
+    auto flog2 = [](uint64_t v) { int l = 0; while (v >>= 1) ++l; return l; };
+    const uint64_t common = (uint64_t)1 << std::min(flog2(Z), std::min(flog2(Y), flog2(X)));   // :69-81 common_power_of_2
+    const bool has_remainder = (Z % common) || (Y % common) || (X % common);                   // :83-94, :125-131
+    if (!has_remainder && ((Z % ts) || (Y % ts) || (X % ts))) return false;                    // encode_full (:141-186) assumes whole tiles
+    return true;
+}
+
+bool tile_shuffle_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t ts)
+{
+    return ts > 0 && Z >= ts && Y >= ts && X >= ts && Z % ts == 0 && Y % ts == 0 && X % ts == 0;
+}
+
+void tile_shuffle_order(const float* sums, size_t ntiles, size_t per_tile, int elem_size, uint64_t* decode_map)
+{
+    // tile_shuffle_utils.hpp:176-219: std::vector<in_value_t> metric; metric[i] = sum / n_elements_per_tile (float -> voxel type)
+    std::vector<uint32_t> metric(ntiles);
+    for (size_t i = 0; i < ntiles; ++i) {
+        const float m = sums[i] / per_tile;
+        metric[i] = elem_size == 2 ? (uint32_t)(uint16_t)m : (uint32_t)(uint8_t)m;
+    }
+    std::vector<uint32_t> sorted_metric = metric;
+    std::sort(sorted_metric.begin(), sorted_metric.end());
+    // std::find(metric, sorted[i]) for every i = the first tile with that metric
+    std::map<uint32_t, uint64_t> first;
+    for (size_t i = ntiles; i-- > 0;) first[metric[i]] = i;
+    for (size_t i = 0; i < ntiles; ++i) decode_map[i] = first[sorted_metric[i]];
+}
+
+uint64_t bitshuffle_block_elems(int elem_size, uint64_t block_size)
+{
+    if (block_size == 0) {
+        // bshuf_default_block_size (kiyo-masui/bitshuffle, bitshuffle_core.c): "needs to be absolutely stable between versions"
+        uint64_t b = 8192 / (uint64_t)elem_size;
+        b = (b / 8) * 8;
+        return b < 128 ? 128 : b;
+    }
+    return block_size % 8 ? 0 : block_size;
 }
 
 void frame_shuffle_order(const float* sums, size_t Z, size_t per_frame, uint64_t* decode_map)

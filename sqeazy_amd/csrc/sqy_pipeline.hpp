@@ -27,7 +27,7 @@ std::vector<std::string> split_outside_verbatim(const std::string& s, const std:
 pairs_t parse_pairs(const std::string& pipeline);
 std::map<std::string, std::string> parse_minors(const std::string& cfg);
 
-enum class StageKind { diff3x3x1, bitswap1, frame_shuffle, raster_reorder, quantiser, lz4, pass_through, unsupported };
+enum class StageKind { diff3x3x1, bitswap1, bitshuffle, frame_shuffle, raster_reorder, zcurve_reorder, tile_shuffle, quantiser, lz4, pass_through, unsupported };
 
 struct Lz4Params {
     int accel = 1;
@@ -97,6 +97,17 @@ int clean_number_of_threads(int n);
 // undefined (a remainder in some but not all dimensions; tile_size a proper multiple of the 16-byte SSE block on a
 // remainder-free shape)
 bool raster_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size, int elem_size);
+
+// zcurve_reorder (encoders/zcurve_reorder_utils.hpp): tile sizes 2..128 (powers of two) -- inside a tile the reference's
+// morton_at_ct<log2(tile)> code is plain row-major, so the stage is "tiles of tile^3 (smaller at the high ends) in (z,y,x) tile
+// order"; false where the reference runs past its buffers (other tile sizes; encode_full with a tile that does not divide the shape)
+bool zcurve_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size);
+// tile_shuffle (encoders/tile_shuffle_utils.hpp:104-224, encode_full): only shapes that are whole multiples of the tile
+bool tile_shuffle_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size);
+// metric = (T)(sequential float sum / voxels per tile), sorted ascending, slot i <- first tile whose metric equals sorted[i]
+void tile_shuffle_order(const float* sums, size_t ntiles, size_t per_tile, int elem_size, uint64_t* decode_map);
+// bitshuffle: elements per block (bshuf_default_block_size for 0); 0 when the configured size is not a multiple of 8
+uint64_t bitshuffle_block_elems(int elem_size, uint64_t block_size);
 
 // ---- header ----
 std::string header_pack(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
