@@ -698,7 +698,7 @@ class _Stage:
     def config(self):
         if self.name == "bitswap1":
             return "num_bits_per_plane=1"
-        if self.name == "diff3x3x1":
+        if self.name in ("diff3x3x1", "pass_through"):
             return ""
         if self.name == "lz4":
             return self.lz4.config()
@@ -778,6 +778,8 @@ def pipeline_encode(pipeline, vol, nthreads=2):
             if s.tile is None:
                 s.tile = 16 // cur.dtype.itemsize
             cur = raster_reorder(cur, s.tile)
+        elif s.name == "pass_through":
+            cur = np.ascontiguousarray(cur).reshape(-1).view(np.uint8)     # pass_through_scheme_impl.hpp:66-79: a copy, re-typed to bytes
         elif s.name == "zcurve_reorder":
             if seen_sink:
                 raise NotImplementedError("zcurve_reorder as a tail filter is not restated")
@@ -839,6 +841,8 @@ def pipeline_decode(blob):
             cur = dec[np.ascontiguousarray(cur).view(np.uint8)]
         elif s.name == "raster_reorder":
             cur = raster_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
+        elif s.name == "pass_through":
+            pass
         elif s.name == "zcurve_reorder":
             cur = zcurve_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
         elif s.name == "tile_shuffle":

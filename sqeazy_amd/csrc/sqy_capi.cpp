@@ -360,6 +360,12 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 cur = out;
                 break;
             }
+            case StageKind::pass_through: {
+                // pass_through_scheme_impl.hpp:66-79: the sink that only re-types the stream to bytes
+                cur_len *= (uint64_t)cur_elem;
+                cur_elem = 1;
+                break;
+            }
             case StageKind::zcurve_reorder: {
                 if (dims.size() != 3) {
                     std::fprintf(stderr, "[sqeazy::detail::zcurve::encode] received non-3D shape which is currently unsupported!\n");
@@ -772,10 +778,18 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
         return 1 + 100;
     };
     // element size of the stream in front of every stage (the quantiser sink turns it into bytes)
+    // (the quantiser maps every voxel to one byte; pass_through re-types the voxels: elem times as many one-byte elements)
     std::vector<int> elem_before(pipe.stages.size());
+    std::vector<uint64_t> count_before(pipe.stages.size());
     {
         int e = elem;
-        for (size_t i = 0; i < pipe.stages.size(); ++i) { elem_before[i] = e; if (pipe.stages[i].kind == StageKind::quantiser) e = 1; }
+        uint64_t c = n;
+        for (size_t i = 0; i < pipe.stages.size(); ++i) {
+            elem_before[i] = e;
+            count_before[i] = c;
+            if (pipe.stages[i].kind == StageKind::quantiser) e = 1;
+            if (pipe.stages[i].kind == StageKind::pass_through) { c *= (uint64_t)e; e = 1; }
+        }
     }
     const uint8_t* cur = d_src + h.size;
     uint64_t cur_bytes = h.payload_bytes;
@@ -791,7 +805,8 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
     for (size_t si = pipe.stages.size(); si-- > 0;) {
         const Stage& st = pipe.stages[si];
         const int e_in = elem_before[si];                                       // element size on the ENCODER's input side of this stage
-        const uint64_t stage_in_bytes = n * (uint64_t)e_in;                     // bytes the inverse has to produce
+        const uint64_t n_in = count_before[si];                                 // elements on that side
+        const uint64_t stage_in_bytes = n_in * (uint64_t)e_in;                  // bytes the inverse has to produce
         switch (st.kind) {
             case StageKind::lz4: {
                 const uint64_t total = stage_in_bytes;
@@ -855,7 +870,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 ProfScope ps("bitswap1_decode", stream, pend);
-                SQY_HIP(sqy::launch_bitswap1_decode(cur, out, n, e_in, stream));
+                SQY_HIP(sqy::launch_bitswap1_decode(cur, out, n_in, e_in, stream));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }
@@ -874,6 +889,8 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }
+            case StageKind::pass_through:
+                break;                                                          // pass_through_scheme_impl.hpp:81-95: bytes are the voxels
             case StageKind::zcurve_reorder: {
                 if (h.shape.size() != 3) return stage_error(si);
                 auto t = st.cfg.find("tile_size");

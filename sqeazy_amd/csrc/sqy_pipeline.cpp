@@ -451,6 +451,7 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
                 if (st.lz4.accel < 0) return fail("lz4 accel < 0 raises liblz4's acceleration above 1; not implemented on MI355X");
                 break;
             case StageKind::pass_through:
+                break;
             default:
                 return fail("stage '" + st.name + "' is not implemented on MI355X");
         }

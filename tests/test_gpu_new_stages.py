@@ -83,3 +83,13 @@ def test_bitshuffle_pipelines(sqy, oracle):
     _rt(sqy, oracle, "bitshuffle->lz4", synth.stack((24, 64, 96), np.uint8))
     rc, blob = sqy.encode("bitshuffle->lz4", vol, nthreads=1)          # and the serial LZ4 layout behind it
     assert rc == 0 and blob == oracle.pipeline_encode("bitshuffle->lz4", vol, nthreads=1)
+
+
+def test_pass_through_sink(sqy, oracle):
+    """pass_through_scheme_impl.hpp:66-95: the sink that only re-types the voxels to bytes; tail filters then work on bytes"""
+    for vol in (synth.stack((12, 40, 56)), synth.stack((12, 40, 56), np.uint8)):
+        for pipe in ("pass_through", "pass_through->lz4", "pass_through->bitswap1->lz4", "bitswap1->pass_through->lz4",
+                     "diff3x3x1->pass_through->bitshuffle->lz4"):
+            if vol.dtype == np.uint8 and pipe.startswith("diff"):
+                continue
+            _rt(sqy, oracle, pipe, vol)

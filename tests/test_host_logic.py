@@ -46,11 +46,12 @@ def test_pipeline_possible_matches_reference_rules(sqy, oracle):
     supported = ["lz4", "bitswap1", "diff3x3x1->bitswap1->lz4", "frame_shuffle->lz4", "quantiser->bitswap1->lz4",
                  "raster_reorder->lz4", "raster_reorder(tile_size=4)->bitswap1->lz4", "tile_shuffle->lz4", "zcurve_reorder->lz4",
                  "zcurve_reorder(tile_size=8)->bitswap1->lz4", "bitshuffle->lz4", "bitshuffle(block_size=64)->lz4", "quantiser->bitshuffle->lz4",
+                 "pass_through", "pass_through->lz4", "bitswap1->pass_through->bitswap1->lz4",
                  "bitswap1(num_bits_per_plane=1)->lz4(accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0)"]
     for p in supported:
         assert oracle.can_be_built_from(p) and sqy.pipeline_possible(p), p
     # valid for the reference, not implemented here: answered false (documented deviation)
-    for p in ["pass_through", "lz4(accel=9)", "lz4->bitswap1", "lz4->raster_reorder", "raster_reorder(tile_size=0)->lz4",
+    for p in ["lz4(accel=9)", "lz4->bitswap1", "lz4->raster_reorder", "raster_reorder(tile_size=0)->lz4",
               "bitshuffle(block_size=12)->lz4", "remove_background->lz4", "quantiser->tile_shuffle->lz4"]:
         assert oracle.can_be_built_from(p) and not sqy.pipeline_possible(p), p
     assert not sqy.pipeline_possible("quantiser->lz4", np.uint8)
