@@ -5,7 +5,7 @@ set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 P=gpurun_out/prof
-rm -rf $P; mkdir -p $P
+rm -rf $P; mkdir -p $P      # (delete your local gpurun_out/prof before fetching: gpurun merges, it does not remove stale files)
 B="bench.py"
 timeout -k 10 500 python3 $B > $P/bench_plain.log 2>&1 || exit 1
 tail -1 $P/bench_plain.log | cut -c1-400

@@ -21,20 +21,30 @@ src = os.path.join(ROOT, "gpurun_out", "prof")
 dst = os.path.join(ROOT, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-SHORT = {"sqy::lz4_chunks_kernel": "lz4_chunks", "void sqy::lz4_chunks_kernel<false, false>": "lz4_chunks", "void sqy::lz4_chunks_kernel<false, true>": "lz4_chunks_dense", "sqy::bitswap1_u16_tiles": "bitswap1_u16", "sqy::bitswap1_u16_regs": "bitswap1_u16",
-         "sqy::lz4_frame_gather_kernel": "lz4_frame_gather", "sqy::lz4_frame_scan_kernel": "lz4_frame_scan",
-         "sqy::bitswap1_u16_generic": "bitswap1_u16_generic"}
+SHORT = {"lz4_chunks_kernel<false, false>": "lz4_chunks", "lz4_chunks_kernel<false, true>": "lz4_chunks_dense",
+         "lz4_chunks_kernel<true, false>": "lz4_linked", "bitswap1_u16_regs": "bitswap1_u16",
+         "lz4_frame_gather_kernel": "lz4_frame_gather", "lz4_frame_scan_kernel": "lz4_frame_scan",
+         "bitswap1_u16_generic": "bitswap1_u16_generic", "lz4_dedupe_key_kernel": "lz4_dedupe_key",
+         "lz4_dedupe_verify_kernel": "lz4_dedupe_verify"}
+
+
+def is_ours(name):
+    return name.startswith("sqy::") or name.startswith("void sqy::")
 
 
 def short(name):
     base = name.split("(")[0]
+    if base.startswith("void "):
+        base = base[5:]
+    if base.startswith("sqy::"):
+        base = base[5:]
     return SHORT.get(base, base)
 
 
 rows = []
 for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
-        if r["Name"].startswith("sqy::"):
+        if is_ours(r["Name"]):
             rows.append(r)
 with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
     f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick  (defaults: 30 steps, 5 warm-up, 2 calls in flight)   (sqy:: kernels only)\n")
@@ -47,7 +57,7 @@ pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("pmc_fetch", "pmc_write"):
     for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
-            if r["Kernel_Name"].startswith("sqy::"):
+            if is_ours(r["Kernel_Name"]):
                 pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
 traffic = {}
 with open(os.path.join(dst, "%s_pmc_hbm.csv" % tag), "w") as f:
