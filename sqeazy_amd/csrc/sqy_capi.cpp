@@ -822,9 +822,9 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 uint32_t* frame_first = reinterpret_cast<uint32_t*>(blk + max_blocks * 16);
                 void* cand = blk + idx_bytes;
                 if (ws->csize.ensure(64)) return 1;
-                uint32_t* counts = static_cast<uint32_t*>(ws->csize.p);          // [0..2] index result, [4] decode error flag
+                uint32_t* counts = static_cast<uint32_t*>(ws->csize.p);          // [0..3] index result, [4] decode error flag
                 SQY_HIP(hipMemsetAsync(counts, 0, 32, stream));
-                uint32_t hc[3] = {0, 0, 100};
+                uint32_t hc[4] = {0, 0, 100, 0};
                 if (nchunks > 1) {
                     // chunked layout expected: rank the frame list in parallel
                     {
@@ -857,7 +857,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (!out) return 1;
                 {
                     ProfScope ps("lz4_frames_decode", stream, pend);
-                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, counts + 4, stream));
+                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream));
                 }
                 uint32_t bad = 0;
                 SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
@@ -962,8 +962,9 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (h.shape.size() != 3) return 1;
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
+                if (ws->lz4_scratch.ensure(sqy::diff3x3x1_decode_scratch_bytes(h.shape[2]))) return 1;
                 ProfScope ps("diff3x3x1_decode", stream, pend);
-                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, stream));
+                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, ws->lz4_scratch.p, stream));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }

@@ -89,9 +89,14 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
                                  uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream);
 // frame f decodes to out + f*frame_stride; every block decodes to at most block_bytes
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
-                                    uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t* errflag, hipStream_t stream);
+                                    uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
+                                    uint32_t* errflag, hipStream_t stream);
 hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int elem_size, hipStream_t stream);
-hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream);
+// scratch: diff3x3x1_decode_scratch_bytes(X) of device memory for the one-launch kernel (null: always one launch per frame);
+// synchronises the stream when the one-launch kernel is used
+uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X);
+hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
+                                   hipStream_t stream);
 hipError_t launch_quantiser_decode(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
 hipError_t launch_frame_scatter(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
 

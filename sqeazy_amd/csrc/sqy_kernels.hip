@@ -2132,7 +2132,7 @@ void bitshuffle_generic_kernel(const uint8_t* __restrict__ in, uint8_t* __restri
 
 // ------------------------------------------------------------------------------------------------
 // Frame index.  blk[i] = {offset of block i's data in the stream (lo, hi), size | raw flag << 31, block id in its frame},
-// frame_first[f] = index of the first block of frame f, counts[0..2] = #frames, #blocks, error code.
+// frame_first[f] = index of the first block of frame f, counts[0..3] = #frames, #blocks, error code, #compressed blocks.
 //
 // The frames of the chunked layout form a linked list through their size fields -- walking it is a pointer chase
 // through cold memory (one lane, about 0.75 us per frame: 3 ms for the 4096 frames of a 1 GiB stack).  The fast path
@@ -2281,6 +2281,7 @@ void lz4_frame_rank_kernel(const uint8_t* __restrict__ in, uint64_t n, const Fra
         const uint64_t off = c.pos + 11;
         blk[r] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), c.field, 0u);
         frame_first[r] = r;
+        if (!(c.field >> 31)) atomicAdd(&counts[3], 1u);                  // (compressed blocks: picks the decode kernel's ring)
     }
     if (tid == 0) { frame_first[L] = L; counts[0] = L; counts[1] = L; counts[2] = 0; }
 }
@@ -2295,7 +2296,7 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
     // after an end mark -- the next frame's 7 header bytes and its first block size: one dependent load per
     // single-block frame.
     uint64_t off = 0;
-    uint32_t nframes = 0, nblocks = 0, err = 0;
+    uint32_t nframes = 0, nblocks = 0, err = 0, ncomp = 0;
     auto load16 = [&](uint64_t o, uint32_t w[4]) {
         // bytes past the end of the stream read as 0xFF (never a valid header, size fields fail the bounds checks)
         if (o + 16 <= n) { const uint4 v = ld_u128(in + o); w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w; return; }
@@ -2327,6 +2328,7 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
             if (off + sz > n || nblocks >= max_blocks) { err = 4; break; }
             blk[nblocks] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), field, j);
             ++nblocks; ++j;
+            ncomp += !(field >> 31);
             off += sz + (block_checksum ? 4 : 0);
             load16(off, w);                                             // next size field or end mark, and 12 bytes behind it
             field = w[0];
@@ -2341,24 +2343,31 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
         ++nframes;
     }
     frame_first[nframes] = nblocks;
-    counts[0] = nframes; counts[1] = nblocks; counts[2] = err;
+    counts[0] = nframes; counts[1] = nblocks; counts[2] = err; counts[3] = ncomp;
 }
 
 // One wavefront per frame; the last 64 KiB of decoded output live in an LDS ring so that match copies (which may
 // overlap their own output and, in block-linked frames, reach into the previous block) never read global memory
 // the wave has just written.  Output leaves through the ring in 16-byte pieces.  The compressed bytes are parsed out of
-// a 4 KiB LDS stage refilled 64 x 16 B at a time (a token/length/offset byte costs an LDS broadcast read instead of a
+// a 3-4 KiB LDS stage refilled 64 x 16 B at a time (a token/length/offset byte costs an LDS broadcast read instead of a
 // dependent global load); stored blocks of single-block frames are copied straight from the stream to the output.
-constexpr uint32_t DEC_RING = 65536, DEC_IN = 4096;
+// DEC_RING = 64 KiB: every match source is in the ring (68 KiB of LDS per frame wave: 2 waves per CU) -- right when few frames
+// are compressed and each is a long chain of short sequences (latency-bound).  DEC_RING = 16 KiB (20 KiB: 8 waves per CU): for
+// streams with thousands of compressed frames (throughput-bound); a match that reaches further back than the ring reads its
+// source from the output buffer, where those bytes have long been flushed (one global round trip for such a match).
 
+template <uint32_t DEC_RING>
 __global__ __launch_bounds__(64)
 void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
                               uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes,
                               uint32_t* __restrict__ errflag)
 {
-    __shared__ __attribute__((aligned(16))) uint8_t dring_raw[DEC_RING + DEC_IN];   // static: 68 KiB (dynamic LDS stops at 64 KiB by default)
+    // stage of compressed bytes: 4 KiB, or 3 KiB beside the small ring (ring + stage + marks < 20 KiB: 8 waves per CU, not 7)
+    constexpr uint32_t DEC_IN = DEC_RING < 65536u ? 3072u : 4096u;
+    __shared__ __attribute__((aligned(16))) uint8_t dring_raw[DEC_RING + DEC_IN + 64];   // static: 68 KiB (dynamic LDS stops at 64 KiB by default)
     lds_u8* ring = (lds_u8*)dring_raw;
     lds_u8* stage = (lds_u8*)dring_raw + DEC_RING;
+    lds_u8* owner_mark = (lds_u8*)dring_raw + DEC_RING + DEC_IN;                   // 64 bytes: which sequence starts at an output byte
     const int lane = threadIdx.x;
     const uint32_t f = blockIdx.x;
     const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
@@ -2411,6 +2420,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         const uint32_t block_start = pos;
         uint32_t ip = 0;
         uint32_t sbase = 0, shi = 0;                               // stage holds block bytes [sbase, shi)
+        uint32_t one_by_one = 0, backoff = 8;                      // sequences to take singly before the next batch attempt
         auto fill = [&](uint32_t at) {
             sbase = at & ~15u;
 #pragma unroll
@@ -2434,9 +2444,27 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
 
         // match copy: `ml` bytes from `offset` bytes back, onto the ring at pos
         auto copy_match = [&](uint32_t offset, uint32_t ml) {
+            if (DEC_RING < 65536u && offset > DEC_RING) {
+                // behind the ring: those bytes left for global memory at least (offset - 1023) bytes ago.  Loads bypass the L1
+                // (sc1): the line may have been read before this wave's later stores to it.
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint8_t* const gsrc = out + frame_out;
+                for (uint32_t j = 0; j < ml; j += 64) {
+                    const uint32_t cnt = ml - j < 64 ? ml - j : 64;
+                    if (j + cnt + 2048u > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the source was written by this very match)
+                    uint32_t v = 0;
+                    if ((uint32_t)lane < cnt) v = __hip_atomic_load(gsrc + (pos - offset + (uint32_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                    wave_lds_sync();
+                    pos += cnt;
+                    flush(false);
+                }
+                return;
+            }
             // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
             // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
-            const uint32_t lmod = offset >= 64u ? (uint32_t)lane : (uint32_t)lane % offset;   // (an integer modulo is ~40 instructions)
+            // (an integer modulo is ~40 instructions: only when a step's source overlaps its destination)
+            const uint32_t lmod = (offset >= 64u || offset >= ml) ? (uint32_t)lane : (uint32_t)lane % offset;
             // long matches switch to 1 KiB steps (16 bytes per lane) once enough of the match is written: byte p also
             // equals byte p - off2 for any multiple off2 of the offset, and off2 >= 1024 makes a step's source disjoint
             // from its destination
@@ -2477,8 +2505,120 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             }
         };
         while (ip < sz) {
-            // a sequence whose header (token, a few literals, offset, match-length extension bytes) lies inside 16 bytes --
-            // nearly all of them -- is parsed out of ONE 16-byte broadcast read of the stage
+            // Batch: the next 64 compressed bytes, one per lane.  Every lane parses the sequence that WOULD start at its byte
+            // (token, literal count < 15, offset, at most one match-length extension byte); a scalar walk from lane 0 along
+            // the "next start" links marks the real starts; their output positions are one prefix sum; the output then comes
+            // 64 bytes per step (below).  A single wave's serial chain pays for every instruction, taken branch and LDS round
+            // trip: ~100 cycles per short sequence this way against ~800 when each is parsed and copied on its own.
+            if (one_by_one) --one_by_one;
+            else if (ip + 96u <= sz) {
+                need(ip, 96);
+                const uint32_t wi = ip - sbase + (uint32_t)lane;
+                const uint32_t tokb = stage[wi];
+                const uint32_t flit = tokb >> 4, fml = tokb & 15u;
+                const uint32_t w = lds_ld_u32(stage + wi + 1u + flit);            // offset, first extension byte
+                const uint32_t offs = w & 0xffffu, ext = (w >> 16) & 0xffu;
+                const bool okl = flit < 15u && (fml < 15u || ext < 255u);
+                const uint32_t mlen = fml < 15u ? fml + 4u : 19u + ext;           // <= 273
+                const uint32_t nxt = (uint32_t)lane + 3u + flit + (fml == 15u ? 1u : 0u);
+                const uint64_t okmask = ballot(okl);
+                uint64_t starts = 0;
+                uint32_t cur = 0;
+                while (cur < 64u && ((okmask >> cur) & 1ull)) {
+                    const uint32_t nx = lane_read(nxt, cur);
+                    if (nx > 64u) break;                                           // (a sequence in the batch ends inside the 64 bytes)
+                    starts |= 1ull << cur;
+                    cur = nx;
+                }
+                if (starts) {
+                    const bool is_start = (starts >> lane) & 1ull;
+                    uint32_t inc = is_start ? flit + mlen : 0u;                    // inclusive prefix sum of the output lengths
+                    inc += __builtin_amdgcn_update_dpp(0u, inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+                    inc += __builtin_amdgcn_update_dpp(0u, inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+                    inc += __builtin_amdgcn_update_dpp(0u, inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+                    inc += __builtin_amdgcn_update_dpp(0u, inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+                    inc += __builtin_amdgcn_update_dpp(0u, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
+                    inc += __builtin_amdgcn_update_dpp(0u, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
+                    const uint32_t total = lane_read(inc, 63);
+                    const uint32_t rel = inc - (is_start ? flit + mlen : 0u);      // output of this start begins at pos + rel
+                    const uint32_t base = pos;
+                    // refuse (to the one-by-one path below, which answers exactly): an impossible offset, a block that overflows
+                    const bool wrong = is_start && (offs == 0u || offs > base + rel + flit);
+                    const uint32_t info = flit | (mlen << 4) | (offs << 16);
+                    const uint32_t nst = (uint32_t)__builtin_popcountll(starts);
+                    const bool fits = !ballot(wrong) && base - block_start + total <= block_bytes;
+                    if (fits && total < 64u * nst) {
+                        // short sequences: the batch's output is produced 64 bytes per step, one byte per lane.  A lane finds
+                        // the sequence that owns its byte (marks at the first output byte of every sequence, running maximum),
+                        // then takes a literal from the stage or a match byte from `offset` back -- out of the ring, or out of
+                        // this very step (a lane further left; chains such as runs resolve by pointer doubling).
+                        const uint32_t wbase = ip - sbase;
+                        uint32_t carry = 0;
+                        for (uint32_t r0 = 0; r0 < total; r0 += 64u) {
+                            const uint32_t q = r0 + (uint32_t)lane;
+                            owner_mark[lane] = 0;
+                            wave_lds_sync();
+                            if (is_start && rel - r0 < 64u) owner_mark[rel - r0] = (uint8_t)(lane + 1);
+                            wave_lds_sync();
+                            uint32_t mx = owner_mark[lane];
+                            if (lane == 0 && mx == 0u) mx = carry;
+                            {
+                                uint32_t t;
+                                t = __builtin_amdgcn_update_dpp(0u, mx, 0x111, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                                t = __builtin_amdgcn_update_dpp(0u, mx, 0x112, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                                t = __builtin_amdgcn_update_dpp(0u, mx, 0x114, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                                t = __builtin_amdgcn_update_dpp(0u, mx, 0x118, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                                t = __builtin_amdgcn_update_dpp(0u, mx, 0x142, 0xa, 0xf, false); mx = mx > t ? mx : t;
+                                t = __builtin_amdgcn_update_dpp(0u, mx, 0x143, 0xc, 0xf, false); mx = mx > t ? mx : t;
+                            }
+                            carry = lane_read(mx, 63);
+                            const uint32_t s_of = mx - 1u;                           // (byte 0 of the batch belongs to lane 0's sequence)
+                            const uint32_t inf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_of * 4u), (int)info);
+                            const uint32_t rl = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_of * 4u), (int)rel);
+                            const uint32_t k = q - rl, fl = inf & 15u, off = inf >> 16;
+                            const bool active = q < total;
+                            const bool is_lit = k < fl;
+                            const uint32_t roundpos = base + r0;
+                            const uint32_t P = base + q - off;                       // match byte: equals the byte at frame position P
+                            const bool in_step = active && !is_lit && P >= roundpos;
+                            uint32_t val = 0;
+                            if (active && is_lit) val = stage[wbase + s_of + 1u + k];
+                            if (DEC_RING < 65536u) {
+                                const bool far = active && !is_lit && off > DEC_RING;      // behind the ring: flushed long ago
+                                if (ballot(far)) {
+                                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                                    if (far) val = __hip_atomic_load(out + frame_out + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                }
+                                if (active && !is_lit && !in_step && !far) val = ring[P & (DEC_RING - 1)];
+                            } else {
+                                if (active && !is_lit && !in_step) val = ring[P & (DEC_RING - 1)];
+                            }
+                            bool has = !in_step;
+                            uint32_t dep = in_step ? P - roundpos : (uint32_t)lane;     // < lane
+                            while (ballot(!has)) {
+                                const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(dep * 4u), (int)((has ? 0x80000000u : 0u) | (dep << 8) | val));
+                                if (!has) {
+                                    if (g >> 31) { val = g & 0xffu; has = true; }
+                                    else dep = (g >> 8) & 63u;
+                                }
+                            }
+                            if (active) ring[(roundpos + (uint32_t)lane) & (DEC_RING - 1)] = (uint8_t)val;
+                            wave_lds_sync();
+                            pos = roundpos + (total - r0 < 64u ? total - r0 : 64u);
+                            flush(false);
+                        }
+                        ip += cur;
+                        backoff = 8;
+                        continue;
+                    }
+                    // longer sequences: one at a time below is the better path (long copies, 1 KiB steps); look at the stream
+                    // again later -- ever later while it keeps looking like this
+                    if (fits) { one_by_one = backoff > nst ? backoff : nst; backoff = backoff < 256u ? backoff * 2u : 256u; }
+                }
+            }
+            // one sequence at a time: whatever the batch does not take (long literal runs, long matches, the block's tail).
+            // A sequence whose header (token, a few literals, offset, match-length extension bytes) lies inside 16 bytes
+            // is parsed out of ONE 16-byte broadcast read of the stage
             uint32_t token;
             bool have_token = false;
             if (ip + 16u <= sz) {
@@ -2505,13 +2645,14 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                         wave_lds_sync();
                         pos += flit;
                     }
+                    ip += 3u + flit;
+                    if (DEC_RING < 65536u && offset > DEC_RING) { copy_match(offset, ml); continue; }
                     const uint32_t lm = offset >= 64u ? (uint32_t)lane : (uint32_t)lane % offset;
                     uint32_t v = 0;
                     if ((uint32_t)lane < ml) v = ring[(pos - offset + lm) & (DEC_RING - 1)];
                     if ((uint32_t)lane < ml) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
                     wave_lds_sync();
                     pos += ml;
-                    ip += 3u + flit;
                     flush(false);
                     continue;
                 }
@@ -2652,15 +2793,19 @@ void bitswap1_decode_kernel(const T* __restrict__ in, T* __restrict__ out, uint6
     if (blockIdx.x == 0 && w < len - L) out[L + w] = in[L + w];
 }
 
-// inverse diff3x3x1, one launch per frame z (plane z-1 must be final): diff_scheme_impl.hpp:143-194
+// inverse diff3x3x1, voxels [r0, r1) of frame z (everything before them must be final): diff_scheme_impl.hpp:143-194.
+// The reference decodes in raster order and reads its own output: a rewritten voxel needs the 3x3 neighbourhood one frame back,
+// i.e. indices idx - frame - X - 1 .. idx - frame + X + 1.  Those lie in frame z-1 -- except for the last X + 1 voxels of a
+// frame, whose lower neighbours are the first voxels of frame z itself (they are rewritten only in geometries whose rows' reach
+// spills over the row end: Z - 2 > X - 1, or the single-row case).  The launcher therefore decodes such frames in two steps.
 template <typename T, typename ST>
 __global__ __launch_bounds__(256)
 void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t z, uint64_t length, uint64_t Y, uint64_t X,
-                                   uint64_t hx, uint64_t zlim, int single)
+                                   uint64_t hx, uint64_t zlim, int single, uint64_t r0, uint64_t r1)
 {
     const uint64_t frame = Y * X;
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= frame) return;
+    const uint64_t r = r0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= r1) return;
     const uint64_t idx = z * frame + r;
     T v = in[idx];
     if (z >= 1 && diff_touched(idx, length, Y, X, hx, zlim, single != 0)) {
@@ -2672,6 +2817,237 @@ void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out
         v = (T)((uint32_t)(int32_t)(ST)v + (uint32_t)sum / 9u);
     }
     out[idx] = v;
+}
+
+// inverse diff3x3x1 in ONE launch, for the geometry every real stack has (16-bit, Z <= X, rows of whole 16-byte vectors): a
+// rewritten voxel (1 <= z < zlim, 1 <= y <= Y-2, 1 <= x < Z-1) needs rows y-1..y+1 of the decoded frame z-1 only.  One workgroup
+// owns a strip of rows through all frames and keeps its decoded strip of the last frame in LDS; the two rows it lacks come from
+// the neighbouring strips.  Strips therefore run at most one frame apart: no grid-wide barrier, no launch per frame (255 launches
+// at ~10 us each were most of the 4 ms this stage took on a 256 x 2048^2 stack).
+// The hand-over decides the speed (a chain of dependent hand-overs, one per frame): an edge row travels through an exchange buffer
+// as 8-byte words of 3 voxels + a 16-bit frame tag, written and polled with agent-scope atomics (sc1: the neighbour may sit on
+// another XCD, whose L2 is not coherent with this one's for ordinary accesses).  The data carries its own "ready": one memory
+// round trip from store to use, instead of four with a counter published behind the data (drain the stores, publish, poll, load).
+// Two slots per edge, by frame parity: a strip overwrites a slot only after it has received the neighbour's next frame, which the
+// neighbour computed after reading that slot.  The buffer starts as all-ones (tag 0xffff is never used).
+// All workgroups must be resident at once: the launcher sizes the grid to the chip; a wait that does not end (the chip shared so
+// that some strips cannot start) raises the abort word behind the exchange buffer and the launcher falls back to per-frame kernels.
+constexpr uint32_t DIFFDEC_NT = 1024;         // threads per strip: the stage is instruction issue, so every SIMD gets 4 waves to interleave
+constexpr uint32_t DIFFDEC_MAXV = 2;          // 16-byte vectors per thread and frame
+constexpr uint32_t DIFFDEC_MAXQ = 2;          // exchange words per thread and halo row (rows of up to 6144 voxels)
+constexpr uint64_t DIFFDEC_MAX_STRIPS = 256;  // one workgroup per CU: all resident whatever else the stream's neighbours run
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global access in flight (vmcnt(0)),
+// here the frame fetched ahead and the stores of the frame before -- an HBM round trip per barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__global__ __launch_bounds__(DIFFDEC_NT)
+void diff3x3x1_decode_strips_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint32_t Z, uint32_t Y, uint32_t X, uint32_t hx,
+                                    uint32_t zlim, uint32_t R, uint64_t* __restrict__ exch, uint32_t* __restrict__ abort_word)
+{
+    typedef uint16_t T;
+    extern __shared__ uint4 diffdec_lds[];                       // (R + 2) rows of the decoded previous frame: row ry at (ry + 1) * X; + 2 rows
+    __shared__ uint32_t s_abort;
+    constexpr uint32_t V = 8;
+    T* const prev = reinterpret_cast<T*>(diffdec_lds);
+    const uint32_t tid = threadIdx.x, G = gridDim.x;
+    if (tid == 0) s_abort = 0;
+    // consecutive strips on one XCD (workgroups are dealt round-robin to the 8 XCDs): most hand-overs stay inside one die
+    uint32_t strip;
+    {
+        const uint32_t k = blockIdx.x % 8u, q = G / 8u, rem = G % 8u;
+        strip = k * q + (k < rem ? k : rem) + blockIdx.x / 8u;
+    }
+    const uint32_t y0 = strip * R, y1 = (y0 + R < Y) ? y0 + R : Y, nrows = y1 - y0;
+    const uint32_t XV = X / V, nvec = nrows * XV;
+    const uint32_t NQ = (X + 2u) / 3u;                           // exchange words per row
+    const uint64_t frame = (uint64_t)Y * X;
+    // exchange slot of (strip s, side, parity): side 0 = the strip's top row (for strip s-1), side 1 = its bottom row (for s+1)
+    auto slot = [&](uint32_t s_, uint32_t side, uint32_t par) { return exch + ((uint64_t)(s_ * 2u + side) * 2u + par) * NQ; };
+    uint32_t vry[DIFFDEC_MAXV], vx0[DIFFDEC_MAXV];
+#pragma unroll
+    for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
+        const uint32_t v = tid + i * DIFFDEC_NT;
+        vry[i] = v / XV;
+        vx0[i] = (v - vry[i] * XV) * V;
+    }
+    T* const edge_new = prev + (uint64_t)(R + 2) * X;              // the new frame's top and bottom row on their way out (2 rows)
+    auto publish = [&](uint32_t z_) {
+        const uint64_t tag = (uint64_t)(z_ + 1u) << 48;
+        uint64_t* const pt = slot(strip, 0u, z_ & 1u);
+        uint64_t* const pb = slot(strip, 1u, z_ & 1u);
+        const T* const top = edge_new, * const bot = edge_new + X;
+        for (uint32_t q = tid; q < NQ; q += DIFFDEC_NT) {
+            const uint32_t x = q * 3u;
+            const uint32_t x1 = x + 1u < X ? x + 1u : x, x2 = x + 2u < X ? x + 2u : x;
+            if (strip > 0) __hip_atomic_store(pt + q, (uint64_t)top[x] | ((uint64_t)top[x1] << 16) | ((uint64_t)top[x2] << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (strip + 1u < G) __hip_atomic_store(pb + q, (uint64_t)bot[x] | ((uint64_t)bot[x1] << 16) | ((uint64_t)bot[x2] << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    lds_barrier();
+    uint4 vout[DIFFDEC_MAXV];                                      // the decoded frame z-1, on its way out
+    uint4 vnext[DIFFDEC_MAXV];                                     // the stored frame z+1, fetched a frame ahead
+#pragma unroll
+    for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
+        if (tid + i * DIFFDEC_NT < nvec) vnext[i] = *reinterpret_cast<const uint4*>(in + (uint64_t)y0 * X + (uint64_t)(tid + i * DIFFDEC_NT) * V);
+    for (uint32_t z = 0; z < Z; ++z) {
+        uint4 vin[DIFFDEC_MAXV];
+#pragma unroll
+        for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) vin[i] = vnext[i];
+        // global traffic that nobody waits for -- the decoded frame z-1 out, the stored frame z+1 in -- is issued right AFTER the
+        // wait for the neighbours' rows: memory operations complete in order, so anything issued just before that wait would
+        // be waited for as well (an HBM round trip on the hand-over chain, every frame)
+        auto background_traffic = [&]() {
+            if (z > 0) {
+                T* const d = out + (uint64_t)(z - 1) * frame + (uint64_t)y0 * X;
+#pragma unroll
+                for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
+                    if (tid + i * DIFFDEC_NT < nvec) *reinterpret_cast<uint4*>(d + (uint64_t)(tid + i * DIFFDEC_NT) * V) = vout[i];
+            }
+            if (z + 1 < Z) {
+                const T* const src = in + (uint64_t)(z + 1) * frame + (uint64_t)y0 * X;
+#pragma unroll
+                for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
+                    if (tid + i * DIFFDEC_NT < nvec) vnext[i] = *reinterpret_cast<const uint4*>(src + (uint64_t)(tid + i * DIFFDEC_NT) * V);
+            }
+        };
+        const bool rewritten = z >= 1 && z < zlim && hx > 0;
+        if (rewritten) {
+            // rows y0-1 and y1 of the decoded frame z-1 (none at the volume's top and bottom: rows 0 and Y-1 are never rewritten)
+            const uint32_t want = z;                             // tag of frame z-1 (tags are frame + 1)
+            const uint64_t* const qa = slot(strip - 1u, 1u, (z - 1u) & 1u);
+            const uint64_t* const qb = slot(strip + 1u, 0u, (z - 1u) & 1u);
+            const bool has_a = strip > 0, has_b = strip + 1u < G;
+            uint64_t wa[DIFFDEC_MAXQ], wb[DIFFDEC_MAXQ];
+            uint32_t spins = 0;
+            bool ok = true;
+            for (;;) {
+                bool all = true;
+#pragma unroll
+                for (uint32_t i = 0; i < DIFFDEC_MAXQ; ++i) {               // (every load in flight before the first is looked at)
+                    const uint32_t q = tid + i * DIFFDEC_NT;
+                    if (q < NQ && has_a) wa[i] = __hip_atomic_load(qa + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (q < NQ && has_b) wb[i] = __hip_atomic_load(qb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+#pragma unroll
+                for (uint32_t i = 0; i < DIFFDEC_MAXQ; ++i) {
+                    const uint32_t q = tid + i * DIFFDEC_NT;
+                    if (q < NQ && has_a && (uint32_t)(wa[i] >> 48) != want) all = false;
+                    if (q < NQ && has_b && (uint32_t)(wb[i] >> 48) != want) all = false;
+                }
+                if (all) break;
+                if (++spins > (1u << 20) || ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
+                __builtin_amdgcn_s_sleep(1);
+            }
+            if (!ok) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
+            background_traffic();
+#pragma unroll
+            for (uint32_t i = 0; i < DIFFDEC_MAXQ; ++i) {
+                const uint32_t q = tid + i * DIFFDEC_NT;
+                if (q >= NQ) continue;
+#pragma unroll
+                for (uint32_t j = 0; j < 3; ++j) {
+                    const uint32_t x = q * 3u + j;
+                    if (x >= X) continue;
+                    if (has_a) prev[x] = (T)(wa[i] >> (16u * j));
+                    if (has_b) prev[(uint64_t)(nrows + 1) * X + x] = (T)(wb[i] >> (16u * j));
+                }
+            }
+            lds_barrier();
+            if (s_abort) return;                                 // (uniform: read after the barrier, never reset)
+            // one vector of 8 voxels: in + mean of the 3x3 neighbourhood one frame back (all sums mod 2^16, as the reference's
+            // pixel-typed accumulator).  Packed 16-bit arithmetic, two voxels per instruction: the stage is VALU work
+            // (one workgroup per CU), ~7 instructions a voxel this way against ~25 voxel by voxel.
+            auto decode_vec = [&](uint4& io, uint32_t ry, uint32_t x0) {
+                const uint32_t y = y0 + ry;
+                if (y < 1 || y + 2 > Y || x0 >= 1u + hx) return;                // row or vector without rewritten voxels
+                const T* const c = prev + (uint64_t)(ry + 1) * X + x0;          // this row of frame z-1; the rows above and below at -X, +X
+                const uint4 a = *reinterpret_cast<const uint4*>(c - X), b = *reinterpret_cast<const uint4*>(c), d = *reinterpret_cast<const uint4*>(c + X);
+                // (x0 = 0: column -1 belongs to voxel x = 0, never rewritten; x0 + V = X: to voxel X-1, never rewritten as Z <= X)
+                const uint32_t cm1 = x0 ? ((uint32_t)c[-(int64_t)X - 1] + c[-1] + c[(int64_t)X - 1]) & 0xffffu : 0u;
+                const uint32_t cp8 = x0 + V < X ? ((uint32_t)c[-(int64_t)X + V] + c[V] + c[X + V]) & 0xffffu : 0u;
+                typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+                auto pk_add = [](uint32_t p, uint32_t q) -> uint32_t {
+                    const u16x2 r = __builtin_bit_cast(u16x2, p) + __builtin_bit_cast(u16x2, q);
+                    return __builtin_bit_cast(uint32_t, r);
+                };
+                const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, dw[4] = {d.x, d.y, d.z, d.w};
+                uint32_t C[6];                                                 // column sums, two per word: C[k+1] = columns 2k, 2k+1
+                C[0] = cm1 << 16;
+                C[5] = cp8;
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) C[k + 1] = pk_add(pk_add(aw[k], bw[k]), dw[k]);
+                uint32_t w[4] = {io.x, io.y, io.z, io.w};
+                const bool whole = x0 >= 1u && x0 + V <= 1u + hx;               // every voxel of the vector is rewritten
+#pragma unroll
+                for (uint32_t k = 0; k < 4; ++k) {
+                    const uint32_t left = __builtin_amdgcn_alignbit(C[k + 1], C[k], 16);       // columns 2k-1, 2k
+                    const uint32_t right = __builtin_amdgcn_alignbit(C[k + 2], C[k + 1], 16);  // columns 2k+1, 2k+2
+                    const uint32_t S = pk_add(pk_add(left, C[k + 1]), right);
+                    // x / 9 = (x * 58255) >> 19 for x < 2^16
+                    uint32_t m_lo = ((S & 0xffffu) * 58255u) >> 19, m_hi = ((S >> 16) * 58255u) >> 19;
+                    if (!whole) {
+                        const uint32_t xl = x0 + 2u * k, xh = xl + 1u;
+                        if (xl < 1u || xl >= 1u + hx) m_lo = 0;
+                        if (xh >= 1u + hx) m_hi = 0;
+                    }
+                    w[k] = pk_add(w[k], m_lo | (m_hi << 16));
+                }
+                io = make_uint4(w[0], w[1], w[2], w[3]);
+            };
+            // the strip's edge rows first: they go to the neighbours (staged in LDS, repacked into exchange words) while the
+            // rows in between are still being computed -- the hand-over chain sees two rows of work per frame, not the strip
+            const bool publish_now = z + 1 < zlim;
+#pragma unroll
+            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
+                if (tid + i * DIFFDEC_NT >= nvec) continue;
+                const bool top = vry[i] == 0, bot = vry[i] + 1 == nrows;
+                if (!top && !bot) continue;
+                decode_vec(vin[i], vry[i], vx0[i]);
+                if (publish_now) {
+                    if (top) *reinterpret_cast<uint4*>(edge_new + vx0[i]) = vin[i];
+                    if (bot) *reinterpret_cast<uint4*>(edge_new + X + vx0[i]) = vin[i];
+                }
+            }
+            if (publish_now) {
+                lds_barrier();
+                publish(z);
+            }
+#pragma unroll
+            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
+                if (tid + i * DIFFDEC_NT >= nvec) continue;
+                if (vry[i] == 0 || vry[i] + 1 == nrows) continue;
+                decode_vec(vin[i], vry[i], vx0[i]);
+            }
+            lds_barrier();                                                   // every read of frame z-1 is done
+        } else if (z + 1 < zlim && hx > 0) {
+            background_traffic();
+            // frame 0 (stored as it is): its edge rows go out all the same
+#pragma unroll
+            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
+                if (tid + i * DIFFDEC_NT >= nvec) continue;
+                if (vry[i] == 0) *reinterpret_cast<uint4*>(edge_new + vx0[i]) = vin[i];
+                if (vry[i] + 1 == nrows) *reinterpret_cast<uint4*>(edge_new + X + vx0[i]) = vin[i];
+            }
+            lds_barrier();
+            publish(z);
+        } else
+            background_traffic();
+        // the decoded strip: to LDS for the next frame, and (a frame later) to the output
+        if (z + 1 < zlim && hx > 0) {
+#pragma unroll
+            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
+                if (tid + i * DIFFDEC_NT < nvec) *reinterpret_cast<uint4*>(prev + (uint64_t)(vry[i] + 1) * X + vx0[i]) = vin[i];
+        }
+#pragma unroll
+        for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) vout[i] = vin[i];
+    }
+    if (Z > 0) {
+        T* const d = out + (uint64_t)(Z - 1) * frame + (uint64_t)y0 * X;
+#pragma unroll
+        for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
+            if (tid + i * DIFFDEC_NT < nvec) *reinterpret_cast<uint4*>(d + (uint64_t)(tid + i * DIFFDEC_NT) * V) = vout[i];
+    }
 }
 
 // inverse quantiser: out[i] = lut_decode[in[i]]
@@ -3066,11 +3442,18 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
 }
 
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
-                                    uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t* errflag, hipStream_t stream)
+                                    uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
+                                    uint32_t* errflag, hipStream_t stream)
 {
     if (nframes == 0) return hipSuccess;
-    hipLaunchKernelGGL(lz4_frames_decode_kernel, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
-                       out_bytes, frame_stride, block_bytes, errflag);
+    // more compressed blocks than the 64 KiB-ring kernel keeps resident (2 per CU) plus half a round: the small ring's four-fold
+    // occupancy wins; below that the frames are few and long, and every match served from LDS wins
+    if (ncompressed > 768u && nframes > 768u)
+        hipLaunchKernelGGL(lz4_frames_decode_kernel<16384>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
+                           out_bytes, frame_stride, block_bytes, errflag);
+    else
+        hipLaunchKernelGGL(lz4_frames_decode_kernel<65536>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
+                           out_bytes, frame_stride, block_bytes, errflag);
     {   // stored blocks of single-block frames (a block never exceeds block_bytes)
         const uint32_t slices = (uint32_t)((block_bytes + DEC_COPY_SLICE - 1) / DEC_COPY_SLICE);
         if (slices == 0 || (uint64_t)nframes * slices > 0x7fffffffull) return hipErrorInvalidValue;
@@ -3093,7 +3476,11 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
     return hipGetLastError();
 }
 
-hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream)
+// scratch for the one-launch kernel: 256 strips x 2 edges x 2 frame parities x ceil(X / 3) words, and the abort word
+uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X) { return DIFFDEC_MAX_STRIPS * 4 * ((X + 2) / 3) * 8 + 64; }
+
+hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
+                                   hipStream_t stream)
 {
     const uint64_t length = Z * Y * X, frame = Y * X;
     if (length == 0) return hipSuccess;
@@ -3101,14 +3488,49 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
     const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
     const int single = (noff == 1);
     const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
-    const unsigned blocks = (unsigned)((frame + 255) / 256);
+    // one launch for the usual geometry (see diff3x3x1_decode_strips_kernel); synchronises the stream to learn whether it ran through
+    // (16-bit only: the reference defines the 8-bit stage for extents <= 127 voxels)
+    if (scratch && elem_size == 2 && !single && noff > 0 && Z <= X && X % 8 == 0 && Y < (1ull << 31) && X < (1ull << 31) &&
+        ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+        const uint64_t R = (Y + DIFFDEC_MAX_STRIPS - 1) / DIFFDEC_MAX_STRIPS;
+        const uint64_t G = (Y + R - 1) / R;
+        const uint64_t lds = (R + 4) * X * 2;             // the strip of the last frame + 2 halo rows + 2 rows on their way out
+        const uint64_t NQ = (X + 2) / 3;
+        if (lds <= 65536 && R * (X / 8) <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXV && NQ <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXQ) {
+            const uint64_t exch_bytes = G * 4 * NQ * 8;
+            uint32_t* const abort_word = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + exch_bytes);
+            hipError_t e = hipMemsetAsync(scratch, 0xff, exch_bytes, stream);
+            if (e != hipSuccess) return e;
+            e = hipMemsetAsync(abort_word, 0, 64, stream);
+            if (e != hipSuccess) return e;
+            hipLaunchKernelGGL(diff3x3x1_decode_strips_kernel, dim3((unsigned)G), dim3(DIFFDEC_NT), (size_t)lds, stream, (const uint16_t*)in,
+                               (uint16_t*)out, (uint32_t)Z, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)R,
+                               static_cast<uint64_t*>(scratch), abort_word);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            uint32_t aborted = 0;
+            e = hipMemcpyAsync(&aborted, abort_word, sizeof(aborted), hipMemcpyDeviceToHost, stream);
+            if (e != hipSuccess) return e;
+            e = hipStreamSynchronize(stream);
+            if (e != hipSuccess) return e;
+            if (!aborted) return hipSuccess;
+        }
+    }
+    // per frame; the last X + 1 voxels of a frame read the frame's own first voxels when rows spill over (see the kernel)
+    const bool spills = single || hx + 1 >= X;      // (hx = X-1: voxel X-1 of row Y-2 already reads voxel 0 of its own frame)
     for (uint64_t z = 0; z < Z; ++z) {
-        if (elem_size == 2)
-            hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint16_t, int16_t>), dim3(blocks), dim3(256), 0, stream, (const uint16_t*)in,
-                               (uint16_t*)out, z, length, Y, X, hx, zlim, single);
-        else
-            hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint8_t, int8_t>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)in,
-                               (uint8_t*)out, z, length, Y, X, hx, zlim, single);
+        const uint64_t split = (spills && frame > X + 1) ? frame - X - 1 : frame;
+        for (int part = 0; part < 2; ++part) {
+            const uint64_t r0 = part ? split : 0, r1 = part ? frame : split;
+            if (r0 >= r1) continue;
+            const unsigned blocks = (unsigned)((r1 - r0 + 255) / 256);
+            if (elem_size == 2)
+                hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint16_t, int16_t>), dim3(blocks), dim3(256), 0, stream, (const uint16_t*)in,
+                                   (uint16_t*)out, z, length, Y, X, hx, zlim, single, r0, r1);
+            else
+                hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint8_t, int8_t>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)in,
+                                   (uint8_t*)out, z, length, Y, X, hx, zlim, single, r0, r1);
+        }
     }
     return hipGetLastError();
 }

@@ -63,6 +63,51 @@ def test_decode_long_matches_and_overlaps(sqy, oracle):
         assert rc == 0 and np.array_equal(back, vol)
 
 
+def _frame_with_far_matches(rng, n, kind):
+    if kind == 0:                                              # one long period beyond 16 KiB: match length > offset, source behind the ring
+        p = int(rng.integers(16385, 60000))
+        return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
+    if kind == 1:                                              # the same with 1 % noise: many separate far matches
+        p = int(rng.integers(16400, 17500))
+        a = np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n].copy()
+        m = rng.random(n) < 0.01
+        a[m] = rng.integers(0, 256, int(m.sum()), dtype=np.uint8)
+        return a
+    if kind == 2:
+        return rng.integers(0, 256, n, dtype=np.uint8)         # stays raw
+    if kind == 3:
+        a = np.zeros(n, np.uint8)
+        idx = rng.integers(0, n, n // 40)
+        a[idx] = rng.integers(0, 256, idx.size, dtype=np.uint8)
+        return a
+    if kind == 4:                                              # slices copied from 16 KiB .. 64 KiB back, literals in between
+        a = rng.integers(0, 256, n, dtype=np.uint8)
+        pos = 40000 if n > 80000 else n // 3
+        while pos < n - 4000:
+            ln = int(rng.integers(4, 3000))
+            back = int(rng.integers(16384, min(pos, 65535) + 1)) if pos > 16384 else pos
+            a[pos:pos + ln] = a[pos - back:pos - back + ln]
+            pos += ln + int(rng.integers(0, 40))
+        return a
+    p = int(rng.integers(1, 300))
+    return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
+
+
+@pytest.mark.parametrize("pipeline,frame_bytes,nframes", [("lz4", 256 << 10, 800), ("lz4(blocksize_kb=64)", 64 << 10, 1100),
+                                                         ("lz4(blocksize_kb=64,framestep_kb=256)", 256 << 10, 780)])
+def test_decode_many_frames_small_ring(sqy, oracle, pipeline, frame_bytes, nframes):
+    """more than 768 compressed frames select the 16 KiB-ring decode kernel: matches that reach further back than the ring
+    (up to 64 KiB, also across the blocks of a multi-block frame, also longer than their offset) come from the output buffer"""
+    rng = np.random.default_rng(nframes)
+    d = np.concatenate([_frame_with_far_matches(rng, frame_bytes, f % 6) for f in range(nframes)] + [rng.integers(0, 256, 777, dtype=np.uint8)])
+    vol = d.reshape(1, 1, -1)
+    blob = oracle.pipeline_encode(pipeline, vol)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+    rc, mine = sqy.encode(pipeline, vol, nthreads=2)
+    assert rc == 0 and mine == blob
+
+
 def test_decode_serial_layout_from_liblz4(sqy, oracle):
     """a blob in the reference's nthreads=1 layout (ONE block-linked frame, made with liblz4 itself) decodes too"""
     from oracle import ref
@@ -187,3 +232,38 @@ def test_decode_composite_return_codes(sqy, oracle):
     blob[h["size"] + 1] ^= 0xff
     assert sqy.decode(bytes(blob))[0] == 1
     assert sqy.decode(b"no header here at all, just text" * 10)[0] == 1
+
+
+@pytest.mark.parametrize("shape,dtype", [((2, 3, 5), np.uint16), ((5, 3, 2), np.uint16), ((2, 3, 2), np.uint8), ((40, 5, 4), np.uint16),
+                                         ((30, 4, 8), np.uint8), ((12, 6, 3), np.uint16), ((70, 7, 16), np.uint16), ((9, 3, 3), np.uint8),
+                                         ((33, 9, 15), np.uint16), ((18, 4, 17), np.uint8)])
+def test_diff_decode_rows_that_spill(sqy, oracle, shape, dtype):
+    """geometries in which a row's rewritten span runs over the row end (Z - 2 > X - 1, or the single-row case): the last voxels
+    of a frame then depend on the first voxels of the SAME decoded frame"""
+    if dtype == np.uint8 and max(shape) > 100:
+        pytest.skip("8-bit diff: small extents only")
+    rng = np.random.default_rng(sum(shape))
+    for trial in range(3):
+        vol = rng.integers(0, 65536 if dtype == np.uint16 else 256, shape).astype(dtype)
+        try:
+            blob = oracle.pipeline_encode("diff3x3x1->lz4", vol)
+        except ValueError:
+            pytest.skip("shape outside what the reference defines for diff3x3x1")
+        assert np.array_equal(oracle.pipeline_decode(blob), vol)
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, vol), (shape, trial)
+        rc, mine = sqy.encode("diff3x3x1->lz4", vol, nthreads=2)
+        assert rc == 0 and mine == blob
+
+
+@pytest.mark.parametrize("shape,dtype", [((9, 300, 64), np.uint16), ((64, 17, 64), np.uint16), ((3, 700, 128), np.uint16), ((20, 3, 64), np.uint16),
+                                         ((16, 4, 128), np.uint16), ((5, 600, 8), np.uint16), ((24, 300, 24), np.uint16), ((31, 513, 192), np.uint16), ((50, 40, 2048), np.uint16), ((128, 3, 128), np.uint16),
+                                         ((2, 64, 64), np.uint16), ((7, 2100, 64), np.uint16), ((64, 256, 64), np.uint16), ((33, 1030, 256), np.uint16)])
+def test_diff_decode_one_launch_kernel(sqy, oracle, shape, dtype):
+    """16-bit, Z <= X, X a multiple of 8: the strip kernel (one launch, neighbour strips hand their edge rows over)"""
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.integers(0, 65536 if dtype == np.uint16 else 256, shape).astype(dtype)
+    blob = oracle.pipeline_encode("diff3x3x1->bitswap1->lz4", vol)
+    for _ in range(2):
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, vol), shape
