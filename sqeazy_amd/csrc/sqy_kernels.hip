@@ -1249,48 +1249,87 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 ml = fwl;                                                 // settled by the speculative compares
             } else {
                 ml = fwl;                                                 // bytes already known equal; continue from there
-                for (;;) {
-                    uint32_t got[4];
-                    // uniform test: both operands of the whole 4 KiB round resident in the ring and clear of matchlimit
-                    const uint32_t qa = q + ml, ra = r + ml;
-                    const bool round_in_lds = ra >= w.wlo && qa + 4096u + 16u <= w.hi_valid() && qa + 4096u + 16u <= matchlimit;
-                    if (round_in_lds) {
+                // rounds of 64 lanes x 16 bytes per KiB.  Out of the ring as far as it is resident (at least AHEAD bytes beyond
+                // ip: matches of up to ~2 KiB never touch global memory); beyond that both sides stream from global memory,
+                // 4 KiB per round and the next round's loads in flight while this one is looked at (a zero run of 256 KiB is
+                // 64 rounds: 64 dependent HBM round trips one after the other, or one and a stream behind it); the last
+                // bytes in front of matchlimit take the exact byte-wise path.
+                auto settle = [&](const uint32_t (&got)[4], uint32_t T) -> bool {   // adds the round's equal bytes to ml; true = mismatch found
 #pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const uint32_t d = (uint32_t)t * 1024u + (uint32_t)lane * 16u;
-                            got[t] = first_diff16(w.lds128(qa + d), w.lds128(ra + d));
-                            if (t == 0) {
-                                // most matches end inside the first KiB: look at it before paying for the other three
-                                if (ballot(got[0] != 16u)) { got[1] = got[2] = got[3] = 0; break; }
-                            }
-                        }
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            const uint32_t a = qa + (uint32_t)t * 1024u + (uint32_t)lane * 16u;
-                            const uint32_t room = a < matchlimit ? matchlimit - a : 0u;
-                            const uint32_t maxlen = room < 16u ? room : 16u;
-                            got[t] = (maxlen == 0) ? 0u : common16(w, a, a - q + r, maxlen);
-                            if (t == 0) {
-                                if (ballot(got[0] != 16u)) { got[1] = got[2] = got[3] = 0; break; }
-                            }
-                        }
-                    }
-                    bool stop = false;
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) {
-                        if (!stop) {
+                    for (uint32_t t = 0; t < 4; ++t) {
+                        if (t < T) {
                             const uint64_t nf = ballot(got[t] != 16u);
                             if (nf) {
                                 const uint32_t l = ctz64(nf);
                                 ml += l * 16u + lane_read(got[t], l);
-                                stop = true;
-                            } else {
-                                ml += 1024u;
+                                return true;
                             }
+                            ml += 1024u;
                         }
                     }
-                    if (stop) break;
+                    return false;
+                };
+                const uint32_t src_end = matchlimit < (w.n & ~15u) ? matchlimit : (w.n & ~15u);   // 16-byte loads stay below this
+                for (;;) {
+                    uint32_t got[4] = {0, 0, 0, 0};
+                    const uint32_t qa = q + ml, ra = r + ml;
+                    const uint32_t lds_end = w.hi_valid() < matchlimit ? w.hi_valid() : matchlimit;
+                    if (ra >= w.wlo && qa + 1024u + 16u <= lds_end) {
+                        // whole KiBs resident on both sides (ra < qa)
+                        uint32_t T = (lds_end - 16u - qa) >> 10;
+                        T = T < 4u ? T : 4u;
+                        got[0] = first_diff16(w.lds128(qa + (uint32_t)lane * 16u), w.lds128(ra + (uint32_t)lane * 16u));
+                        if (T > 1u && !ballot(got[0] != 16u)) {              // most matches end inside the first KiB: look at it before the others
+#pragma unroll
+                            for (uint32_t t = 1; t < 4; ++t)
+                                if (t < T) got[t] = first_diff16(w.lds128(qa + t * 1024u + (uint32_t)lane * 16u), w.lds128(ra + t * 1024u + (uint32_t)lane * 16u));
+                        } else
+                            T = 1;
+                        if (settle(got, T)) break;
+                        continue;
+                    }
+                    if (qa + 4096u + 16u <= src_end) {
+                        // streaming: round k+1 is loaded while round k is compared
+                        uint4 ca[4], cb[4], na[4], nb[4];
+#pragma unroll
+                        for (uint32_t t = 0; t < 4; ++t) {
+                            ca[t] = glb_ld_u128(w.src + qa + t * 1024u + (uint32_t)lane * 16u);
+                            cb[t] = glb_ld_u128(w.src + ra + t * 1024u + (uint32_t)lane * 16u);
+                        }
+                        bool stop = false;
+                        uint32_t at = qa;                                        // ip-side position of the round in ca/cb
+                        for (;;) {
+                            const bool more = at + 8192u + 16u <= src_end;       // another whole round behind this one
+                            if (more) {
+#pragma unroll
+                                for (uint32_t t = 0; t < 4; ++t) {
+                                    na[t] = glb_ld_u128(w.src + at + 4096u + t * 1024u + (uint32_t)lane * 16u);
+                                    nb[t] = glb_ld_u128(w.src + (at - qa + ra) + 4096u + t * 1024u + (uint32_t)lane * 16u);
+                                }
+                            }
+#pragma unroll
+                            for (uint32_t t = 0; t < 4; ++t) got[t] = first_diff16(ca[t], cb[t]);
+                            if (settle(got, 4u)) { stop = true; break; }
+                            if (!more) break;
+                            at += 4096u;
+#pragma unroll
+                            for (uint32_t t = 0; t < 4; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
+                        }
+                        if (stop) break;
+                        continue;
+                    }
+                    // the tail: lanes stop at matchlimit, positions without 16 readable bytes compare byte by byte
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        const uint32_t a = qa + (uint32_t)t * 1024u + (uint32_t)lane * 16u;
+                        const uint32_t room = a < matchlimit ? matchlimit - a : 0u;
+                        const uint32_t maxlen = room < 16u ? room : 16u;
+                        got[t] = (maxlen == 0) ? 0u : common16(w, a, a - q + r, maxlen);
+                        if (t == 0) {
+                            if (ballot(got[0] != 16u)) { got[1] = got[2] = got[3] = 0; break; }
+                        }
+                    }
+                    if (settle(got, 4u)) break;
                 }
                 ml = sgpr(ml);
             }
