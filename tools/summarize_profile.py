@@ -77,6 +77,25 @@ sha = open(sha_file).read().strip() if os.path.exists(sha_file) else None
 json.dump({"library_sha256": sha, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py --quick",
            "hbm_bytes": "(2 * FETCH_SIZE + WRITE_SIZE) * 1024 per launch, mean over launches", "traffic": traffic},
           open(os.path.join(dst, "%s_pmc_hbm.json" % tag), "w"), indent=1, sort_keys=True)
+# wave-level counters (what the waves wait for), summed over the XCDs' instances of a launch, mean over launches
+sq = collections.defaultdict(lambda: collections.defaultdict(list))
+for name in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
+    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+        per_launch = collections.defaultdict(float)
+        for r in csv.DictReader(open(f)):
+            if is_ours(r["Kernel_Name"]):
+                per_launch[(short(r["Kernel_Name"]), r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+        for (k, _, c), v in per_launch.items():
+            sq[k][c].append(v)
+if sq:
+    names = sorted({c for k in sq for c in sq[k]})
+    with open(os.path.join(dst, "%s_pmc_sq.csv" % tag), "w") as f:
+        f.write("# rocprofv3 --pmc <SQ counters> --kernel-trace -- python3 bench.py --quick (three passes); per launch, mean over launches\n")
+        w = csv.writer(f)
+        w.writerow(["kernel"] + names)
+        for k in sorted(sq):
+            w.writerow([k] + ["%.0f" % (sum(sq[k][c]) / len(sq[k][c])) if sq[k][c] else "" for c in names])
+    print(open(os.path.join(dst, "%s_pmc_sq.csv" % tag)).read())
 for n in ("bench_plain.log", "bench_trace.log"):
     p = os.path.join(src, n)
     if os.path.exists(p):
