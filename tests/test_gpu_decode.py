@@ -267,3 +267,46 @@ def test_diff_decode_one_launch_kernel(sqy, oracle, shape, dtype):
     for _ in range(2):
         rc, back = sqy.decode(blob)
         assert rc == 0 and np.array_equal(back, vol), shape
+
+
+def _medium_runs(rng, n):
+    """short literal bursts between runs of 8..300 bytes with periods 1..70: matches of 4..300 bytes at small offsets,
+    i.e. output bytes that depend on bytes produced a few lanes earlier in the same 64-byte step of the batch decoder"""
+    out = np.empty(n + 400, np.uint8)
+    pos = 0
+    while pos < n:
+        lit = int(rng.integers(0, 12))
+        out[pos:pos + lit] = rng.integers(0, 256, lit, dtype=np.uint8)
+        pos += lit
+        p = int(rng.integers(1, 71))
+        run = int(rng.integers(8, 300))
+        pat = rng.integers(0, 256, p, dtype=np.uint8)
+        out[pos:pos + run] = np.tile(pat, run // p + 1)[:run]
+        pos += run
+    return out[:n]
+
+
+@pytest.mark.parametrize("seed,pipeline", [(1, "lz4"), (2, "lz4"), (3, "lz4(blocksize_kb=64)"), (4, "lz4(blocksize_kb=64,framestep_kb=256)")])
+def test_decode_batches_with_dependencies_inside_a_step(sqy, oracle, seed, pipeline):
+    rng = np.random.default_rng(seed)
+    n = (3 << 20) + 12345 if seed < 3 else 900 * (64 << 10) + 77          # the second kind: > 768 frames -> the 16 KiB-ring kernel
+    d = _medium_runs(rng, n)
+    vol = d.reshape(1, 1, -1)
+    blob = oracle.pipeline_encode(pipeline, vol)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+    if seed == 1:                                                          # and the serial layout: one wave, 13 linked blocks
+        blob1 = oracle.pipeline_encode(pipeline, vol, nthreads=1)
+        rc, back = sqy.decode(blob1)
+        assert rc == 0 and np.array_equal(back, vol)
+
+
+@pytest.mark.parametrize("shape", [(2, 5000, 64), (3, 300, 4096), (5, 40, 8192), (64, 2049, 64), (17, 1023, 520), (8, 257, 8), (100, 33, 104)])
+def test_diff_decode_one_launch_kernel_strip_geometries(sqy, oracle, shape):
+    """strips of 1..20 rows, the last one short, rows from 16 bytes to 8 KiB; X = 8192 exceeds the exchange words a thread
+    takes and uses the per-frame kernels"""
+    rng = np.random.default_rng(sum(shape))
+    vol = rng.integers(0, 65536, shape).astype(np.uint16)
+    blob = oracle.pipeline_encode("diff3x3x1->lz4", vol)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol), shape
