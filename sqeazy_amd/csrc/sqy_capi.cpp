@@ -183,6 +183,8 @@ struct Stager {
 struct Context {
     Workspace ws;
     hipStream_t stream = nullptr;       // used when the caller brings no stream (host-pointer entry points)
+    hipStream_t side = nullptr;         // decode: stored frames are copied here while the compressed ones are decoded
+    hipEvent_t fork = nullptr, join = nullptr;
     std::vector<PendingEvent> pending;
     Stager stager;
     bool busy = false;
@@ -208,6 +210,9 @@ struct ContextLease {
                 std::unique_ptr<Context> c(new Context());
                 if (hipHostMalloc(&c->ws.pinned, 4096, hipHostMallocDefault) != hipSuccess) return;
                 if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return;
+                if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return;
+                if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) return;
+                if (hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) return;
                 ctx = c.get();
                 g_pool[dev].push_back(std::move(c));
                 break;
@@ -235,9 +240,11 @@ struct ContextLease {
 struct DrainOnExit {
     hipStream_t s;
     std::vector<PendingEvent>* pending;
+    hipStream_t side = nullptr;         // the context's side stream (decode)
     ~DrainOnExit()
     {
         (void)hipStreamSynchronize(s);
+        if (side) (void)hipStreamSynchronize(side);
         if (!pending->empty()) {
             if (g_prof_on.load()) prof_collect(*pending);
             else { for (PendingEvent& p : *pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); } pending->clear(); }
@@ -287,7 +294,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
 
     Workspace* ws = &cx.ws;
     std::vector<PendingEvent>* pend = &cx.pending;
-    DrainOnExit drain{stream, pend};
+    DrainOnExit drain{stream, pend, cx.side};
 
     // ---- walk the stages ----
     const uint8_t* cur = static_cast<const uint8_t*>(d_src);
@@ -733,7 +740,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
     const uint8_t* d_src = static_cast<const uint8_t*>(d_src_v);
     Workspace* ws = &cx.ws;
     std::vector<PendingEvent>* pend = &cx.pending;
-    DrainOnExit drain{stream, pend};
+    DrainOnExit drain{stream, pend, cx.side};
 
     // header: fetch a prefix of the blob, grow until the delimiter is inside
     std::vector<char> head;
@@ -857,7 +864,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (!out) return 1;
                 {
                     ProfScope ps("lz4_frames_decode", stream, pend);
-                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream));
+                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, cx.side, cx.fork, cx.join));
                 }
                 uint32_t bad = 0;
                 SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));

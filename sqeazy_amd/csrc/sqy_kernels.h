@@ -90,7 +90,8 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
 // frame f decodes to out + f*frame_stride; every block decodes to at most block_bytes
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
-                                    uint32_t* errflag, hipStream_t stream);
+                                    uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream = nullptr, hipEvent_t fork = nullptr,
+                                    hipEvent_t join = nullptr);
 hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int elem_size, hipStream_t stream);
 // scratch: diff3x3x1_decode_scratch_bytes(X) of device memory for the one-launch kernel (null: always one launch per frame);
 // synchronises the stream when the one-launch kernel is used

@@ -2812,11 +2812,11 @@ void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* 
 // inverse bitswap1 (bitplane_reorder_scalar.hpp:81-116): one thread per group of W voxels
 template <typename T>
 __global__ __launch_bounds__(256)
-void bitswap1_decode_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t len, uint64_t seg)
+void bitswap1_decode_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t len, uint64_t seg, uint64_t w0)
 {
     constexpr uint32_t W = sizeof(T) * 8;
     const uint64_t L = seg * W;
-    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t w = w0 + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w < seg) {
         uint32_t plane[W];
 #pragma unroll
@@ -2829,7 +2829,44 @@ void bitswap1_decode_kernel(const T* __restrict__ in, T* __restrict__ out, uint6
             out[w * W + j] = (T)v;
         }
     }
-    if (blockIdx.x == 0 && w < len - L) out[L + w] = in[L + w];
+    if (blockIdx.x == 0 && threadIdx.x < len - L) out[L + threadIdx.x] = in[L + threadIdx.x];
+}
+
+// 16-bit, whole tiles of 8192 voxels: the mirror image of bitswap1_u16_regs.  A lane takes 8 consecutive words of every plane
+// (16 coalesced 1 KiB loads per wave), transposes them two groups at a time (the bit transpose is its own inverse) and writes its
+// 128 voxels as 16 x 16 B.  (The generic kernel moves 2 bytes per lane and instruction.)
+__global__ __launch_bounds__(256)
+void bitswap1_decode_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words)
+{
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
+    for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
+        uint32_t pl[16][4];
+#pragma unroll
+        for (int b = 0; b < 16; ++b) {
+            const v4u* src = reinterpret_cast<const v4u*>(in + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
+            const v4u t = __builtin_nontemporal_load(src + lane);
+            pl[b][0] = t.x; pl[b][1] = t.y; pl[b][2] = t.z; pl[b][3] = t.w;
+        }
+        v4u* dst = reinterpret_cast<v4u*>(out + tile * BSW_TILE_VOX) + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint32_t r[16];
+#pragma unroll
+            for (int b = 0; b < 16; ++b) r[b] = pl[b][q];
+            transpose16x16_pairs(r);                                      // r[i] = voxel 15-i of group A | of group B << 16
+            uint32_t ga[8], gb[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                ga[k] = __builtin_amdgcn_perm(r[14 - 2 * k], r[15 - 2 * k], 0x05040100u);
+                gb[k] = __builtin_amdgcn_perm(r[14 - 2 * k], r[15 - 2 * k], 0x07060302u);
+            }
+            const v4u a0 = {ga[0], ga[1], ga[2], ga[3]}, a1 = {ga[4], ga[5], ga[6], ga[7]};
+            const v4u b0 = {gb[0], gb[1], gb[2], gb[3]}, b1 = {gb[4], gb[5], gb[6], gb[7]};
+            dst[4 * q] = a0; dst[4 * q + 1] = a1; dst[4 * q + 2] = b0; dst[4 * q + 3] = b1;
+        }
+    }
 }
 
 // inverse diff3x3x1, voxels [r0, r1) of frame z (everything before them must be final): diff_scheme_impl.hpp:143-194.
@@ -3482,9 +3519,20 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
 
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
-                                    uint32_t* errflag, hipStream_t stream)
+                                    uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join)
 {
     if (nframes == 0) return hipSuccess;
+    // the stored frames are copied (HBM-bound) while the compressed ones are decoded (latency-bound, HBM idle): disjoint
+    // outputs, both only read the stream -- on a second stream when the caller has one to spare.  The decode kernel is
+    // launched first: its few long-running waves should get their slots before the copy's many short workgroups fill the CUs.
+    const bool side = copy_stream && copy_stream != stream && fork && join;
+    hipStream_t cs = side ? copy_stream : stream;
+    if (side) {
+        hipError_t e = hipEventRecord(fork, stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(copy_stream, fork, 0);
+        if (e != hipSuccess) return e;
+    }
     // more compressed blocks than the 64 KiB-ring kernel keeps resident (2 per CU) plus half a round: the small ring's four-fold
     // occupancy wins; below that the frames are few and long, and every match served from LDS wins
     if (ncompressed > 768u && nframes > 768u)
@@ -3496,8 +3544,14 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     {   // stored blocks of single-block frames (a block never exceeds block_bytes)
         const uint32_t slices = (uint32_t)((block_bytes + DEC_COPY_SLICE - 1) / DEC_COPY_SLICE);
         if (slices == 0 || (uint64_t)nframes * slices > 0x7fffffffull) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(lz4_stored_frames_copy_kernel, dim3(nframes * slices), dim3(256), 0, stream, in, (const uint4*)blk, frame_first,
+        hipLaunchKernelGGL(lz4_stored_frames_copy_kernel, dim3(nframes * slices), dim3(256), 0, cs, in, (const uint4*)blk, frame_first,
                            out, out_bytes, frame_stride, slices);
+    }
+    if (side) {
+        hipError_t e = hipEventRecord(join, copy_stream);
+        if (e != hipSuccess) return e;
+        e = hipStreamWaitEvent(stream, join, 0);
+        if (e != hipSuccess) return e;
     }
     return hipGetLastError();
 }
@@ -3508,10 +3562,22 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
     const uint64_t W = (uint64_t)elem_size * 8, seg = len / W;
     uint64_t blocks = (seg + 255) / 256;
     if (blocks == 0) blocks = 1;
-    if (elem_size == 2)
-        hipLaunchKernelGGL((bitswap1_decode_kernel<uint16_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, len, seg);
-    else
-        hipLaunchKernelGGL((bitswap1_decode_kernel<uint8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, len, seg);
+    if (elem_size == 2) {
+        // whole tiles of 8192 voxels through the register kernel (16-byte aligned buffers and plane segments), the rest one group per thread
+        uint64_t w0 = 0;
+        const uint64_t n_tiles = seg / (BSW_TILE_VOX / 16);
+        if (n_tiles && seg % 8 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
+            uint64_t g = (n_tiles + 3) / 4;
+            if (g > 65536) g = 65536;
+            hipLaunchKernelGGL(bitswap1_decode_u16_regs, dim3((unsigned)g), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, n_tiles, seg);
+            w0 = n_tiles * (BSW_TILE_VOX / 16);
+        }
+        const uint64_t rest = seg - w0;
+        uint64_t rb = (rest + 255) / 256;
+        if (rb == 0) rb = 1;                                            // (block 0 also moves the len % 16 voxels behind the planes)
+        hipLaunchKernelGGL((bitswap1_decode_kernel<uint16_t>), dim3((unsigned)rb), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, len, seg, w0);
+    } else
+        hipLaunchKernelGGL((bitswap1_decode_kernel<uint8_t>), dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t*)in, (uint8_t*)out, len, seg, (uint64_t)0);
     return hipGetLastError();
 }
 
