@@ -225,10 +225,11 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="keep timing blocks of --steps steps until this much has been timed")
     ap.add_argument("--frames", type=int, default=SHAPE[0], help="z extent per GPU (default: the BASELINE config)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the second measurement with the RCCL gather to rank 0 inside the step")
-    ap.add_argument("--inflight", type=int, default=2,
+    ap.add_argument("--inflight", type=int, default=3,
                     help="C-ABI calls in flight per GPU (host threads, one stream + workspace each; the C-ABI is re-entrant like "
-                         "the reference's).  1 = strictly one call after the other.  Two already keep the GPU busy (the LZ4 parse "
-                         "of one call overlaps the HBM-bound kernels of the other); more only stretch each kernel's duration")
+                         "the reference's).  1 = strictly one call after the other.  A call is three phases -- transpose (HBM), LZ4 "
+                         "parse (latency-bound, HBM idle), frame gather (HBM) -- so three calls keep every phase busy "
+                         "(measured: 1 -> 550, 2 -> 880, 3 -> 1035, 4 -> 850, 5 -> 950 GB/s)")
     args = ap.parse_args()
 
     # (SQY_BENCH_FORCE_SPAWN=1: rehearsal of the self-launch on a one-GPU box)
@@ -413,6 +414,8 @@ def main():
                                        "roofline_frac_whole_call": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                         # every kernel of the call together: algorithmic bytes of one step / wall time of one step
+                         "whole_step_frac": round((algo_bytes / 1e9) / (dt / args.steps) / HBM_PEAK_GBS, 5),
                          "algorithmic_bytes_per_launch": algo_bytes, "avg_launch_ms": round(avg_ms, 4), "launches_timed": dom_n,
                          # the same kernel with the GPU to itself (one call at a time, measured right after the timed region)
                          "alone_launch_ms": round(alone_ms, 4) if alone_ms else None,

@@ -1583,8 +1583,13 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
     if ((uint32_t)tid < head) dd[tid] = ss[tid];
     dd += head; ss += head; len -= head;
     const uint32_t nvec = len >> 4;
-    for (uint32_t i = tid; i < nvec; i += 256) {
-        *reinterpret_cast<uint4*>(dd + (size_t)i * 16) = ld_u128(ss + (size_t)i * 16);
+    // four loads in flight per thread before the first store (a 32 KiB slice is 8 vectors per thread)
+    for (uint32_t i0 = tid; i0 < nvec; i0 += 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j * 256u < nvec) v[j] = ld_u128(ss + (size_t)(i0 + j * 256u) * 16);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j * 256u < nvec) *reinterpret_cast<uint4*>(dd + (size_t)(i0 + j * 256u) * 16) = v[j];
     }
     const uint32_t done = nvec << 4;
     if ((uint32_t)tid < len - done) dd[done + tid] = ss[done + tid];
@@ -1626,15 +1631,22 @@ void histogram_u16_kernel(const uint16_t* __restrict__ in, uint64_t len, uint32_
     for (uint32_t q = 1; q < 4; ++q) if (votes[q] > votes[best]) best = q;
     const uint32_t wbase = best * HIST_WIN_BINS;
 
-    for (uint64_t v = v0 + tid; v < v1; v += 256) {
-        const uint4 x = src[v];
-        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+    for (uint64_t vb = v0 + tid; vb < v1; vb += 1024) {                 // four loads in flight per thread
+        uint4 xs[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint32_t a = w[j] & 0xffffu, b = w[j] >> 16;
-            const uint32_t ra = a - wbase, rb = b - wbase;
-            if (ra < (uint32_t)HIST_WIN_BINS) atomicAdd(&hwin[ra], 1u); else atomicAdd(&histo[a], 1u);
-            if (rb < (uint32_t)HIST_WIN_BINS) atomicAdd(&hwin[rb], 1u); else atomicAdd(&histo[b], 1u);
+        for (uint32_t u = 0; u < 4; ++u) if (vb + u * 256u < v1) xs[u] = src[vb + u * 256u];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            if (vb + u * 256u >= v1) continue;
+            const uint4 x = xs[u];
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t a = w[j] & 0xffffu, b = w[j] >> 16;
+                const uint32_t ra = a - wbase, rb = b - wbase;
+                if (ra < (uint32_t)HIST_WIN_BINS) atomicAdd(&hwin[ra], 1u); else atomicAdd(&histo[a], 1u);
+                if (rb < (uint32_t)HIST_WIN_BINS) atomicAdd(&hwin[rb], 1u); else atomicAdd(&histo[b], 1u);
+            }
         }
     }
     // tail voxels (len % 8) by the last block
@@ -1661,14 +1673,22 @@ void quantiser_apply_u16_kernel(const uint16_t* __restrict__ in, uint8_t* __rest
     const uint64_t nvec = len / 8;
     const uint4* src = reinterpret_cast<const uint4*>(in);
     uint2* dst = reinterpret_cast<uint2*>(out);
-    for (uint64_t v = (uint64_t)blockIdx.x * 256 + tid; v < nvec; v += (uint64_t)gridDim.x * 256) {
-        const uint4 x = src[v];
-        uint2 y;
-        y.x = (uint32_t)slut[x.x & 0xffffu] | ((uint32_t)slut[x.x >> 16] << 8) | ((uint32_t)slut[x.y & 0xffffu] << 16) |
-              ((uint32_t)slut[x.y >> 16] << 24);
-        y.y = (uint32_t)slut[x.z & 0xffffu] | ((uint32_t)slut[x.z >> 16] << 8) | ((uint32_t)slut[x.w & 0xffffu] << 16) |
-              ((uint32_t)slut[x.w >> 16] << 24);
-        dst[v] = y;
+    const uint64_t step = (uint64_t)gridDim.x * 256;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * 256 + tid; v0 < nvec; v0 += 4 * step) {           // four loads in flight per thread
+        uint4 xs[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (v0 + j * step < nvec) xs[j] = src[v0 + j * step];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            if (v0 + j * step >= nvec) continue;
+            const uint4 x = xs[j];
+            uint2 y;
+            y.x = (uint32_t)slut[x.x & 0xffffu] | ((uint32_t)slut[x.x >> 16] << 8) | ((uint32_t)slut[x.y & 0xffffu] << 16) |
+                  ((uint32_t)slut[x.y >> 16] << 24);
+            y.y = (uint32_t)slut[x.z & 0xffffu] | ((uint32_t)slut[x.z >> 16] << 8) | ((uint32_t)slut[x.w & 0xffffu] << 16) |
+                  ((uint32_t)slut[x.w >> 16] << 24);
+            dst[v0 + j * step] = y;
+        }
     }
     if (blockIdx.x == 0) {
         for (uint64_t i = nvec * 8 + tid; i < len; i += 256) out[i] = slut[in[i]];
@@ -2041,8 +2061,14 @@ void frame_gather_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ o
     }
     const uint8_t* s = in + map[f] * frame_bytes;
     if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
-        for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < nvec; v += (uint64_t)blocks_per_frame * 256)
-            reinterpret_cast<uint4*>(d)[v] = reinterpret_cast<const uint4*>(s)[v];
+        const uint64_t step = (uint64_t)blocks_per_frame * 256;
+        for (uint64_t v0 = (uint64_t)part * 256 + threadIdx.x; v0 < nvec; v0 += 4 * step) {   // four loads in flight per thread
+            uint4 t[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) if (v0 + j * step < nvec) t[j] = reinterpret_cast<const uint4*>(s)[v0 + j * step];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) if (v0 + j * step < nvec) reinterpret_cast<uint4*>(d)[v0 + j * step] = t[j];
+        }
         if (part == 0)
             for (uint64_t i = nvec * 16 + threadIdx.x; i < frame_bytes; i += 256) d[i] = s[i];
     } else {
@@ -2804,7 +2830,13 @@ void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* 
     const uint32_t head = head0 < len0 ? head0 : len0;
     if ((uint32_t)tid < head) d[tid] = s[tid];
     const uint32_t nvec = (len0 - head) >> 4;
-    for (uint32_t i = tid; i < nvec; i += 256) *reinterpret_cast<uint4*>(d + head + (size_t)i * 16) = ld_u128(s + head + (size_t)i * 16);
+    for (uint32_t i0 = tid; i0 < nvec; i0 += 1024) {             // four loads in flight per thread before the first store
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j * 256u < nvec) v[j] = ld_u128(s + head + (size_t)(i0 + j * 256u) * 16);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j * 256u < nvec) *reinterpret_cast<uint4*>(d + head + (size_t)(i0 + j * 256u) * 16) = v[j];
+    }
     const uint32_t done = head + (nvec << 4);
     if ((uint32_t)tid < len0 - done) d[done + tid] = s[done + tid];
 }
@@ -3158,8 +3190,14 @@ void frame_scatter_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ 
     uint8_t* d = out + map[f] * frame_bytes;
     const uint64_t nvec = frame_bytes / 16;
     if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
-        for (uint64_t v = (uint64_t)part * 256 + threadIdx.x; v < nvec; v += (uint64_t)blocks_per_frame * 256)
-            reinterpret_cast<uint4*>(d)[v] = reinterpret_cast<const uint4*>(s)[v];
+        const uint64_t step = (uint64_t)blocks_per_frame * 256;
+        for (uint64_t v0 = (uint64_t)part * 256 + threadIdx.x; v0 < nvec; v0 += 4 * step) {   // four loads in flight per thread
+            uint4 t[4];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) if (v0 + j * step < nvec) t[j] = reinterpret_cast<const uint4*>(s)[v0 + j * step];
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) if (v0 + j * step < nvec) reinterpret_cast<uint4*>(d)[v0 + j * step] = t[j];
+        }
         if (part == 0)
             for (uint64_t i = nvec * 16 + threadIdx.x; i < frame_bytes; i += 256) d[i] = s[i];
     } else {

@@ -47,7 +47,7 @@ for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
         if is_ours(r["Name"]):
             rows.append(r)
 with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick  (defaults: 30 steps, 5 warm-up, 2 calls in flight)   (sqy:: kernels only)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick  (defaults: 30 steps, 5 warm-up, 3 calls in flight)   (sqy:: kernels only)\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
