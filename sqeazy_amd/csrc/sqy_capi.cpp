@@ -25,6 +25,7 @@
 
 namespace {
 
+
 using sqy::Pipeline;
 using sqy::Stage;
 using sqy::StageKind;
@@ -182,9 +183,26 @@ struct Stager {
 
 struct Context {
     Workspace ws;
+    // Streams are created on first use, not with the context: HIP deals streams to a handful of hardware queues in creation
+    // order, and a caller that brings its own streams (one per host thread) should not find two of them behind the same queue
+    // because this library created streams of its own in between -- their kernels would then never overlap (bench, three
+    // callers: 750 instead of 1120 GB/s in about every other process).
     hipStream_t stream = nullptr;       // used when the caller brings no stream (host-pointer entry points)
     hipStream_t side = nullptr;         // decode: stored frames are copied here while the compressed ones are decoded
     hipEvent_t fork = nullptr, join = nullptr;
+    hipStream_t own_stream()
+    {
+        if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
+        return stream;
+    }
+    bool ensure_side()
+    {
+        if (side && fork && join) return true;
+        if (!side && hipStreamCreateWithFlags(&side, hipStreamNonBlocking) != hipSuccess) { side = nullptr; return false; }
+        if (!fork && hipEventCreateWithFlags(&fork, hipEventDisableTiming) != hipSuccess) { fork = nullptr; return false; }
+        if (!join && hipEventCreateWithFlags(&join, hipEventDisableTiming) != hipSuccess) { join = nullptr; return false; }
+        return true;
+    }
     std::vector<PendingEvent> pending;
     Stager stager;
     bool busy = false;
@@ -209,10 +227,6 @@ struct ContextLease {
             if (g_pool[dev].size() < kMaxCtxPerDev) {
                 std::unique_ptr<Context> c(new Context());
                 if (hipHostMalloc(&c->ws.pinned, 4096, hipHostMallocDefault) != hipSuccess) return;
-                if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return;
-                if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) return;
-                if (hipEventCreateWithFlags(&c->fork, hipEventDisableTiming) != hipSuccess) return;
-                if (hipEventCreateWithFlags(&c->join, hipEventDisableTiming) != hipSuccess) return;
                 ctx = c.get();
                 g_pool[dev].push_back(std::move(c));
                 break;
@@ -701,7 +715,8 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
     ContextLease lease;
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     Workspace* ws = &lease.ctx->ws;
-    hipStream_t stream = lease.ctx->stream;
+    hipStream_t stream = lease.ctx->own_stream();
+    if (!stream) { std::fprintf(stderr, "[sqeazy]\t no HIP stream\n"); return 1; }
     uint64_t len = 1;
     for (unsigned i = 0; i < rank; ++i) {
         if (shape[i] <= 0) return 1;
@@ -863,8 +878,9 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 uint8_t* out = out_buf(si, total);
                 if (!out) return 1;
                 {
+                    const bool side_ok = cx.ensure_side();           // (without it the copy simply follows on the same stream)
                     ProfScope ps("lz4_frames_decode", stream, pend);
-                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, cx.side, cx.fork, cx.join));
+                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, side_ok ? cx.side : nullptr, cx.fork, cx.join));
                 }
                 uint32_t bad = 0;
                 SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
@@ -1035,7 +1051,8 @@ int decode_from_host(const char* src, long srclength, char* dst, int elem_size)
     ContextLease lease;
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     Workspace* ws = &lease.ctx->ws;
-    hipStream_t stream = lease.ctx->stream;
+    hipStream_t stream = lease.ctx->own_stream();
+    if (!stream) { std::fprintf(stderr, "[sqeazy]\t no HIP stream\n"); return 1; }
     uint64_t n = 1;
     for (uint64_t d : h.shape) n *= d;
     const uint64_t raw = n * (uint64_t)h.elem_size();
