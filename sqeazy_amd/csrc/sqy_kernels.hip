@@ -12,6 +12,7 @@
 //
 // No CUDA compatibility layer, no dual paths: this file only targets gfx950.
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 #include <cstdlib>
 
@@ -3640,6 +3641,10 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
         const uint64_t lds = (R + 4) * X * 2;             // the strip of the last frame + 2 halo rows + 2 rows on their way out
         const uint64_t NQ = (X + 2) / 3;
         if (lds <= 65536 && R * (X / 8) <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXV && NQ <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXQ) {
+            // one strips kernel at a time per process: two fit the chip side by side, three dispatched from three host threads
+            // at once could each end up half resident and wait for strips that cannot start (until the poll limit, ~1 s)
+            static std::mutex strips_mu;
+            std::lock_guard<std::mutex> strips_lock(strips_mu);
             const uint64_t exch_bytes = G * 4 * NQ * 8;
             uint32_t* const abort_word = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + exch_bytes);
             hipError_t e = hipMemsetAsync(scratch, 0xff, exch_bytes, stream);

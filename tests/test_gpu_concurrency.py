@@ -40,3 +40,29 @@ def test_many_threads_mixed_calls(sqy, oracle):
     for th in threads:
         th.join(timeout=600)
     assert not errors, errors[:3]
+
+
+def test_concurrent_full_width_diff_decodes(sqy, oracle):
+    """six host threads decode a volume whose diff3x3x1 stage takes the one-launch strip kernel with all 256 strips: the strips
+    of one launch wait for each other, so launches from different threads must not end up half resident side by side"""
+    import time
+    vol = synth.stack((48, 1024, 256), np.uint16)
+    blob = oracle.pipeline_encode("diff3x3x1->bitswap1->lz4", vol)
+    errors = []
+
+    def worker(t):
+        try:
+            for _ in range(4):
+                rc, dec = sqy.decode(blob)
+                assert rc == 0 and np.array_equal(dec, vol), ("decode", t)
+        except Exception as e:   # pragma: no cover
+            errors.append(repr(e))
+
+    t0 = time.perf_counter()
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors[:3]
+    assert time.perf_counter() - t0 < 60, "decodes stalled (strip kernels waiting for strips that could not start?)"
