@@ -500,6 +500,7 @@ __device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
 // The first pass keeps the ring at 8 KiB (26 KiB of LDS per chunk wave = 6 waves per CU).  The DENSE kernel, which only
 // runs the chunks the first pass gave up, takes 32 KiB: with 64 probes per batch nearly every batch would otherwise have
 // a candidate behind the ring, i.e. a global round trip per batch.
+constexpr uint32_t LZ4_RINGLESS_U = 64u * 15u;   // probes since the last match from which on the batches stride over the ring (step >= 16)
 constexpr uint32_t LZ4_WIN_LEAN = 8192, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 template <uint32_t LZ4_WIN>
@@ -845,7 +846,11 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
         for (;;) {
             SQY_STAMP(0);
-            w.ensure(P);
+            // Skip-accelerated probing (no match for a while: incompressible data) strides over the ring: at a step of 16 bytes a
+            // batch of 64 probes spans a KiB, later several -- most probes lie behind the resident range and are read from global
+            // memory anyway, and refilling the ring up to P + AHEAD would cost an HBM round trip per batch for bytes nobody reads.
+            // The ring is left behind then; the first match restarts it (ensure's "jumped past everything" path).
+            if (U < LZ4_RINGLESS_U) w.ensure(P);
 
             uint32_t f = 64, fcand = 0;      // first matching probe of the batch and its candidate
             uint32_t ipf = 0;                // its position
