@@ -150,3 +150,142 @@ def unpack_container(buf):
         out.append(buf[off:off + int(s)])
         off += int(s)
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Single-blob mode ("optional"): N ranks produce ONE blob, byte-identical to what one call on the whole
+# volume yields, for `bitswap1->lz4` in the chunked layout.  The whole volume's payload is the 16 (8) bit planes one after
+# the other, each cut into LZ4 chunks that are compressed independently; a z-slab's bits are a contiguous piece of every
+# plane.  When that piece is a whole number of chunks, the frames a rank gets for its slab ARE the frames of the whole
+# volume for that piece -- the single blob is  header(whole shape) | plane 15: rank 0's frames, rank 1's, ... | plane 14: ...
+# No halo, no re-encoding: every rank makes its ordinary slab call, the root re-orders byte ranges.
+# ---------------------------------------------------------------------------------------------------------------------
+LZ4_CHUNK_BYTES = 256 << 10          # sqeazy's default framestep (lz4.hpp:91-101)
+SINGLE_BLOB_PIPELINE = "bitswap1->lz4"
+
+
+def single_blob_possible(shape, dtype, world, chunk_bytes=LZ4_CHUNK_BYTES):
+    """every rank's slab (slab_range) must cover a whole number of LZ4 chunks of every bit plane: voxels_r / 8 bytes per plane"""
+    shape = [int(s) for s in shape]
+    if len(shape) != 3 or np.dtype(dtype) not in (np.dtype(np.uint16), np.dtype(np.uint8)):
+        return False
+    per_frame = shape[1] * shape[2]
+    for r in range(world):
+        _, nz = slab_range(shape[0], r, world)
+        if nz == 0 or (nz * per_frame) % (8 * chunk_bytes):
+            return False
+    return True
+
+
+def walk_frames(payload):
+    """(offset, length) of every LZ4 frame in `payload` (bytes-like): magic, FLG/BD/HC, blocks (4-byte size field, bit 31 =
+    stored), end mark.  Only what sqeazy writes (no content size, checksums or dictionary id)."""
+    buf = memoryview(payload)
+    out, off, n = [], 0, len(buf)
+    while off < n:
+        if n - off < 11 or bytes(buf[off:off + 4]) != b"\x04\x22\x4d\x18":
+            raise ValueError("no LZ4 frame at payload offset %d" % off)
+        p = off + 7
+        while True:
+            field = int.from_bytes(buf[p:p + 4], "little")
+            p += 4
+            if field == 0:
+                break
+            p += field & 0x7fffffff
+            if p + 4 > n:
+                raise ValueError("LZ4 frame runs past the payload")
+        out.append((off, p - off))
+        off = p
+    return out
+
+
+def plane_ranges(slab_blob, slab_shape, dtype, chunk_bytes=LZ4_CHUNK_BYTES):
+    """header size and the byte range (offset into the blob, length) of every bit plane's frames inside one slab blob"""
+    import sqeazy_amd
+    blob = bytes(slab_blob)
+    hdr = sqeazy_amd.header_size(blob[:65536])
+    W = np.dtype(dtype).itemsize * 8
+    plane_bytes = int(np.prod(slab_shape)) // 8
+    if plane_bytes % chunk_bytes:
+        raise ValueError("the slab is not a whole number of LZ4 chunks per bit plane")
+    per_plane = plane_bytes // chunk_bytes
+    frames = walk_frames(blob[hdr:])
+    if len(frames) != W * per_plane:
+        raise ValueError("%d frames where %d x %d were expected" % (len(frames), W, per_plane))
+    ranges = []
+    for p in range(W):
+        first, last = frames[p * per_plane], frames[(p + 1) * per_plane - 1]
+        ranges.append((hdr + first[0], last[0] + last[1] - first[0]))
+    return hdr, ranges
+
+
+def build_header(pipeline, dtype, shape, payload_bytes):
+    """the header sqeazy puts in front of `payload_bytes` of payload (SQYAMD_Header_Build, host only)"""
+    import ctypes
+    import sqeazy_amd
+    L = sqeazy_amd.lib()
+    dims = (ctypes.c_long * len(shape))(*[int(s) for s in shape])
+    n = ctypes.c_long(0)
+    esz = np.dtype(dtype).itemsize
+    if L.SQYAMD_Header_Build(pipeline.encode(), esz, dims, len(shape), ctypes.c_long(int(payload_bytes)), None, ctypes.byref(n)):
+        raise ValueError("SQYAMD_Header_Build refused %r" % (pipeline,))
+    buf = ctypes.create_string_buffer(n.value)
+    cap = ctypes.c_long(n.value)
+    if L.SQYAMD_Header_Build(pipeline.encode(), esz, dims, len(shape), ctypes.c_long(int(payload_bytes)), buf, ctypes.byref(cap)):
+        raise ValueError("SQYAMD_Header_Build failed")
+    return buf.raw[:cap.value]
+
+
+def assemble_single_blob(shape, dtype, slab_blobs, ranges, pipeline=SINGLE_BLOB_PIPELINE):
+    """slab_blobs[r]: rank r's slab blob (1-D uint8 torch tensor, any device, or bytes); ranges[r]: plane_ranges of it.
+    Returns the whole volume's blob as a uint8 torch tensor on the device of the first slab blob (bytes in, bytes out)."""
+    import torch
+    W = np.dtype(dtype).itemsize * 8
+    payload = sum(ln for rr in ranges for (_, ln) in rr)
+    head = build_header(pipeline, dtype, shape, payload)
+    as_bytes = not hasattr(slab_blobs[0], "device")
+    if as_bytes:
+        parts = [head]
+        for p in range(W):
+            for r, b in enumerate(slab_blobs):
+                o, ln = ranges[r][p]
+                parts.append(bytes(b[o:o + ln]))
+        return b"".join(parts)
+    dev = slab_blobs[0].device
+    out = torch.empty(len(head) + payload, dtype=torch.uint8, device=dev)
+    out[:len(head)] = torch.frombuffer(bytearray(head), dtype=torch.uint8).to(dev)
+    pos = len(head)
+    for p in range(W):
+        for r, b in enumerate(slab_blobs):
+            o, ln = ranges[r][p]
+            out[pos:pos + ln] = b[o:o + ln]
+            pos += ln
+    return out
+
+
+def gather_single_blob(blob, nbytes, shape, dtype, group=None, root=0, pipeline=SINGLE_BLOB_PIPELINE):
+    """Every rank passes the blob of ITS slab (slab_range of shape[0]); `root` gets the single blob of the whole volume
+    (uint8 tensor on its device), everybody else None.  Exchange: one all_gather of 1 + W plane sizes, then the
+    variable-length gather of the slab blobs (compressed bytes only)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    if not single_blob_possible(shape, dtype, world):
+        raise ValueError("slabs of %r over %d ranks are not whole LZ4 chunks per bit plane" % (list(shape), world))
+    _, nz = slab_range(shape[0], rank, world)
+    W = np.dtype(dtype).itemsize * 8
+    hdr, rr = plane_ranges(blob[:nbytes].cpu().numpy().tobytes(), (nz, shape[1], shape[2]), dtype)
+    mine = torch.tensor([hdr] + [v for pr in rr for v in pr], dtype=torch.int64, device=blob.device)
+    table = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(table, mine, group=group)
+    sizes, flat = gather_blobs(blob, nbytes, group=group, root=root)
+    if rank != root:
+        return None
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    blobs, ranges = [], []
+    for r in range(world):
+        t = [int(v) for v in table[r].tolist()]
+        blobs.append(flat[int(offs[r]):int(offs[r + 1])])
+        ranges.append([(t[1 + 2 * p], t[2 + 2 * p]) for p in range(W)])
+    return assemble_single_blob(shape, dtype, blobs, ranges, pipeline)

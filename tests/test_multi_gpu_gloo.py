@@ -113,6 +113,79 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def _worker_single_blob(rank, world, port, q):
+    """single-blob mode: every rank encodes its slab (the CPU oracle stands in for the GPU call), rank 0 ends up with ONE blob
+    that is byte for byte what one call on the whole volume yields"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from oracle import sqy_oracle as o
+    from sqeazy_amd import multi, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        for dtype, shape in ((np.uint16, (8 * world, 256, 1024)), (np.uint8, (4 * world, 512, 1024))):
+            full = synth.stack(shape, dtype)
+            assert multi.single_blob_possible(shape, dtype, world)
+            z0, nz = multi.slab_range(shape[0], rank, world)
+            blob = o.pipeline_encode("bitswap1->lz4", full[z0:z0 + nz])
+            t = torch.zeros(len(blob) + 64, dtype=torch.uint8)
+            t[:len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            one = multi.gather_single_blob(t, len(blob), shape, dtype)
+            if rank == 0:
+                got = one.numpy().tobytes()
+                assert got == o.pipeline_encode("bitswap1->lz4", full), (np.dtype(dtype).name, len(got))
+                assert np.array_equal(o.pipeline_decode(got), full)
+            else:
+                assert one is None
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:   # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_single_blob_assembly_from_slab_blobs():
+    """no process group: the re-ordering alone, 1 / 2 / 4 slabs, both voxel types; and the shapes it has to refuse"""
+    sys.path.insert(0, ROOT)
+    from oracle import sqy_oracle as o
+    from sqeazy_amd import multi, synth
+    for dtype in (np.uint16, np.uint8):
+        shape = (16, 512, 1024)
+        vol = synth.stack(shape, dtype)
+        want = o.pipeline_encode("bitswap1->lz4", vol)
+        for world in (1, 2, 4):
+            blobs, ranges = [], []
+            for r in range(world):
+                z0, nz = multi.slab_range(shape[0], r, world)
+                b = o.pipeline_encode("bitswap1->lz4", vol[z0:z0 + nz])
+                blobs.append(b)
+                ranges.append(multi.plane_ranges(b, (nz,) + shape[1:], dtype)[1])
+            assert multi.assemble_single_blob(shape, dtype, blobs, ranges) == want, (np.dtype(dtype).name, world)
+    assert not multi.single_blob_possible((13, 24, 32), np.uint16, 2)          # slabs that are no whole chunks per plane
+    assert not multi.single_blob_possible((16, 512, 1024), np.uint16, 3)       # uneven split: 6 + 5 + 5 frames
+    assert not multi.single_blob_possible((16, 512, 1024), np.uint16, 8)       # 2 frames = half a chunk per plane
+    with pytest.raises(ValueError):
+        multi.walk_frames(b"\x04\x22\x4d\x18\x40\x60\x51" + (100).to_bytes(4, "little") + b"short")
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_single_blob_gather(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_single_blob, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
 def test_slab_range_partitions():
     from sqeazy_amd import multi
     for Z in (1, 7, 8, 13, 512):
