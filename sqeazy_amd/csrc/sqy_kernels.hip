@@ -2532,6 +2532,26 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                 }
                 return;
             }
+            if (ml <= 256u && offset >= ml) {
+                // the source ends in front of the destination: nothing to extend, the up to four 64-byte steps do not depend on
+                // each other -- all reads are issued before the first write, one LDS round trip for the whole match
+                uint32_t v[4];
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t k = (uint32_t)lane + 64u * j;
+                    v[j] = 0;
+                    if (k < ml) v[j] = ring[(pos - offset + k) & (DEC_RING - 1)];
+                }
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t k = (uint32_t)lane + 64u * j;
+                    if (k < ml) ring[(pos + k) & (DEC_RING - 1)] = (uint8_t)v[j];
+                }
+                wave_lds_sync();
+                pos += ml;
+                flush(false);
+                return;
+            }
             // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
             // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
             // (an integer modulo is ~40 instructions: only when a step's source overlaps its destination)
