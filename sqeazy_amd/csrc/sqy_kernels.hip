@@ -2702,8 +2702,52 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                         backoff = 8;
                         continue;
                     }
-                    // longer sequences: one at a time below is the better path (long copies, 1 KiB steps); look at the stream
-                    // again later -- ever later while it keeps looking like this
+                    // longer sequences (the batch still knows where each starts, how long it is and where it goes): all literals
+                    // of the batch reach the ring in one step -- lane i holds byte i of the window; it belongs to the last start
+                    // s <= i and is literal number i - s - 1 of that sequence --, then the matches in order, each with all its
+                    // reads in front of its writes.  Not when a match reaches so far back that literals written ahead of it
+                    // would land on its source.
+                    const bool clash = is_start && offs <= DEC_RING && offs + total > DEC_RING;
+                    if (fits && nst >= 8u && !ballot(clash)) {              // (fewer do not pay for the batch's parse)
+                        {
+                            const uint64_t below = starts & (~0ull >> (63u - (uint32_t)lane));
+                            const uint32_t s_of = 63u - (uint32_t)__builtin_clzll(below | 1ull);
+                            const uint32_t key = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_of * 4u), (int)(rel | (flit << 16)));
+                            const uint32_t k = (uint32_t)lane - s_of - 1u;          // (lane == s_of: wraps, never < flit)
+                            if ((uint32_t)lane < cur && k < (key >> 16))
+                                ring[(base + (key & 0xffffu) + k) & (DEC_RING - 1)] = (uint8_t)tokb;
+                            wave_lds_sync();
+                        }
+                        uint64_t todo = starts;
+                        while (todo) {
+                            const uint32_t sl = ctz64(todo);
+                            todo &= todo - 1ull;
+                            const uint32_t inf = lane_read(info, sl);
+                            const uint32_t off = inf >> 16, mln = (inf >> 4) & 0xfffu;
+                            pos = base + lane_read(rel, sl) + (inf & 15u);
+                            if (mln <= 256u && off >= mln && off <= DEC_RING) {
+                                uint32_t v[4];
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; ++j) {
+                                    const uint32_t kk = (uint32_t)lane + 64u * j;
+                                    v[j] = 0;
+                                    if (kk < mln) v[j] = ring[(pos - off + kk) & (DEC_RING - 1)];
+                                }
+#pragma unroll
+                                for (uint32_t j = 0; j < 4; ++j) {
+                                    const uint32_t kk = (uint32_t)lane + 64u * j;
+                                    if (kk < mln) ring[(pos + kk) & (DEC_RING - 1)] = (uint8_t)v[j];
+                                }
+                                wave_lds_sync();
+                                pos += mln;
+                                flush(false);
+                            } else
+                                copy_match(off, mln);
+                        }
+                        ip += cur;
+                        backoff = 8;
+                        continue;
+                    }
                     if (fits) { one_by_one = backoff > nst ? backoff : nst; backoff = backoff < 256u ? backoff * 2u : 256u; }
                 }
             }
