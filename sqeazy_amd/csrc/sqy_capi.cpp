@@ -749,6 +749,20 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
 
 // ---- decode --------------------------------------------------------------------------------------
 // dynamic_pipeline::decode (dynamic_pipeline.hpp:740-846): tail filters^-1, sink^-1, head filters^-1 in reverse.
+// the quantiser's decode LUT (256 x u16, base64 in the header) into ws->small; synchronous: the host copy does not outlive the call
+int quantiser_lut_to_device(const sqy::Stage& st, Workspace* ws, hipStream_t stream)
+{
+    auto it = st.cfg.find("decode_lut_string");
+    if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t quantiser: no decode_lut_string in the header\n"); return 1; }
+    const std::string b64 = it->second.substr(10, it->second.size() - 21);   // strip <verbatim> ... </verbatim>
+    const std::vector<unsigned char> lut = sqy::base64_decode(b64);
+    if (lut.size() != 512) { std::fprintf(stderr, "[sqeazy]\t quantiser: malformed decode LUT\n"); return 1; }
+    if (ws->small.ensure(4096)) return 1;
+    SQY_HIP(hipMemcpy(ws->small.p, lut.data(), 512, hipMemcpyHostToDevice));
+    (void)stream;
+    return 0;
+}
+
 int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t dst_capacity, int want_elem, hipStream_t stream)
 {
     if (!d_src_v || !d_dst) return 1;
@@ -890,6 +904,25 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 break;
             }
             case StageKind::bitswap1: {
+                // quantiser right in front (on the encoder's side): the inverse transpose and the quantiser's look-up in one pass
+                if (e_in == 1 && si >= 1 && pipe.stages[si - 1].kind == StageKind::quantiser && count_before[si - 1] == n_in &&
+                    elem_before[si - 1] == 2) {
+                    if (quantiser_lut_to_device(pipe.stages[si - 1], ws, stream)) return 1;
+                    uint8_t* out16 = out_buf(si - 1, n_in * 2);
+                    if (!out16) return 1;
+                    if (sqy::bitswap1_u8_decode_lut_possible(cur, out16, n_in)) {
+                        {
+                            ProfScope ps("bitswap1_quantiser_decode", stream, pend);
+                            SQY_HIP(sqy::launch_bitswap1_u8_decode_lut(cur, reinterpret_cast<uint16_t*>(out16), n_in,
+                                                                       static_cast<const uint16_t*>(ws->small.p), stream));
+                        }
+                        cur = out16; cur_bytes = n_in * 2;
+                        si -= 1;                                           // the quantiser stage is done as well
+                        break;
+                    }
+                    // (odd sizes: the two stages one after the other; out16 is the quantiser's output buffer below)
+                    if (si - 1 != 0) use_ping = !use_ping;                 // hand the buffer back to the quantiser stage
+                }
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 ProfScope ps("bitswap1_decode", stream, pend);
@@ -992,13 +1025,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 break;
             }
             case StageKind::quantiser: {
-                auto it = st.cfg.find("decode_lut_string");
-                if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t quantiser: no decode_lut_string in the header\n"); return 1; }
-                const std::string b64 = it->second.substr(10, it->second.size() - 21);   // strip <verbatim> ... </verbatim>
-                const std::vector<unsigned char> lut = sqy::base64_decode(b64);
-                if (lut.size() != 512) { std::fprintf(stderr, "[sqeazy]\t quantiser: malformed decode LUT\n"); return 1; }
-                if (ws->small.ensure(4096)) return 1;
-                SQY_HIP(hipMemcpyAsync(ws->small.p, lut.data(), 512, hipMemcpyHostToDevice, stream));
+                if (quantiser_lut_to_device(st, ws, stream)) return 1;
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 {

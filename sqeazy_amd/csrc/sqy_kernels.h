@@ -92,6 +92,9 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
                                     uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream = nullptr, hipEvent_t fork = nullptr,
                                     hipEvent_t join = nullptr);
+// decode of quantiser->bitswap1: inverse transpose of the 8-bit planes and the quantiser's look-up in one pass
+bool bitswap1_u8_decode_lut_possible(const void* in, const void* out, uint64_t len);
+hipError_t launch_bitswap1_u8_decode_lut(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
 hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int elem_size, hipStream_t stream);
 // scratch: diff3x3x1_decode_scratch_bytes(X) of device memory for the one-launch kernel (null: always one launch per frame);
 // synchronises the stream when the one-launch kernel is used

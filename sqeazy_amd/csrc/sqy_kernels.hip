@@ -2934,6 +2934,49 @@ void bitswap1_decode_kernel(const T* __restrict__ in, T* __restrict__ out, uint6
     if (blockIdx.x == 0 && threadIdx.x < len - L) out[L + threadIdx.x] = in[L + threadIdx.x];
 }
 
+// 8-bit planes straight to the quantiser's 16-bit values (decode of `quantiser->bitswap1->...`): the inverse transpose and the
+// look-up in one pass -- the 8-bit volume in between (1 byte per voxel written and read again) never exists.  A thread takes 16
+// consecutive bytes of every plane (8 coalesced 16-byte loads) = 128 voxels and writes their 256 bytes of 16-bit values.
+__global__ __launch_bounds__(256)
+void bitswap1_u8_decode_lut_kernel(const uint8_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t nvec, uint64_t seg,
+                                   const uint16_t* __restrict__ lut)
+{
+    __shared__ uint16_t sl[256];
+    sl[threadIdx.x] = lut[threadIdx.x];
+    __syncthreads();
+    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * 256) {
+        uint32_t pw[8][4];                                               // pw[b] = 16 bytes of the plane that carries bit b
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+            const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(in + (uint64_t)(7 - b) * seg) + v);
+            pw[b][0] = t.x; pw[b][1] = t.y; pw[b][2] = t.z; pw[b][3] = t.w;
+        }
+        v4u* dst = reinterpret_cast<v4u*>(out + v * 128);
+#pragma unroll
+        for (int g = 0; g < 16; ++g) {
+            // byte b of t = plane byte of bit b, voxel j at bit j after the per-byte bit reversal (stored with voxel j at bit 7-j)
+            uint64_t t = 0;
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t byte = (pw[b][g >> 2] >> (8 * (g & 3))) & 0xffu;
+                t |= (uint64_t)(__brev(byte) >> 24) << (8 * b);
+            }
+            // 8x8 bit transpose (its own inverse): byte j = voxel j
+            uint64_t y;
+            y = (t ^ (t >> 7)) & 0x00AA00AA00AA00AAull; t = t ^ y ^ (y << 7);
+            y = (t ^ (t >> 14)) & 0x0000CCCC0000CCCCull; t = t ^ y ^ (y << 14);
+            y = (t ^ (t >> 28)) & 0x00000000F0F0F0F0ull; t = t ^ y ^ (y << 28);
+            const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+            v4u o;
+            o.x = (uint32_t)sl[lo & 0xffu] | ((uint32_t)sl[(lo >> 8) & 0xffu] << 16);
+            o.y = (uint32_t)sl[(lo >> 16) & 0xffu] | ((uint32_t)sl[lo >> 24] << 16);
+            o.z = (uint32_t)sl[hi & 0xffu] | ((uint32_t)sl[(hi >> 8) & 0xffu] << 16);
+            o.w = (uint32_t)sl[(hi >> 16) & 0xffu] | ((uint32_t)sl[hi >> 24] << 16);
+            dst[g] = o;
+        }
+    }
+}
+
 // 16-bit, whole tiles of 8192 voxels: the mirror image of bitswap1_u16_regs.  A lane takes 8 consecutive words of every plane
 // (16 coalesced 1 KiB loads per wave), transposes them two groups at a time (the bit transpose is its own inverse) and writes its
 // 128 voxels as 16 x 16 B.  (The generic kernel moves 2 bytes per lane and instruction.)
@@ -3661,6 +3704,22 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
         e = hipStreamWaitEvent(stream, join, 0);
         if (e != hipSuccess) return e;
     }
+    return hipGetLastError();
+}
+
+// true when the fused kernel took the job (8-bit planes of whole 16-byte vectors, aligned buffers); false: run the two stages one by one
+bool bitswap1_u8_decode_lut_possible(const void* in, const void* out, uint64_t len)
+{
+    const uint64_t seg = len / 8;
+    return len != 0 && len % 128 == 0 && seg % 16 == 0 && ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+}
+
+hipError_t launch_bitswap1_u8_decode_lut(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream)
+{
+    const uint64_t seg = len / 8, nvec = seg / 16;
+    uint64_t g = (nvec + 255) / 256;
+    if (g > 65536) g = 65536;
+    hipLaunchKernelGGL(bitswap1_u8_decode_lut_kernel, dim3((unsigned)g), dim3(256), 0, stream, in, out, nvec, seg, lut);
     return hipGetLastError();
 }
 
