@@ -41,8 +41,10 @@ def data(shape, dtype, kind):
     return a.astype(dtype).reshape(shape)
 
 
-t0 = time.time(); cases = 0; skipped = 0
+t0 = time.time(); cases = 0; skipped = 0; last_note = t0
 while time.time() - t0 < budget:
+    if time.time() - last_note > 60:
+        print("  ... %d cases equal so far" % cases, flush=True); last_note = time.time()
     dtype = np.uint16 if rng.random() < 0.7 else np.uint8
     pipe = str(rng.choice(PIPES16 if dtype == np.uint16 else PIPES8))
     big = rng.random() < float(os.environ.get("STRESS_BIG", "0.15"))
