@@ -31,16 +31,16 @@
  * (JSON + "|01307#!" delimiter, including leading pad). */
 SQY_FUNCTION_PREFIX int SQY_Header_Size(const char* src, long* length);
 
-/* inc/sqeazy.h:40, src/sqeazy.cpp:24-34.  *num in: bytes at src; out: rank of the stored volume. */
+/* inc/sqeazy.h:41, src/sqeazy.cpp:24-33.  *num in: bytes at src; out: rank of the stored volume. */
 SQY_FUNCTION_PREFIX int SQY_Decompressed_NDims(const char* src, long* num);
 
-/* inc/sqeazy.h:55, src/sqeazy.cpp:36-47.  shape[0] in: bytes at src; out: shape[0..rank) = {z,y,x}. */
+/* inc/sqeazy.h:56, src/sqeazy.cpp:35-46.  shape[0] in: bytes at src; out: shape[0..rank) = {z,y,x}. */
 SQY_FUNCTION_PREFIX int SQY_Decompressed_Shape(const char* src, long* shape);
 
-/* inc/sqeazy.h:69, src/sqeazy.cpp:49-59.  *Sizeof in: bytes at src; out: bytes per voxel. */
+/* inc/sqeazy.h:70, src/sqeazy.cpp:48-58.  *Sizeof in: bytes at src; out: bytes per voxel. */
 SQY_FUNCTION_PREFIX int SQY_Decompressed_Sizeof(const char* src, long* Sizeof);
 
-/* inc/sqeazy.h:81, src/sqeazy.cpp:62-69.  version[0..3) = major, minor, patch. */
+/* inc/sqeazy.h:81, src/sqeazy.cpp:61-69.  version[0..3) = major, minor, patch. */
 SQY_FUNCTION_PREFIX int SQY_Version_Triple(int* version);
 
 /* inc/sqeazy.h:109-115, src/sqeazy.cpp:72-106.  Encode a uint8 volume.
@@ -49,11 +49,11 @@ SQY_FUNCTION_PREFIX int SQY_Version_Triple(int* version);
  *   shape       long[shape_size], voxels per dimension
  *   dst         at least SQY_Pipeline_Max_Compressed_Length_* bytes
  *   dstlength   out only: bytes written (header + payload)
- *   nthreads    <=0 or > hardware threads: all hardware threads.  The value selects the LZ4 LAYOUT
- *               exactly as in the reference (encoders/lz4.hpp:227-239): effective 1 -> one
- *               block-linked frame (NOT available on MI355X, returns 1 unless the stream fits one
- *               chunk); >=2 -> one independent frame per 256 KiB chunk (byte-identical for every
- *               count >= 2), which is what the GPU produces. */
+ *   nthreads    <=0 or > hardware threads: all hardware threads (src/sqeazy_algorithms.hpp:14-22).  The value selects
+ *               the LZ4 LAYOUT exactly as in the reference (encoders/lz4.hpp:227-239): effective 1 -> ONE frame of
+ *               block-linked 256 KiB blocks (lz4_utils.hpp:99-173; produced on the GPU by one wavefront per frame:
+ *               bit-identical, but serial -- about 1.3 GB/s); >=2 -> one independent frame per 256 KiB chunk
+ *               (lz4_utils.hpp:193-274; byte-identical for every count >= 2; the fast path). */
 SQY_FUNCTION_PREFIX int SQY_PipelineEncode_UI8(const char* pipeline, const char* src, long* shape, unsigned shape_size,
                                                char* dst, long* dstlength, int nthreads);
 
@@ -70,9 +70,12 @@ SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_UI16(const char* pipe
 SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI8(const char* pipeline, long* shape, unsigned shape_size, long* length);
 SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI16(const char* pipeline, long* shape, unsigned shape_size, long* length);
 
-/* inc/sqeazy.h:219-243, src/sqeazy.cpp:233-268.  true iff the string parses as head filters -> sink ->
- * tail filters AND every stage is implemented here: diff3x3x1, bitswap1, frame_shuffle, raster_reorder, quantiser, lz4.
- * (The reference additionally accepts its background-removal filters, tile_shuffle, zcurve_reorder and pass_through.) */
+/* inc/sqeazy.h:219-243, src/sqeazy.cpp:233-268.  true iff the string parses as head filters -> sink -> tail filters
+ * (src/sqeazy_pipelines.hpp:31-77) AND every stage is implemented here.  Head filters: diff3x3x1, bitswap1, bitshuffle,
+ * raster_reorder, tile_shuffle, frame_shuffle, zcurve_reorder; sinks: pass_through, quantiser (16-bit input; every
+ * weighting_function with a finite exponent, decode_lut_path), lz4 (accel 1 or 2); tail filters on the sink's bytes: bitswap1,
+ * bitshuffle, lz4.  false where the reference says true: the background filters (remove_background, rmbkrd_neighbor5x5x5,
+ * rmestbkrd), the video sinks, and diff3x3x1 / raster_reorder / tile_shuffle / frame_shuffle / zcurve_reorder as TAIL filters. */
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI16(const char* pipeline_string);
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI8(const char* pipeline_string);
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible(const char* pipeline_string, int sizeofpixel);

@@ -64,6 +64,9 @@ void sqo_histogram_u8(const uint8_t* in, size_t len, uint32_t* histo /*256*/);
 /* builds lut_encode[nbins] (bytes) and lut_decode[256] (as raw type, widened to u16) from a histogram,
  * weighting_function=none.  nbins = 65536 (u16) or 256 (u8). */
 void sqo_quantiser_build_luts(const uint32_t* histo, size_t nbins, uint8_t* lut_encode, uint16_t* lut_decode);
+/* mode 0 none, 1 power_of(num, den), 2 offset_power_of(num, den)  (encoders/quantiser_weighters.hpp:20-160) */
+void sqo_quantiser_weights(const uint32_t* histo, size_t nbins, int mode, int num, int den, float* weights);
+void sqo_quantiser_build_luts_w(const uint32_t* histo, size_t nbins, int mode, int num, int den, uint8_t* lut_encode, uint16_t* lut_decode);
 void sqo_quantiser_apply_u16(const uint16_t* in, size_t len, const uint8_t* lut_encode, uint8_t* out);
 void sqo_quantiser_apply_u8(const uint8_t* in, size_t len, const uint8_t* lut_encode, uint8_t* out);
 

@@ -298,19 +298,45 @@ def histogram(a):
     return h
 
 
-def quantiser_build_luts(histo):
+def quantiser_weighting(text):
+    """(mode, numerator, denominator) the way quantiser_scheme::encode reads `weighting_function`
+    (quantiser_scheme_impl.hpp:186-198, extract_ratio :25-47): a string containing "none" -> weights 1; otherwise every run of
+    digits is an integer -- one: exponent n/1, two: n/d, anything else: 0/0 -- and "offset" anywhere selects offset_power_of.
+    A string without "_" also gives 0/0.  0/0 and n/0 (NaN / infinite exponents) are rejected here: the reference computes
+    garbage LUTs from them."""
+    import re
+    if "none" in text:
+        return 0, 1, 1
+    ints = [int(t) for t in re.findall(r"[0-9]+", text)] if "_" in text else []
+    if len(ints) == 1:
+        ints.append(1)
+    if len(ints) != 2 or ints[1] == 0:
+        raise ValueError("weighting_function=%s: the reference's exponent is not a finite number" % text)
+    return (2 if "offset" in text else 1), ints[0], ints[1]
+
+
+def quantiser_weights(histo, weighting="none"):
+    histo = _c(histo, np.uint32)
+    mode, num, den = quantiser_weighting(weighting)
+    w = np.zeros(histo.size, dtype=np.float32)
+    lib().sqo_quantiser_weights(_ptr(histo, _u32p), ctypes.c_size_t(histo.size), mode, num, den, w.ctypes.data_as(ctypes.POINTER(ctypes.c_float)))
+    return w
+
+
+def quantiser_build_luts(histo, weighting="none"):
     histo = _c(histo, np.uint32)
     enc = np.zeros(histo.size, dtype=np.uint8)
     dec = np.zeros(256, dtype=np.uint16)
-    lib().sqo_quantiser_build_luts(_ptr(histo, _u32p), ctypes.c_size_t(histo.size), _ptr(enc, _u8p), _ptr(dec, _u16p))
+    mode, num, den = quantiser_weighting(weighting)
+    lib().sqo_quantiser_build_luts_w(_ptr(histo, _u32p), ctypes.c_size_t(histo.size), mode, num, den, _ptr(enc, _u8p), _ptr(dec, _u16p))
     return enc, dec
 
 
-def quantiser_encode(a):
-    """quantiser_scheme<T,char>::encode (quantiser_scheme_impl.hpp:176-226), weighting none.
+def quantiser_encode(a, weighting="none"):
+    """quantiser_scheme<T,char>::encode (quantiser_scheme_impl.hpp:176-226).
     returns (bytes as uint8 array of a.shape, lut_decode as array of a.dtype[256])"""
     a = np.ascontiguousarray(a)
-    enc, dec = quantiser_build_luts(histogram(a))
+    enc, dec = quantiser_build_luts(histogram(a), weighting)
     flat = a.reshape(-1)
     out = np.empty(flat.size, dtype=np.uint8)
     if a.dtype == np.uint16:
@@ -318,6 +344,25 @@ def quantiser_encode(a):
     else:
         lib().sqo_quantiser_apply_u8(_ptr(flat, _u8p), ctypes.c_size_t(flat.size), _ptr(enc, _u8p), _ptr(out, _u8p))
     return out.reshape(a.shape), dec.astype(a.dtype)
+
+
+def lut_to_file(path, lut):
+    """quantiser::lut_to_file (quantiser_utils.hpp:490-498): one decimal value per line"""
+    with open(path, "w") as f:
+        for v in lut:
+            f.write("%d\n" % int(v))
+
+
+def lut_from_file(path, dtype=np.uint16):
+    """quantiser::lut_from_file (quantiser_utils.hpp:501-515): whitespace-separated values into a 256-entry table"""
+    lut = np.zeros(256, dtype=dtype)
+    try:
+        vals = open(path).read().split()
+    except OSError:
+        vals = []
+    for i, t in enumerate(vals[:256]):
+        lut[i] = int(t)
+    return lut
 
 
 def raster_reorder(a, tile_size=None, decode=False):
@@ -792,8 +837,11 @@ def pipeline_encode(pipeline, vol, nthreads=2):
         elif s.name == "bitshuffle":
             cur = bitshuffle(cur, s.block)
         elif s.name == "quantiser":
-            cur, dec = quantiser_encode(cur)
-            s.cmap["decode_lut_string"] = to_verbatim(dec)
+            cur, dec = quantiser_encode(cur, s.cmap.get("weighting_function", "none"))
+            if "decode_lut_path" in s.cmap:                    # quantiser_scheme_impl.hpp:200-204: to the file INSTEAD of the header
+                lut_to_file(s.cmap["decode_lut_path"], dec)
+            else:
+                s.cmap["decode_lut_string"] = to_verbatim(dec)
         elif s.name == "lz4":
             payload = lz4_encode(cur.reshape(-1).view(np.uint8), s.lz4, nthreads)
             cur = payload
@@ -835,9 +883,12 @@ def pipeline_decode(blob):
             cur = diff3x3x1_decode(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]))
         elif s.name == "quantiser":
             import base64
-            lut = s.cmap["decode_lut_string"]
-            lut = lut[len("<verbatim>"):-len("</verbatim>")]
-            dec = np.frombuffer(base64.b64decode(lut), dtype=dtype)
+            if "decode_lut_path" in s.cmap:                    # quantiser_scheme_impl.hpp:83-85 (constructor): the file wins
+                dec = lut_from_file(s.cmap["decode_lut_path"], dtype)
+            else:
+                lut = s.cmap["decode_lut_string"]
+                lut = lut[len("<verbatim>"):-len("</verbatim>")]
+                dec = np.frombuffer(base64.b64decode(lut), dtype=dtype)
             cur = dec[np.ascontiguousarray(cur).view(np.uint8)]
         elif s.name == "raster_reorder":
             cur = raster_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)

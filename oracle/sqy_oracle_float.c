@@ -27,19 +27,40 @@ void sqo_histogram_u8(const uint8_t* in, size_t len, uint32_t* histo)
     for (size_t i = 0; i < len; ++i) histo[in[i]] += 1;
 }
 
-/* encoders/quantiser_utils.hpp:386-418 (setup_com) with weighters::none:
- *   importance[i] = histo[i] * 1.f                                   (:154-168)
+/* encoders/quantiser_weighters.hpp:20-160 as selected by quantiser_scheme_impl.hpp:186-198 (computeWeights,
+ * quantiser_utils.hpp:317-322; the weights start out as 1.f, :85,104):
+ *   mode 0  none                       weights stay 1.f
+ *   mode 1  power_of(num, den)         weights[i] = std::pow(i, exponent) for every bin             (:121-136)
+ *   mode 2  offset_power_of(num, den)  weights[i] = std::pow(i - offset, exponent) for i >= offset, offset = first non-zero
+ *                                      bin of the histogram; the bins below keep 1.f               (:40-84)
+ * exponent = float(num) / den (:32,110).  i is an integer (omp_size_type), so std::pow promotes both arguments to double
+ * and the result is narrowed to the float element. */
+void sqo_quantiser_weights(const uint32_t* histo, size_t nbins, int mode, int num, int den, float* weights)
+{
+    for (size_t i = 0; i < nbins; ++i) weights[i] = 1.f;
+    if (mode == 0) return;
+    const float exponent = (float)num / den;
+    size_t offset = 0;
+    if (mode == 2) while (offset < nbins && !histo[offset]) ++offset;
+    for (size_t i = offset; i < nbins; ++i) weights[i] = (float)pow((double)(long long)(i - offset), (double)exponent);
+}
+
+/* encoders/quantiser_utils.hpp:386-418 (setup_com):
+ *   importance[i] = histo[i] * weights[i]                            (:154-168)
  *   importanceSum = (float) sum over importance accumulated in double (:400, init `0.`)
  *   n_levels <= 256 -> linear_mapping_quantisation (:286-306) else adaptive_lloyd_com (:227-284)
  * lut_encode is `char` in the reference; its bytes are what is stored, so uint8_t here. */
-void sqo_quantiser_build_luts(const uint32_t* histo, size_t nbins, uint8_t* lut_encode, uint16_t* lut_decode)
+void sqo_quantiser_build_luts_w(const uint32_t* histo, size_t nbins, int mode, int num, int den, uint8_t* lut_encode, uint16_t* lut_decode)
 {
     const size_t max_compressed = 256;
     const uint16_t raw_max = (nbins == 65536) ? 65535 : 255;
     float* importance = (float*)malloc(nbins * sizeof(float));
+    float* weights = (float*)malloc(nbins * sizeof(float));
     memset(lut_encode, 0, nbins);
     memset(lut_decode, 0, max_compressed * sizeof(uint16_t));
-    for (size_t i = 0; i < nbins; ++i) importance[i] = (float)histo[i] * 1.f;
+    sqo_quantiser_weights(histo, nbins, mode, num, den, weights);
+    for (size_t i = 0; i < nbins; ++i) importance[i] = (float)histo[i] * weights[i];
+    free(weights);
 
     double acc = 0.;
     for (size_t i = 0; i < nbins; ++i) acc = acc + importance[i];
@@ -88,6 +109,11 @@ void sqo_quantiser_build_luts(const uint32_t* histo, size_t nbins, uint8_t* lut_
         lut_decode[comp_idx] = (uint16_t)index_wmean;
     }
     free(importance);
+}
+
+void sqo_quantiser_build_luts(const uint32_t* histo, size_t nbins, uint8_t* lut_encode, uint16_t* lut_decode)
+{
+    sqo_quantiser_build_luts_w(histo, nbins, 0, 1, 1, lut_encode, lut_decode);
 }
 
 /* encoders/quantiser_utils.hpp:26-42 (applyLUT) via quantiser_scheme_impl.hpp:206-223 */

@@ -553,7 +553,12 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 uint16_t lut_decode[256];
                 SQY_HIP(hipMemcpyAsync(histo.data(), d_histo, 65536 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 SQY_HIP(hipStreamSynchronize(stream));
-                sqy::quantiser_build_luts(histo.data(), 65536, lut_encode.data(), lut_decode);
+                sqy::QuantiserWeighting qw;
+                {
+                    auto wf = st.cfg.find("weighting_function");
+                    if (wf != st.cfg.end() && !sqy::quantiser_parse_weighting(wf->second, &qw)) return 1;    // (refused by supported() already)
+                }
+                sqy::quantiser_build_luts(histo.data(), 65536, lut_encode.data(), lut_decode, qw);
                 SQY_HIP(hipMemcpyAsync(d_lut, lut_encode.data(), 65536, hipMemcpyHostToDevice, stream));
                 uint8_t* out = next_buf(cur_len);
                 if (!out) return 1;
@@ -562,7 +567,15 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     SQY_HIP(sqy::launch_quantiser_apply_u16(reinterpret_cast<const uint16_t*>(cur), out, cur_len, d_lut, stream));
                 }
                 SQY_HIP(hipStreamSynchronize(stream));                     // lut_encode (host) is read by the async copy above
-                st.cfg["decode_lut_string"] = sqy::to_verbatim(lut_decode, sizeof(lut_decode));
+                {
+                    // quantiser_scheme_impl.hpp:200-204: the decode LUT goes to the file the caller named, else into the header
+                    auto lp = st.cfg.find("decode_lut_path");
+                    if (lp != st.cfg.end()) {
+                        if (!sqy::quantiser_lut_to_file(lp->second, lut_decode, 256))
+                            std::fprintf(stderr, "[sqeazy]\t quantiser: unable to write the decode LUT to %s\n", lp->second.c_str());   // (the reference does not notice)
+                    } else
+                        st.cfg["decode_lut_string"] = sqy::to_verbatim(lut_decode, sizeof(lut_decode));
+                }
                 cur = out;
                 cur_elem = 1;                                              // sink output is `char`
                 break;
@@ -752,15 +765,44 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
 // the quantiser's decode LUT (256 x u16, base64 in the header) into ws->small; synchronous: the host copy does not outlive the call
 int quantiser_lut_to_device(const sqy::Stage& st, Workspace* ws, hipStream_t stream)
 {
-    auto it = st.cfg.find("decode_lut_string");
-    if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t quantiser: no decode_lut_string in the header\n"); return 1; }
-    const std::string b64 = it->second.substr(10, it->second.size() - 21);   // strip <verbatim> ... </verbatim>
-    const std::vector<unsigned char> lut = sqy::base64_decode(b64);
+    std::vector<unsigned char> lut;
+    auto lp = st.cfg.find("decode_lut_path");
+    if (lp != st.cfg.end()) {
+        // quantiser_scheme_impl.hpp:83-85: a path in the configuration wins over a LUT string
+        lut.resize(512);
+        if (!sqy::quantiser_lut_from_file(lp->second, reinterpret_cast<uint16_t*>(lut.data()), 256)) {
+            std::fprintf(stderr, "lut from %s cannot be loaded, decoding skipped\n", lp->second.c_str());               // quantiser_utils.hpp:559-562
+            return 1;
+        }
+    } else {
+        auto it = st.cfg.find("decode_lut_string");
+        if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t quantiser: no decode_lut_string in the header\n"); return 1; }
+        const std::string b64 = it->second.substr(10, it->second.size() - 21);   // strip <verbatim> ... </verbatim>
+        lut = sqy::base64_decode(b64);
+    }
     if (lut.size() != 512) { std::fprintf(stderr, "[sqeazy]\t quantiser: malformed decode LUT\n"); return 1; }
     if (ws->small.ensure(4096)) return 1;
     SQY_HIP(hipMemcpy(ws->small.p, lut.data(), 512, hipMemcpyHostToDevice));
     (void)stream;
     return 0;
+}
+
+// The header of a blob is untrusted input: rank 1..16, every extent positive and below 2^31, fewer than 2^31 voxels (what one
+// encode call can have produced), header and payload inside the blob.  *raw_bytes = decoded size.
+bool header_shape_ok(const sqy::HeaderInfo& h, uint64_t srclen, uint64_t* raw_bytes)
+{
+    if (h.shape.empty() || h.shape.size() > 16) { std::fprintf(stderr, "[sqeazy]\t decode: header with rank %zu\n", h.shape.size()); return false; }
+    uint64_t n = 1;
+    for (uint64_t d : h.shape) {
+        if (d == 0 || d >= ((uint64_t)1 << 31)) { std::fprintf(stderr, "[sqeazy]\t decode: header with an extent of %llu\n", (unsigned long long)d); return false; }
+        n *= d;
+        if (n >= ((uint64_t)1 << 31)) { std::fprintf(stderr, "[sqeazy]\t decode: header claims 2^31 or more voxels\n"); return false; }
+    }
+    const int elem = h.elem_size();
+    if (elem != 1 && elem != 2) { std::fprintf(stderr, "[sqeazy]\t decode: blob holds %s voxels\n", h.type.c_str()); return false; }
+    if (h.size > srclen || h.payload_bytes > srclen - h.size) { std::fprintf(stderr, "[sqeazy]\t decode: blob truncated\n"); return false; }
+    *raw_bytes = n * (uint64_t)elem;
+    return true;
 }
 
 int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_dst, uint64_t dst_capacity, int want_elem, hipStream_t stream)
@@ -793,15 +835,10 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
     Pipeline pipe = Pipeline::from_string(h.pipename);
     // the header is untrusted input: every extent positive, the voxel count below 2^31 (what one encode call can have
     // produced), no wrap-around anywhere
-    if (h.shape.empty() || h.shape.size() > 16) { std::fprintf(stderr, "[sqeazy]\t decode: header with rank %zu\n", h.shape.size()); return 1; }
-    uint64_t n = 1;
-    for (uint64_t d : h.shape) {
-        if (d == 0 || d >= ((uint64_t)1 << 31)) { std::fprintf(stderr, "[sqeazy]\t decode: header with an extent of %llu\n", (unsigned long long)d); return 1; }
-        n *= d;
-        if (n >= ((uint64_t)1 << 31)) { std::fprintf(stderr, "[sqeazy]\t decode: header claims 2^31 or more voxels\n"); return 1; }
-    }
-    const uint64_t raw_bytes = n * (uint64_t)elem;
-    if (raw_bytes > dst_capacity || h.size > srclen || h.payload_bytes > srclen - h.size) {
+    uint64_t raw_bytes = 0;
+    if (!header_shape_ok(h, srclen, &raw_bytes)) return 1;
+    const uint64_t n = raw_bytes / (uint64_t)elem;
+    if (raw_bytes > dst_capacity) {
         std::fprintf(stderr, "[sqeazy]\t decode: buffer too small or blob truncated\n");
         return 1;
     }
@@ -1080,9 +1117,8 @@ int decode_from_host(const char* src, long srclength, char* dst, int elem_size)
     Workspace* ws = &lease.ctx->ws;
     hipStream_t stream = lease.ctx->own_stream();
     if (!stream) { std::fprintf(stderr, "[sqeazy]\t no HIP stream\n"); return 1; }
-    uint64_t n = 1;
-    for (uint64_t d : h.shape) n *= d;
-    const uint64_t raw = n * (uint64_t)h.elem_size();
+    uint64_t raw = 0;
+    if (!header_shape_ok(h, (uint64_t)srclength, &raw)) return 1;          // untrusted input: before anything is allocated or uploaded
     if (ws->io_src.ensure(std::max<uint64_t>((uint64_t)srclength, 16)) || ws->io_dst.ensure(std::max<uint64_t>(raw, 16))) return 1;
     int dev_id = 0;
     SQY_HIP(hipGetDevice(&dev_id));
@@ -1380,7 +1416,14 @@ int SQYAMD_Header_Build(const char* pipeline, int sizeof_voxel, const long* shap
         if (!sqy::Pipeline::supported(pipeline, sizeof_voxel)) return 1;
         const sqy::Pipeline p = sqy::Pipeline::from_string(pipeline, sizeof_voxel);
         std::vector<uint64_t> shp(shape, shape + shape_size);
-        for (uint64_t v : shp) if ((long)v <= 0) return 1;
+        // what one encode call can have produced: < 2^31 voxels, at most INT_MAX payload bytes (decode refuses anything else)
+        uint64_t nvox = 1;
+        for (uint64_t v : shp) {
+            if ((long)v <= 0 || v >= ((uint64_t)1 << 31)) return 1;
+            nvox *= v;
+            if (nvox >= ((uint64_t)1 << 31)) return 1;
+        }
+        if (encoded_bytes > (long)INT_MAX) return 1;
         const std::string hdr = sqy::header_pack(sizeof_voxel, false, shp, p.name(), (uint64_t)encoded_bytes);
         const long need = (long)hdr.size();
         const long have = out ? *outlength : 0;

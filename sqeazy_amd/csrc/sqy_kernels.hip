@@ -57,10 +57,15 @@ __device__ __forceinline__ uint64_t lds_ld_u64(const lds_u8* p) { return reinter
 typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));
 // ONE 16-byte load: four field loads get split by the optimiser into a b64 now and a conditional b64 later when only
 // the low half decides a branch -- a second dependent LDS round trip on the parse's critical path
+// ... issued as TWO 8-byte reads: a ds_read_b128 whose address is not a multiple of 16 is replayed (measured 146 instead of
+// 90 cycles in a dependent chain, tools/lds_bench.hip; SQ_LDS_UNALIGNED_STALL 20 % of the wave-cycles of the round-2 kernel),
+// ds_read_b64 is not (82 cycles at any alignment).  volatile: keeps the two from being merged back into one b128 and from
+// being split into "now" and "later".
 __device__ __forceinline__ uint4 lds_ld_u128(const lds_u8* p)
 {
-    const v4u_any t = *reinterpret_cast<const SQY_LDS v4u_any*>(p);
-    return make_uint4(t.x, t.y, t.z, t.w);
+    const uint64_t lo = reinterpret_cast<const volatile SQY_LDS pk_u64*>(p)->v;
+    const uint64_t hi = reinterpret_cast<const volatile SQY_LDS pk_u64*>(p + 8)->v;
+    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
 }
 __device__ __forceinline__ uint32_t glb_ld_u8(glb_u8* p) { return *p; }
 __device__ __forceinline__ uint32_t glb_ld_u32(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u32*>(p)->v; }
@@ -82,7 +87,9 @@ __device__ __forceinline__ void wave_lds_sync()
 }
 __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
-__device__ __forceinline__ uint64_t ballot(bool p) { return __ballot(p); }
+// (the builtin on a bool: __ballot() first turns the lane mask into 0 / 1 per lane and compares that again -- two vector
+// instructions and their latency per ballot on the parse's critical path)
+__device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 
 // ------------------------------------------------------------------------------------------------
@@ -614,15 +621,24 @@ __device__ __forceinline__ void wave_copy(uint8_t* __restrict__ d, const Lz4Wind
 }
 
 // index of the first differing byte of two 16-byte values (16 when equal)
+// v_ffbl_b32 itself: bit index of the lowest set bit, ~0 for 0.  (__builtin_ffs(v) - 1 means the same, but the compiler does
+// not know that the instruction already yields ~0 for 0 and adds a compare and a select per dword -- 30 instead of 16
+// instructions on the parse's critical path.)
+__device__ __forceinline__ uint32_t ffbl(uint32_t v)
+{
+    uint32_t r;
+    asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
+    return r;
+}
 __device__ __forceinline__ uint32_t first_diff16(uint4 x, uint4 y)
 {
-    // ffs(v) - 1 is v_ffbl_b32: the bit index, or ~0 for v == 0.  "| 32 k" adds the dword offset to a real index and
-    // leaves the "no difference in this dword" marker above every index.  Straight-line on purpose: the branchy form
-    // (low half first, high half only if equal) costs two exec-mask regions per call on the parse's critical path.
-    const uint32_t t0 = (uint32_t)(__builtin_ffs((int)(x.x ^ y.x)) - 1);
-    const uint32_t t1 = (uint32_t)(__builtin_ffs((int)(x.y ^ y.y)) - 1) | 32u;
-    const uint32_t t2 = (uint32_t)(__builtin_ffs((int)(x.z ^ y.z)) - 1) | 64u;
-    const uint32_t t3 = (uint32_t)(__builtin_ffs((int)(x.w ^ y.w)) - 1) | 96u;
+    // "| 32 k" adds the dword offset to a real index and leaves the "no difference in this dword" marker (~0) above every
+    // index.  Straight-line on purpose: the branchy form (low half first, high half only if equal) costs two exec-mask
+    // regions per call.
+    const uint32_t t0 = ffbl(x.x ^ y.x);
+    const uint32_t t1 = ffbl(x.y ^ y.y) | 32u;
+    const uint32_t t2 = ffbl(x.z ^ y.z) | 64u;
+    const uint32_t t3 = ffbl(x.w ^ y.w) | 96u;
     const uint32_t a = t0 < t1 ? t0 : t1, b = t2 < t3 ? t2 : t3;
     const uint32_t m = a < b ? a : b;
     return (m < 128u ? m : 128u) >> 3;
@@ -824,24 +840,43 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         bool pend = false;
         uint32_t pe_lit = 0, pe_mcode = 0, pe_off = 0;
         uint32_t pe_litv = 0;            // per lane: literal byte k-1 for lane k
-        auto emit_pending = [&]() {
+        // two halves, so that the lean loop can run each in the shadow of a different LDS round trip: the output-limit checks
+        // and the room in the stage (scalar), then the bytes (one per lane)
+        uint32_t pe_bytes = 0, pe_ext = 0;
+        auto emit_pending_checks = [&]() {
+            const uint32_t lit = pe_lit, matchCode = pe_mcode;
+            pe_ext = (matchCode + 240u) / 255u;                                     // = (matchCode - 15) / 255 + 1 from 15 on, else 0
+            pe_bytes = 1u + lit + 2u + pe_ext;                                      // <= 1 + 14 + 2 + 4
+            // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension.  Both are
+            // below op + 15 + 8 + 5 (at most 4 extension bytes for the matches the lean loop settles): far from the end of
+            // the output nothing has to be looked at
+            if (op + 33u > olimit &&
+                (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
+                 op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + pe_ext > olimit)) { failed = true; return; }
+            o.reserve(op, pe_bytes);
+        };
+        auto emit_pending_bytes = [&]() {
             pend = false;
-            const uint32_t lit = pe_lit, matchCode = pe_mcode, offset = pe_off;
-            const uint32_t ml_ext = matchCode >= 15u ? (matchCode - 15u) / 255u + 1u : 0u;
-            const uint32_t seq_bytes = 1u + lit + 2u + ml_ext;                      // <= 1 + 14 + 2 + 5
-            // upstream's two limit checks; lit < 15 so lit/255 == 0 and there is no literal-length extension
-            if (op + 1u + lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
-                op + 1u + lit + 2u + (1 + LZ4_LASTLITERALS) + (matchCode + 240u) / 255u > olimit) { failed = true; return; }
-            o.reserve(op, seq_bytes);
+            const uint32_t lit = pe_lit, matchCode = pe_mcode, ml_ext = pe_ext;
+            // everything behind the literals as one little-endian value: offset, then ml_ext - 1 bytes of 255 and the rest
+            // (ml_ext <= 4 here: matches of at most 1 KiB + catch-up).  No lane-dependent branches: the select chain this
+            // replaces was compiled into exec-mask regions.
+            const uint32_t rest = matchCode - 15u - (ml_ext - 1u) * 255u;           // (unused when ml_ext == 0)
+            const uint64_t ones = (1ull << (8u * (ml_ext ? ml_ext - 1u : 0u))) - 1ull;
+            const uint64_t tail = (uint64_t)pe_off | (ml_ext ? ((ones | ((uint64_t)rest << (8u * (ml_ext - 1u)))) << 16) : 0ull);
             const uint32_t k = (uint32_t)lane;
-            uint32_t v = ((lit << 4) | (matchCode < 15u ? matchCode : 15u));
-            v = (k >= 1u && k <= lit) ? pe_litv : v;
-            v = (k == lit + 1u) ? (offset & 0xffu) : v;
-            v = (k == lit + 2u) ? (offset >> 8) : v;
-            const uint32_t j = k - (lit + 3u);
-            v = (k > lit + 2u) ? ((j + 1u < ml_ext) ? 255u : (matchCode - 15u - (ml_ext - 1u) * 255u)) : v;
-            if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
-            op += seq_bytes;
+            const uint32_t j = k - (lit + 1u);                                      // byte of `tail` for the lanes behind the literals
+            const uint32_t tb = (uint32_t)(tail >> (8u * (j & 7u))) & 0xffu;
+            uint32_t v = (lit << 4) | (matchCode < 15u ? matchCode : 15u);
+            v = (k - 1u) < lit ? pe_litv : v;
+            v = k > lit ? tb : v;
+            if (k < pe_bytes) *o.at(op + k) = (uint8_t)v;
+            op += pe_bytes;
+        };
+        auto emit_pending = [&]() {
+            emit_pending_checks();
+            if (failed) { pend = false; return; }
+            emit_pending_bytes();
         };
 
         for (;;) {
@@ -1042,15 +1077,31 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 // count): otherwise its waitcnt pass puts a vmcnt(0) in front of the loop's first ring read, and that
                 // one would wait for the ring block in flight on EVERY iteration.
                 __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0)
+                // per lane: offset of its position from P (probes 0..14; lane 15 performs the pending LZ4_putPosition(P - 2) with
+                // the same instructions), and a word that is non-zero for lanes that do not probe
+                const bool putlane = lane == 15;
+                const uint32_t posoff = putlane ? 0xfffffffeu : (uint32_t)lane;
+                const uint32_t notprobe = (uint32_t)lane < 15u ? 0u : 1u;
                 for (;;) {
-                    if (!(P >= w.wlo + 4u && P + 1200u <= w.hi_valid() && P + 1200u <= matchlimit)) break;
+                    {
+                        // (all scalar: a three-way vector minimum here costs the loop a round through VCC per iteration)
+                        const uint32_t hv = sgpr(w.hi_valid());
+                        const uint32_t top = hv < matchlimit ? hv : matchlimit;
+                        if (!(P >= sgpr(w.wlo) + 4u && P + 1200u <= top)) break;
+                    }
                     SQY_STAMP(1);
-                    const bool putlane = lane == 15;
-                    const uint32_t pos = putlane ? P - 2u : P + (uint32_t)lane;
+                    const uint32_t pos = P + posoff;
                     const uint32_t wlo4 = w.wlo + 4u;
-                    const uint4 s16 = w.lds128(pos);
-                    const uint32_t b4 = w.lds32(pos - 4u);
-                    if (pend) { emit_pending(); if (failed) break; }
+                    // ring offsets of both reads BEFORE the first is issued: computed behind it, the second one's address lands in
+                    // a register the first one is still writing to, and the loop waits for the ring right here (seen in the ISA)
+                    uint32_t o16 = pos & (LZ4_WIN - 1u), o4 = (pos - 4u) & (LZ4_WIN - 1u);
+                    asm volatile("" : "+v"(o16), "+v"(o4));
+                    const uint32_t b4 = lds_ld_u32(w.win + o4);
+                    // (the hash takes five bytes, the tag four: eight bytes per probe are all this batch reads of the sequence)
+                    const uint64_t s8 = lds_ld_u64(w.win + o16);
+                    const uint2 s16 = make_uint2((uint32_t)s8, (uint32_t)(s8 >> 32));
+                    // (in the shadow of those reads: limit checks / stage room of the sequence found in the last iteration)
+                    if (pend) { emit_pending_checks(); if (failed) break; }
                     SQY_STAMP(2);
                     const uint32_t h = lz4_hash5_32(s16.x, s16.y);
                     const uint32_t mytag = tag_of(s16.x);
@@ -1060,73 +1111,75 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     put2 = 0xffffffffu;
                     SQY_STAMP(3);
                     const uint32_t oe = table[h];
+                    // (in the shadow of the table read: its bytes)
+                    if (pend) emit_pending_bytes();
                     const uint32_t old = oe >> tsh;
-                    // tag differs: the candidate's first four bytes differ, it cannot match
-                    const bool near = (uint32_t)lane < 15u && (pos - old) <= LZ4_MAXD && (oe & tmask) == mytag;
-                    const bool cin = near && old >= wlo4;
+                    // tag differs: the candidate's first four bytes differ, it cannot match.  Tag equal: they are equal but for
+                    // one case in 2^tsh -- the FIRST such probe is taken as the winner right away and one wide round (64 lanes x
+                    // 16 bytes from ip / match, ring or global memory) then settles in a single round trip whether the match is
+                    // real and how far it goes (round 2 read every probe's candidate first and only then, for matches of 16
+                    // bytes and more, started the wide round: one dependent round trip more per long match, two when the
+                    // candidate sits behind the ring).
+                    // One word that is zero exactly for a probing lane whose candidate is within reach and carries the tag
+                    // (a single compare feeds the ballot; a boolean expression costs a select and a second compare)
+                    const uint32_t rej = ((oe & tmask) ^ mytag) | ((pos - old) >> 16) | notprobe;
                     SQY_STAMP(4);
-                    uint4 c16 = w.lds128(old);
-                    uint32_t cb4 = w.lds32(old - 4u);
-                    // every lane evaluates itself as the winner: forward bytes, catch-up, flags -- one packed word
-                    uint32_t d = first_diff16(s16, c16);                                // 0..16
-                    SQY_STAMP(5);
-                    // candidates behind the ring (older than ~6 KiB, tag equal so very likely real matches) that sit in
-                    // front of the first ring hit decide the batch: fetch just those from global memory and stay here
-                    const bool far = near && !cin;
-                    const uint64_t farm = ballot(far);
-                    if (farm) {
-                        const uint64_t ml_ = ballot(cin && d >= 4u);
-                        const uint64_t upto = ml_ ? ((2ull << ctz64(ml_)) - 1ull) : ~0ull;
-                        if (farm & upto) {
-                            if (far) {
-                                c16 = glb_ld_u128(w.src + old);                         // old + 16 <= pos + 15 < matchlimit
-                                cb4 = old >= p_lo + 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src + p_lo) << (8u * (4u - (old - p_lo))));
-                                d = first_diff16(s16, c16);
-                            }
-                            SQY_REASON(2);
-                        }
-                    }
-                    SQY_STAMP(6);
-                    const uint64_t mm = ballot(near && d >= 4u);
-                    if (mm == 0) { SQY_REASON(0); break; }
-                    const uint32_t f0 = ctz64(mm);                                      // <= 14
-                    // an earlier probe of this batch in the same bucket would be the true candidate: leave those to the
-                    // generic path (lane 15's put is already in the table, so it needs no check)
-                    bool ok = true;
-                    for (uint32_t c = 1; c <= f0; ++c)
-                        if (ballot(h == lane_read(h, c)) & ((1ull << c) - 1ull)) { ok = false; break; }
-                    if (!ok) { SQY_REASON(3); break; }
-                    SQY_STAMP(7);
+                    const uint64_t nm = ballot(rej == 0u);
+                    if (nm == 0) { SQY_REASON(0); break; }
+                    const uint32_t f0 = ctz64(nm);                                      // <= 14
                     const uint32_t mt0 = lane_read(old, f0);
                     const uint32_t ip0 = P + f0;
-                    uint32_t ml = lane_read(d, f0) - 4u;                                // 0..12
+                    SQY_STAMP(5);
+                    // Commit probes 0..f0 now and read the buckets back: a probe that does not find its own entry shares its
+                    // bucket with another probe of the batch -- the later one's true candidate would be the earlier one --,
+                    // which is left to the generic path below after the buckets are put back (both hold the same old entry).
+                    // (Round 2 compared the hashes lane by lane with readlane before committing: ~16 instructions per probe.)
+                    const bool commit = (uint32_t)lane <= f0;
+                    if (commit) table[h] = mine;
+                    wave_lds_sync();
+                    const uint32_t rb = table[h];
+                    const uint32_t dd = (uint32_t)lane * 16u;
+                    uint32_t g, cb4;
+                    // (two complete branches: a merged load would make the common, ring-only side wait on vmcnt too)
+                    if (mt0 >= wlo4) {
+                        uint32_t ocb = (mt0 - 4u) & (LZ4_WIN - 1u), oi = (ip0 + dd) & (LZ4_WIN - 1u), om = (mt0 + dd) & (LZ4_WIN - 1u);
+                        asm volatile("" : "+v"(ocb), "+v"(oi), "+v"(om));               // (all three reads issued back to back, see the loop top)
+                        cb4 = lds_ld_u32(w.win + ocb);
+                        const uint4 ci = lds_ld_u128(w.win + oi), cm = lds_ld_u128(w.win + om);   // ip side resident and clear of matchlimit (loop condition)
+                        g = first_diff16(ci, cm);
+                    } else {
+                        const uint4 cg = glb_ld_u128(w.src + mt0 + dd);                 // mt0 + 1024 <= ip0 + 1023 < matchlimit
+                        cb4 = mt0 >= p_lo + 4u ? glb_ld_u32(w.src + mt0 - 4u) : (glb_ld_u32(w.src + p_lo) << (8u * (4u - (mt0 - p_lo))));
+                        g = first_diff16(w.lds128(ip0 + dd), cg);
+                        asm volatile("" : "+v"(g));                                     // (keeps the optimiser from re-merging the branches)
+                        SQY_REASON(2);
+                    }
+                    SQY_STAMP(6);
+                    const uint64_t nf = ballot(g != 16u);
+                    uint32_t eq = 1024u;                                                // equal bytes from (ip0, mt0) on
+                    bool settled = false;
+                    if (nf) {
+                        const uint32_t l = ctz64(nf);
+                        eq = l * 16u + lane_read(g, l);
+                        settled = true;
+                    }
+                    SQY_STAMP(7);
+                    if ((ballot(rb != mine) & ((2ull << f0) - 1ull)) != 0ull || eq < 4u) {
+                        // same-bucket probes, or the tag lied (eq < 4): the table as it was, the generic path redoes the batch
+                        if (eq < 4u) SQY_REASON(1); else SQY_REASON(3);
+                        if (commit) table[h] = oe;
+                        wave_lds_sync();
+                        break;
+                    }
+                    const uint32_t ml = eq - 4u;                                        // exact when settled, else "at least"
                     // catch-up of the winner: ip - anchor = f0 literals, match > 0
-                    const uint32_t xb = lane_read(b4 ^ cb4, f0);
+                    const uint32_t xb = lane_read(b4, f0) ^ sgpr(cb4);
                     const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;   // equal bytes in front, 4 = maybe more
                     const uint32_t room0 = back_room(mt0);
                     const uint32_t lim = f0 < room0 ? f0 : room0;
                     const uint32_t bck = bk < lim ? bk : lim;
                     const bool slow_back = bk == 4u && lim > 4u;
-                    bool settled = true;
-                    if (ml == 12u) {
-                        // one wide round: 64 lanes x 16 bytes from ip0+16 / mt0+16 (the ip side resident and clear of matchlimit)
-                        const uint32_t dd = (uint32_t)lane * 16u;
-                        // (two complete branches: a merged load would make the common, ring-only side wait on vmcnt too)
-                        uint32_t g;
-                        if (mt0 >= w.wlo) g = first_diff16(w.lds128(ip0 + 16u + dd), w.lds128(mt0 + 16u + dd));
-                        else { g = first_diff16(w.lds128(ip0 + 16u + dd), glb_ld_u128(w.src + mt0 + 16u + dd)); asm volatile("" : "+v"(g)); }  // (keeps the optimiser from re-merging the branches)
-                        const uint64_t nf = ballot(g != 16u);
-                        if (nf) {
-                            const uint32_t l = ctz64(nf);
-                            ml = 12u + l * 16u + lane_read(g, l);
-                        } else {
-                            ml = 12u + 1024u;
-                            settled = false;
-                        }
-                    }
                     SQY_STAMP(8);
-                    if ((uint32_t)lane <= f0) table[h] = mine;          // commit probes 0..f0: distinct buckets, newer than any entry
-                    wave_lds_sync();
                     if (!settled || slow_back) {
                         // winner known, but the match runs past the wide round or the catch-up past 4 bytes: generic tail
                         if (!settled) SQY_REASON(4); else SQY_REASON(5);

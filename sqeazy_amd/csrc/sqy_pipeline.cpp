@@ -1,8 +1,14 @@
 // sqy_pipeline.cpp -- see sqy_pipeline.hpp.  Pure host logic, no HIP.
 #include "sqy_pipeline.hpp"
 
+// IEEE evaluation in statement order for the quantiser / frame metric host code: no fused multiply-adds (hipcc defaults to
+// -ffp-contract=fast for HIP sources; the declared parity target is the reference compiled without fast-math)
+#pragma clang fp contract(off)
+
 #include <algorithm>
 #include <cmath>
+#include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
@@ -440,9 +446,9 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
             case StageKind::quantiser: {
                 if (elem_size != 2) return fail("quantiser: only 16-bit input is implemented on MI355X");
                 auto w = st.cfg.find("weighting_function");
-                if (w != st.cfg.end() && w->second.find("none") == std::string::npos)
-                    return fail("quantiser: only weighting_function=none is implemented on MI355X");
-                if (st.cfg.count("decode_lut_path")) return fail("quantiser: decode_lut_path is not implemented on MI355X");
+                QuantiserWeighting qw;
+                if (w != st.cfg.end() && !quantiser_parse_weighting(w->second, &qw))
+                    return fail("quantiser: weighting_function=" + w->second + " gives the reference a NaN or infinite exponent; refused");
                 break;
             }
             case StageKind::lz4:
@@ -616,14 +622,72 @@ HeaderInfo header_unpack(const char* begin, const char* end)
 }
 
 // ---- quantiser LUT construction (host, float) ----
-void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode)
+bool quantiser_parse_weighting(const std::string& text, QuantiserWeighting* out)
+{
+    QuantiserWeighting w;
+    if (text.find("none") != std::string::npos) { *out = w; return true; }           // quantiser_scheme_impl.hpp:186
+    if (text.rfind('_') == std::string::npos) return false;                          // extract_ratio :29-32 -> 0/0
+    std::vector<long> ints;                                                          // regex_helpers.hpp:101-115, "[0-9]+"
+    for (size_t i = 0; i < text.size();) {
+        if (text[i] < '0' || text[i] > '9') { ++i; continue; }
+        size_t j = i;
+        long v = 0;
+        while (j < text.size() && text[j] >= '0' && text[j] <= '9') {
+            v = v * 10 + (text[j] - '0');
+            if (v > INT32_MAX) return false;                                         // (std::stoi would throw)
+            ++j;
+        }
+        ints.push_back(v);
+        i = j;
+    }
+    if (ints.size() == 1) ints.push_back(1);
+    if (ints.size() != 2 || ints[1] == 0) return false;
+    w.mode = text.find("offset") != std::string::npos ? 2 : 1;                        // :189
+    w.num = (int)ints[0];
+    w.den = (int)ints[1];
+    *out = w;
+    return true;
+}
+
+bool quantiser_lut_to_file(const std::string& path, const uint16_t* lut, size_t n)
+{
+    FILE* f = std::fopen(path.c_str(), "w");
+    if (!f) return false;
+    for (size_t i = 0; i < n; ++i) std::fprintf(f, "%u\n", (unsigned)lut[i]);
+    return std::fclose(f) == 0;
+}
+
+bool quantiser_lut_from_file(const std::string& path, uint16_t* lut, size_t n)
+{
+    for (size_t i = 0; i < n; ++i) lut[i] = 0;
+    FILE* f = std::fopen(path.c_str(), "r");
+    if (!f) return false;
+    unsigned v = 0;
+    size_t i = 0;
+    while (i < n && std::fscanf(f, "%u", &v) == 1) lut[i++] = (uint16_t)v;
+    std::fclose(f);
+    return true;
+}
+
+void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode,
+                          const QuantiserWeighting& weighting)
 {
     const size_t max_compressed = 256;                                     // quantiser<raw, char>::max_compressed_
     std::vector<float> importance(nbins);
     std::memset(lut_encode, 0, nbins);
     for (size_t i = 0; i < max_compressed; ++i) lut_decode[i] = 0;
-    // computeImportance: importance = histo * weight, weights all 1.f (weighters::none)
-    for (size_t i = 0; i < nbins; ++i) importance[i] = histo[i] * 1.f;
+    // computeWeights (quantiser_utils.hpp:317-322): the weights start out as 1.f (:85,104); power_of writes std::pow(i, e)
+    // into every bin, offset_power_of std::pow(i - offset, e) from the first non-zero bin on (quantiser_weighters.hpp:40-84,
+    // :121-136).  The index is an integer, so std::pow works in double and the result is narrowed to float.
+    std::vector<float> weights(nbins, 1.f);
+    if (weighting.mode != 0) {
+        const float exponent = float(weighting.num) / weighting.den;
+        size_t offset = 0;
+        if (weighting.mode == 2) while (offset < nbins && !histo[offset]) ++offset;
+        for (size_t i = offset; i < nbins; ++i) weights[i] = (float)std::pow((double)(long long)(i - offset), (double)exponent);
+    }
+    // computeImportance: importance = histo * weight
+    for (size_t i = 0; i < nbins; ++i) importance[i] = histo[i] * weights[i];
     // std::accumulate(importance.begin(), importance.end(), 0.) -> double accumulator, assigned to float
     double total = 0.;
     for (size_t i = 0; i < nbins; ++i) total = total + importance[i];

@@ -122,9 +122,22 @@ struct HeaderInfo {
 };
 HeaderInfo header_unpack(const char* begin, const char* end);
 
-// quantiser LUTs from a 65536-bin histogram, weighting "none" (encoders/quantiser_utils.hpp:386-418, :227-306):
+// quantiser `weighting_function` as quantiser_scheme::encode reads it (encoders/quantiser_scheme_impl.hpp:186-198, extract_ratio
+// :25-47): "none" anywhere in the string -> weights 1; otherwise every run of digits is an integer (one: n/1, two: n/d, else
+// 0/0) and "offset" anywhere selects offset_power_of (encoders/quantiser_weighters.hpp:20-95) instead of power_of (:98-160).
+struct QuantiserWeighting {
+    int mode = 0;            // 0 none, 1 power_of, 2 offset_power_of
+    int num = 1, den = 1;    // exponent = float(num) / den
+};
+// false: the reference's exponent would be NaN or infinite (no "_" in the string, not one or two integers, denominator 0)
+bool quantiser_parse_weighting(const std::string& text, QuantiserWeighting* out);
+// quantiser LUTs from a 65536-bin histogram (encoders/quantiser_utils.hpp:386-418, :227-306, weights :317-322):
 // lut_encode[65536] bytes, lut_decode[256] raw values.  IEEE binary32/64 in the reference's statement order.
-void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode);
+void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode,
+                          const QuantiserWeighting& weighting = QuantiserWeighting());
+// quantiser::lut_to_file / lut_from_file (encoders/quantiser_utils.hpp:490-515): one decimal value per line
+bool quantiser_lut_to_file(const std::string& path, const uint16_t* lut, size_t n);
+bool quantiser_lut_from_file(const std::string& path, uint16_t* lut, size_t n);
 
 // frame_shuffle ordering from the per-frame float sums (encoders/frame_shuffle_utils.hpp:126-166):
 // metric = sum / per_frame, sorted ascending, slot i <- first frame whose metric equals sorted[i]

@@ -170,6 +170,10 @@ def single_blob_possible(shape, dtype, world, chunk_bytes=LZ4_CHUNK_BYTES):
     if len(shape) != 3 or np.dtype(dtype) not in (np.dtype(np.uint16), np.dtype(np.uint8)):
         return False
     per_frame = shape[1] * shape[2]
+    # one blob = what ONE call on the whole volume yields, and one call is < 2^31 voxels (the reference counts them in an
+    # int, dynamic_pipeline.hpp:565; SQY_Decode refuses headers that claim more): larger volumes stay sharded containers
+    if shape[0] * per_frame >= 1 << 31:
+        return False
     for r in range(world):
         _, nz = slab_range(shape[0], r, world)
         if nz == 0 or (nz * per_frame) % (8 * chunk_bytes):

@@ -141,6 +141,6 @@ def test_corrupted_blobs_never_crash(sqy, oracle):
                 else:                                          # cut short
                     b = b[:int(rng.integers(h["size"] // 2, len(b)))]
                 rc, back = sqy.decode(bytes(b))
-                assert rc in (0, 1, 11, 101) or rc > 0
+                assert rc in (0, 1, 11, 101), (pipe, trial, rc)      # the documented set: ok, tail filter / header, sink (+10), head filter (+100)
             rc, back = sqy.decode(blob)
             assert rc == 0, pipe

@@ -151,6 +151,46 @@ def test_quantiser(sqy, oracle, pipeline):
         assert blob == want, (pipeline, vol.shape)
 
 
+@pytest.mark.parametrize("weighting", ["power_of_1_2", "power_of_2", "offset_power_of_1_2", "offset_power_of_3_1", "none"])
+def test_quantiser_weighting_functions(sqy, oracle, weighting):
+    """quantiser(weighting_function=...) (encoders/quantiser_weighters.hpp:20-160, selected at quantiser_scheme_impl.hpp:186-198):
+    blob bytes -- LUT in the header included -- against the oracle on the three volumes of test_quantiser, and back"""
+    rng = np.random.default_rng(3)
+    vols = [synth.stack((32, 128, 128), np.uint16),
+            rng.integers(0, 200, (8, 64, 64), dtype=np.uint16),
+            rng.integers(0, 65536, (16, 128, 128), dtype=np.uint16)]
+    pipeline = "quantiser(weighting_function=%s)->bitswap1->lz4" % weighting
+    assert sqy.pipeline_possible(pipeline, np.uint16)
+    for vol in vols:
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2)
+        assert rc == 0
+        want = oracle.pipeline_encode(pipeline, vol)
+        assert blob == want, (pipeline, vol.shape)
+        assert (",weighting_function=%s)" % weighting).encode() in blob[:oracle.header_unpack(blob)["size"]]
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, oracle.pipeline_decode(want))
+    # exponents the reference turns into NaN / infinity are refused
+    for bad in ("power", "power_of_1_0", "power_of_1_2_3"):
+        assert not sqy.pipeline_possible("quantiser(weighting_function=%s)->lz4" % bad, np.uint16)
+
+
+def test_quantiser_decode_lut_path(sqy, oracle, tmp_path):
+    """decode_lut_path (quantiser_scheme_impl.hpp:83-86,200-203): LUT to the named file instead of the header, decode reads it"""
+    vol = synth.stack((16, 64, 64), np.uint16)
+    lut = tmp_path / "a.lut"
+    pipeline = "quantiser(decode_lut_path=%s)->lz4" % lut
+    rc, blob = sqy.encode(pipeline, vol, nthreads=2)
+    assert rc == 0
+    mine = lut.read_text()
+    lut.unlink()
+    want = oracle.pipeline_encode(pipeline, vol)              # (the path is part of the header: same path for both)
+    assert mine == lut.read_text()
+    assert blob == want
+    assert b"decode_lut_string" not in blob[:oracle.header_unpack(blob)["size"]]
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, oracle.pipeline_decode(want))
+
+
 @pytest.mark.parametrize("pipeline", ["raster_reorder->lz4", "raster_reorder(tile_size=4)->bitswap1->lz4", "raster_reorder(tile_size=5)",
                                       "diff3x3x1->raster_reorder->lz4"])
 def test_raster_reorder(sqy, oracle, pipeline):

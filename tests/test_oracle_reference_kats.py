@@ -330,3 +330,121 @@ def test_bitshuffle_semantics(oracle):
         if not pipe.startswith("quantiser"):
             assert np.array_equal(oracle.pipeline_decode(blob), vol)
     assert oracle.header_unpack(oracle.pipeline_encode("bitshuffle->lz4", vol))["pipename"].startswith("bitshuffle(block_size=0)->lz4(")
+
+
+# the one header the reference itself shows byte for byte (docs/overview.md:25-45, `head -n19` of a .sqy file written by
+# sqeazy 0.5.2 @ fb193e3): Boost.PropertyTree's write_json layout -- key order, four spaces per level, every value a quoted
+# string, "dim" repeated once per extent.  (That build still wrote typeid(T).name() = "t" as the type; the tree under
+# /root/reference writes "uint16", header_utils.hpp:19-34.)
+DOCS_OVERVIEW_HEADER = """{
+    "pipename": "bitswap1(num_bits_per_plane=1)->lz4",
+    "raw": {
+        "type": "t",
+        "rank": "3",
+        "shape": {
+            "dim": "128",
+            "dim": "1024",
+            "dim": "256"
+        }
+    },
+    "encoded": {
+        "bytes": "263182"
+    },
+    "sqy": {
+        "version": "0.5.2",
+        "headref": "fb193e3"
+    }
+}
+"""
+
+
+def test_header_bytes_of_docs_overview(oracle):
+    """oracle.header_pack and the product's SQYAMD_Header_Build reproduce the header of docs/overview.md:25-45 byte for byte
+    (type name and the two build constants substituted), followed by the delimiter of sqeazy_header.hpp:586"""
+    import ctypes
+    import sqeazy_amd
+    pipename, shape, nbytes = "bitswap1(num_bits_per_plane=1)->lz4", (128, 1024, 256), 263182
+    want = DOCS_OVERVIEW_HEADER.replace('"type": "t"', '"type": "uint16"').encode("ascii") + b"|01307#!"
+    if len(want) % 2:                               # sqeazy_header.hpp:185-190: spaces in front up to a multiple of sizeof(T)
+        want = b" " + want
+    got = oracle.header_pack(np.uint16, shape, pipename, nbytes, version="0.5.2", headref="fb193e3")
+    assert got == want
+    assert got.count(b"\n") == 19                   # `head -n19` showed the whole JSON text
+    # the product writes the same bytes but for its own build constant
+    L = sqeazy_amd.lib()
+    shp = (ctypes.c_long * 3)(*shape)
+    n = ctypes.c_long(0)
+    # (the stage re-serialises its effective configuration: the lz4 defaults appear in the name, lz4.hpp:132-141)
+    full = b"bitswap1->lz4"
+    assert L.SQYAMD_Header_Build(full, 2, shp, 3, nbytes, None, ctypes.byref(n)) == 0
+    buf = ctypes.create_string_buffer(n.value)
+    assert L.SQYAMD_Header_Build(full, 2, shp, 3, nbytes, buf, ctypes.byref(n)) == 0
+    mine = buf.raw[:n.value]
+    lz4_name = "lz4(accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0)"
+    want_mine = want.replace(b'"headref": "fb193e3"', b'"headref": "mi355x"').replace(b"->lz4", ("->" + lz4_name).encode())
+    if len(want_mine) % 2:
+        want_mine = b" " + want_mine
+    assert mine == want_mine
+    assert mine == oracle.header_pack(np.uint16, shape, "bitswap1(num_bits_per_plane=1)->" + lz4_name, nbytes)
+
+
+def test_quantiser_weighters_reference_kats(oracle):
+    """tests/test_quantiser_impl.cpp:1436-1600 (extract_weighters suite) and :1166-1285 (weighters_on_16bit) restated:
+    extract_ratio on "none" / "power_of_2" / "power_of_1_2"; power_of(3,1) weights on the capped ramp are i^3; offset_power_of
+    equals power_of when bin 0 is populated (offset_versus_no_offset) and differs when the histogram starts with a gap."""
+    with pytest.raises(ValueError):
+        oracle.quantiser_weighting("power")                      # no "_": extract_ratio gives (0, 0), exponent NaN
+    assert oracle.quantiser_weighting("none") == (0, 1, 1)       # (the scheme never calls extract_ratio for "none")
+    assert oracle.quantiser_weighting("power_of_2") == (1, 2, 1)
+    assert oracle.quantiser_weighting("power_of_1_2") == (1, 1, 2)
+    assert oracle.quantiser_weighting("offset_power_of_3_1") == (2, 3, 1)
+    # power_capped_ramp_compare_weights: values (i % 63) over 4096 voxels, power_of(3, 1)
+    ramp = (np.arange(1 << 12) % 63).astype(np.uint16)
+    h = oracle.histogram(ramp)
+    w = oracle.quantiser_weights(h, "power_of_3_1")
+    for i in range(1, 63):
+        assert abs(float(w[i]) - i ** 3) <= 0.01 * i ** 3
+    assert np.array_equal(w[:63], (np.arange(63, dtype=np.float64) ** 3).astype(np.float32))
+    # offset_power_capped_ramp_compare_weights: its input wraps to 0 at value 63, so bin 0 is populated and the offset is 0
+    v = np.arange(1 << 12)
+    inp = np.where(v > 10, v % 63, 10).astype(np.uint16)
+    h2 = oracle.histogram(inp)
+    assert h2[0] > 0
+    assert np.array_equal(oracle.quantiser_weights(h2, "offset_power_of_3_1"), oracle.quantiser_weights(h2, "power_of_3_1"))
+    # offset_vs_no_offset_on_gaps: the first populated bin is not bin 0 -> the offset form starts its power law there
+    gap = (100 + np.arange(1 << 12) % 63).astype(np.uint16)
+    hg = oracle.histogram(gap)
+    wo, wn = oracle.quantiser_weights(hg, "offset_power_of_2"), oracle.quantiser_weights(hg, "power_of_2")
+    assert not np.array_equal(wo, wn)
+    assert (wo[:100] == 1.0).all() and wo[100] == 0.0 and wo[103] == 9.0 and wn[103] == 103.0 ** 2
+    # the weighted LUT differs from the unweighted one and still round-trips through the pipeline (lossy, monotone tables)
+    rng = np.random.default_rng(3)
+    vol = (rng.gamma(2.0, 300.0, (8, 32, 32)).astype(np.uint16) + 50).astype(np.uint16)
+    e0, d0 = oracle.quantiser_build_luts(oracle.histogram(vol))
+    e1, d1 = oracle.quantiser_build_luts(oracle.histogram(vol), "power_of_1_2")
+    e2, d2 = oracle.quantiser_build_luts(oracle.histogram(vol), "offset_power_of_2_1")
+    assert not np.array_equal(d0, d1) and not np.array_equal(d1, d2)
+    for d in (d0, d1, d2):                                       # (entries behind the last used level stay 0)
+        assert (np.diff(d[:int(np.argmax(d)) + 1].astype(np.int64)) >= 0).all()
+    blob = oracle.pipeline_encode("quantiser(weighting_function=power_of_1_2)->bitswap1->lz4", vol)
+    name = oracle.header_unpack(blob)["pipename"]
+    # config() walks a std::map: keys in order (quantiser_scheme_impl.hpp:104-120)
+    assert name.startswith("quantiser(decode_lut_string=<verbatim>") and ",weighting_function=power_of_1_2)->bitswap1(" in name
+    back = oracle.pipeline_decode(blob)
+    assert back.shape == vol.shape and np.array_equal(back, d1[e1[vol]])
+
+
+def test_quantiser_decode_lut_path(oracle, tmp_path):
+    """quantiser_scheme_impl.hpp:200-204 / :83-85: with decode_lut_path the LUT goes to that file (one value per line,
+    quantiser_utils.hpp:490-498) INSTEAD of the header, and decode reads it back from there"""
+    rng = np.random.default_rng(4)
+    vol = rng.integers(0, 3000, (4, 16, 32), dtype=np.uint16)
+    lut = tmp_path / "test.lut"
+    blob = oracle.pipeline_encode("quantiser(decode_lut_path=%s)->lz4" % lut, vol)
+    name = oracle.header_unpack(blob)["pipename"]
+    assert "decode_lut_string" not in name and ("decode_lut_path=%s" % lut) in name
+    lines = lut.read_text().split("\n")
+    assert len(lines) == 257 and lines[-1] == ""
+    enc, dec = oracle.quantiser_build_luts(oracle.histogram(vol))
+    assert [int(t) for t in lines[:-1]] == [int(x) for x in dec]
+    assert np.array_equal(oracle.pipeline_decode(blob), dec[enc[vol]])
