@@ -160,20 +160,20 @@ def secondary_configs(dev):
         v = vol if vol is not None else synth.stack_torch(shape, dtype, dev)
         cap = sqeazy_amd.max_compressed_length(pipeline, shape, dtype) + extra
         buf = torch.empty(cap, dtype=torch.uint8, device=dev)
-        rc, m = sqeazy_amd.encode_device(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+        rc, off, m = sqeazy_amd.encode_device_at(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
         if rc:
             raise RuntimeError("%s returned %d" % (pipeline, rc))
         best, prof = None, {}
         for _ in range(reps):
             sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            rc, m = sqeazy_amd.encode_device(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+            rc, off, m = sqeazy_amd.encode_device_at(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             sqeazy_amd.profile_enable(False)
             if best is None or dt < best:
                 best, prof = dt, sqeazy_amd.profile_get()
         nvox = int(np.prod(shape))
-        hdr = sqeazy_amd.header_size(bytes(buf[:65536].cpu().numpy().tobytes()))
+        hdr = sqeazy_amd.header_size(bytes(buf[off:off + 65536].cpu().numpy().tobytes()))
         algo = algo_per_voxel * nvox + (m - hdr)
         res = {"ms_per_call": round(best * 1e3, 3), "input_GBps": round(nvox * np.dtype(dtype).itemsize / best / 1e9, 1),
                "algorithmic_bytes": int(algo), "roofline_frac": round(algo / best / 1e9 / HBM_PEAK_GBS, 5), "blob_bytes": int(m),
@@ -213,8 +213,8 @@ def secondary_configs(dev):
             def worker(t):
                 torch.cuda.set_device(dev)
                 for i in range(t, nslabs, K):
-                    rc, m = sqeazy_amd.encode_device(pipeline, vols[i].data_ptr(), (256, 2048, 2048), np.uint16, bufs[t].data_ptr(), cap,
-                                                     stream=strs[t].cuda_stream)
+                    rc, _off, m = sqeazy_amd.encode_device_at(pipeline, vols[i].data_ptr(), (256, 2048, 2048), np.uint16, bufs[t].data_ptr(), cap,
+                                                              stream=strs[t].cuda_stream)
                     sizes[i] = m
                     if rc:
                         errs.append(rc)
@@ -315,6 +315,8 @@ def main():
     gatherer = multi.SlabGatherer(world * cap, dev) if (dist_on and not args.no_gather) else None
     torch.cuda.synchronize()
 
+    last_at = [(0, 0, 0)]            # (thread, buffer, offset) of the blob of the last step taken
+
     def run_steps(k, gather=False):
         """k steps: thread t encodes steps t, t+inflight, ...; the main thread takes them in step order and either exchanges the
         sizes (sharded container) or hands the blob to the gatherer (overlapped gather to rank 0), then recycles the buffer"""
@@ -333,29 +335,31 @@ def main():
                     b = free_q[t].get()
                     if b is None or stop.is_set():
                         return
-                    rc, n = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[t][b].data_ptr(), cap, nthreads=0,
-                                                     stream=streams[t].cuda_stream)
+                    rc, off, n = sqeazy_amd.encode_device_at(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[t][b].data_ptr(), cap, nthreads=0,
+                                                             stream=streams[t].cuda_stream)
                     if rc:
-                        raise RuntimeError("SQYAMD_PipelineEncode_UI16_Device returned %d" % rc)
-                    done_q.put((s_, t, b, n))
+                        raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
+                    done_q.put((s_, t, b, n, off))
             except Exception as e:   # pragma: no cover
                 errors.append(e)
-                done_q.put((-1, t, 0, 0))
+                done_q.put((-1, t, 0, 0, 0))
 
         threads = [threading.Thread(target=worker, args=(t,)) for t in range(min(inflight, max(k, 1)))]
         for th in threads:
             th.start()
         pending, nxt, last_n = {}, 0, 0
         while nxt < k:
-            s_, t, b, n = done_q.get()
+            s_, t, b, n, off = done_q.get()
             if s_ < 0:
                 break
-            pending[s_] = (t, b, n)
+            pending[s_] = (t, b, n, off)
             while nxt in pending:
-                t2, b2, n2 = pending.pop(nxt)
+                t2, b2, n2, off2 = pending.pop(nxt)
+                last_at[0] = (t2, b2, off2)
                 if dist_on and gather:
                     # posted, not waited for: the buffer goes back to its caller thread when the gather of this step is done
-                    gatherer.post(outs[t2][b2], n2, on_done=lambda q=free_q[t2], bb=b2: q.put(bb))
+                    # (the blob sits at off2 inside its buffer: frames in place)
+                    gatherer.post(outs[t2][b2][off2:], n2, on_done=lambda q=free_q[t2], bb=b2: q.put(bb))
                 else:
                     if dist_on:
                         multi.exchange_sizes(n2, dev, out=index_rows[nxt % len(index_rows)], sync=False)   # enqueued; the closing fence waits for it
@@ -418,8 +422,8 @@ def main():
     single = []
     for _ in range(5):
         tl = time.perf_counter()
-        rc, _n = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[0][0].data_ptr(), cap, nthreads=0,
-                                          stream=streams[0].cuda_stream)
+        rc, single_off, _n = sqeazy_amd.encode_device_at(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[0][0].data_ptr(), cap, nthreads=0,
+                                                         stream=streams[0].cuda_stream)
         torch.cuda.synchronize()
         single.append((time.perf_counter() - tl) * 1e3)
     sqeazy_amd.profile_enable(False)
@@ -428,7 +432,7 @@ def main():
 
     if rank == 0:
         dt = statistics.median(times)
-        hdr = sqeazy_amd.header_size(bytes(outs[0][0][:4096].cpu().numpy().tobytes()))
+        hdr = sqeazy_amd.header_size(bytes(outs[0][0][single_off:single_off + 4096].cpu().numpy().tobytes()))
         payload_bytes = payload - hdr
         # dominant kernel by device time; per-launch average over every launch of the timed blocks
         dom, (dom_ms, dom_n) = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
@@ -462,6 +466,12 @@ def main():
                          "alone_launch_ms": round(alone_ms, 4) if alone_ms else None,
                          "alone_frac": round((algo_bytes / 1e9) / (alone_ms / 1e3) / HBM_PEAK_GBS, 5) if alone_ms else None,
                          "kernels_ms_per_step": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof.items()}},
+            # one call at a time (what the sqy tool, the HDF5 filter and the Java binding do): latency of the call, its rate, and
+            # the whole call's algorithmic bytes against the roofline
+            "single_call": {"ms": round(single_ms, 4), "value": round(nbytes / (single_ms / 1e3) / 1e9, 1), "unit": "GB/s",
+                            "roofline_frac": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof_alone.items()}},
+            "entry_point": "SQYAMD_PipelineEncode_UI16_DeviceAt (device pointers; the blob may start anywhere in the destination: frames in place)",
             "build": ident,
         }
         tr = measured_traffic(ident["sha256"], dom)

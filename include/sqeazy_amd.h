@@ -101,6 +101,31 @@ SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, 
 SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, const long* shape,
                                                          unsigned shape_size, void* d_dst, long dst_capacity,
                                                          long* dstlength, int nthreads, void* hip_stream);
+/* The same, but the blob may start anywhere inside [d_dst, d_dst + dst_capacity): *dstoffset says where, *dstlength how long it is
+ * (bytes identical to the entry points above).  This is the fast path: for `...->bitswap1->lz4` on 16-bit voxels the bit-plane
+ * transpose writes the plane stream straight into d_dst as the bodies of the LZ4 frames it will become (one frame per 256 KiB
+ * chunk, encoders/lz4_utils.hpp:193-274); the stored frames that end the payload -- the noise planes, 98 % of the payload of a
+ * microscopy stack -- then never move, only the compressed frames in front of them are gathered (no second pass over the
+ * payload).  dst_capacity as above; every other pipeline returns *dstoffset = 0. */
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_DeviceAt(const char* pipeline, const void* d_src, const long* shape,
+                                                            unsigned shape_size, void* d_dst, long dst_capacity, long* dstoffset,
+                                                            long* dstlength, int nthreads, void* hip_stream);
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_DeviceAt(const char* pipeline, const void* d_src, const long* shape,
+                                                           unsigned shape_size, void* d_dst, long dst_capacity, long* dstoffset,
+                                                           long* dstlength, int nthreads, void* hip_stream);
+/* A whole volume as `nslabs` independent z-slab blobs with ONE call (the reference encodes one volume of < 2^31 voxels per call,
+ * src/sqeazy.cpp:108-142; larger volumes are cut into z-slabs by its callers).  shape is the WHOLE volume {z,y,x}; slab i holds
+ * frames [i*(Z/n) + min(i, Z%n), ...) -- the first Z % nslabs slabs get one frame more -- and is encoded exactly as
+ * SQYAMD_PipelineEncode_*_DeviceAt would encode it (every blob is a complete sqeazy blob, bytes identical to the single calls).
+ * Blob i lies inside d_dst[i*slab_capacity, (i+1)*slab_capacity) (slab_capacity >= SQY_Pipeline_Max_Compressed_Length_3D_* of the
+ * largest slab): offsets[i] = its start relative to d_dst, lengths[i] = its bytes.  `inflight` slab calls (<= 0: three) run at a
+ * time on library-owned streams: the transposes, LZ4 parses and gathers of different slabs overlap.  Returns when all are done. */
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_Slabs_UI16_Device(const char* pipeline, const void* d_src, const long* shape,
+                                                                unsigned shape_size, int nslabs, void* d_dst, long slab_capacity,
+                                                                long* offsets, long* lengths, int nthreads, int inflight);
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_Slabs_UI8_Device(const char* pipeline, const void* d_src, const long* shape,
+                                                               unsigned shape_size, int nslabs, void* d_dst, long slab_capacity,
+                                                               long* offsets, long* lengths, int nthreads, int inflight);
 /* host-pointer encode with an explicit destination capacity (returns 1 instead of overflowing dst; the
  * reference-protocol entry points above assume dst holds exactly SQY_Pipeline_Max_Compressed_Length_* bytes) */
 SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_Cap(const char* pipeline, const char* src, long* shape, unsigned shape_size,

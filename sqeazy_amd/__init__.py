@@ -24,6 +24,8 @@ EXPORTED_SYMBOLS = (
     "SQY_Pipeline_Possible_UI16", "SQY_Pipeline_Possible_UI8", "SQY_Pipeline_Possible",
     "SQY_Decompressed_Length", "SQY_Decode_UI16", "SQY_Decode_UI8",
     "SQYAMD_PipelineEncode_UI16_Device", "SQYAMD_PipelineEncode_UI8_Device",
+    "SQYAMD_PipelineEncode_UI16_DeviceAt", "SQYAMD_PipelineEncode_UI8_DeviceAt",
+    "SQYAMD_PipelineEncode_Slabs_UI16_Device", "SQYAMD_PipelineEncode_Slabs_UI8_Device",
     "SQYAMD_PipelineEncode_UI16_Cap", "SQYAMD_PipelineEncode_UI8_Cap",
     "SQYAMD_Decode_UI16_Device", "SQYAMD_Decode_UI8_Device",
     "SQYAMD_Profile_Enable", "SQYAMD_Profile_Reset", "SQYAMD_Profile_Get",
@@ -63,6 +65,12 @@ def lib():
         for f in ("SQYAMD_PipelineEncode_UI8_Device", "SQYAMD_PipelineEncode_UI16_Device"):
             getattr(L, f).argtypes = [ctypes.c_char_p, ctypes.c_void_p, c_long_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_long,
                                       c_long_p, ctypes.c_int, ctypes.c_void_p]
+        for f in ("SQYAMD_PipelineEncode_UI8_DeviceAt", "SQYAMD_PipelineEncode_UI16_DeviceAt"):
+            getattr(L, f).argtypes = [ctypes.c_char_p, ctypes.c_void_p, c_long_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_long,
+                                      c_long_p, c_long_p, ctypes.c_int, ctypes.c_void_p]
+        for f in ("SQYAMD_PipelineEncode_Slabs_UI8_Device", "SQYAMD_PipelineEncode_Slabs_UI16_Device"):
+            getattr(L, f).argtypes = [ctypes.c_char_p, ctypes.c_void_p, c_long_p, ctypes.c_uint, ctypes.c_int, ctypes.c_void_p, ctypes.c_long,
+                                      c_long_p, c_long_p, ctypes.c_int, ctypes.c_int]
         for f in ("SQYAMD_PipelineEncode_UI8_Cap", "SQYAMD_PipelineEncode_UI16_Cap"):
             getattr(L, f).argtypes = [ctypes.c_char_p, ctypes.c_void_p, c_long_p, ctypes.c_uint, ctypes.c_void_p, ctypes.c_long, c_long_p,
                                       ctypes.c_int]
@@ -152,6 +160,26 @@ def encode_device(pipeline, d_src, shape, dtype, d_dst, dst_capacity, nthreads=0
         pipeline.encode(), ctypes.c_void_p(int(d_src)), _longs(shape), ctypes.c_uint(len(shape)), ctypes.c_void_p(int(d_dst)),
         ctypes.c_long(int(dst_capacity)), ctypes.byref(dlen), ctypes.c_int(nthreads), ctypes.c_void_p(stream or 0))
     return rc, dlen.value
+
+
+def encode_device_at(pipeline, d_src, shape, dtype, d_dst, dst_capacity, nthreads=0, stream=None):
+    """SQYAMD_PipelineEncode_*_DeviceAt: the blob may start anywhere inside the destination; returns (rc, offset, bytes)."""
+    sfx = _suffix(dtype)
+    dlen, doff = ctypes.c_long(0), ctypes.c_long(0)
+    rc = getattr(lib(), "SQYAMD_PipelineEncode_%s_DeviceAt" % sfx)(
+        pipeline.encode(), ctypes.c_void_p(int(d_src)), _longs(shape), ctypes.c_uint(len(shape)), ctypes.c_void_p(int(d_dst)),
+        ctypes.c_long(int(dst_capacity)), ctypes.byref(doff), ctypes.byref(dlen), ctypes.c_int(nthreads), ctypes.c_void_p(stream or 0))
+    return rc, doff.value, dlen.value
+
+
+def encode_slabs_device(pipeline, d_src, shape, dtype, nslabs, d_dst, slab_capacity, nthreads=0, inflight=3):
+    """SQYAMD_PipelineEncode_Slabs_*_Device: a whole volume as nslabs z-slab blobs with one call; returns (rc, offsets, lengths)."""
+    offs = (ctypes.c_long * nslabs)()
+    lens = (ctypes.c_long * nslabs)()
+    rc = getattr(lib(), "SQYAMD_PipelineEncode_Slabs_%s_Device" % _suffix(dtype))(
+        pipeline.encode(), ctypes.c_void_p(int(d_src)), _longs(shape), ctypes.c_uint(len(shape)), ctypes.c_int(nslabs),
+        ctypes.c_void_p(int(d_dst)), ctypes.c_long(int(slab_capacity)), offs, lens, ctypes.c_int(nthreads), ctypes.c_int(inflight))
+    return rc, list(offs), list(lens)
 
 
 def header_size(blob):

@@ -274,10 +274,15 @@ bool device_present()
 
 // ---- encode --------------------------------------------------------------------------------------
 // The body of dynamic_pipeline::encode (dynamic_pipeline.hpp:560-616) on device buffers.
+// dstoffset == nullptr: the blob starts at d_dst.  Otherwise it may start anywhere inside [d_dst, d_dst + dst_capacity) and
+// *dstoffset says where ("frames in place": a 16-bit bitswap1 in front of lz4 writes the plane stream straight into d_dst as
+// the bodies of the LZ4 frames it will become; the stored frames that end the payload -- the noise planes, 98 % of the bytes of
+// a microscopy stack -- then never move, only the compressed frames in front are gathered up against them).
 int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, const long* shape, unsigned rank, int elem_size,
-                     void* d_dst, uint64_t dst_capacity, long* dstlength, int nthreads, hipStream_t stream)
+                     void* d_dst, uint64_t dst_capacity, long* dstlength, int nthreads, hipStream_t stream, long* dstoffset = nullptr)
 {
     if (!pipeline_c || !d_src || !shape || !d_dst || !dstlength) return 1;
+    if (dstoffset) *dstoffset = 0;
     const std::string pipeline(pipeline_c);
     std::string why;
     if (!Pipeline::supported(pipeline, elem_size, &why)) {
@@ -331,18 +336,21 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     const uint32_t* lz4_piece_hash = nullptr;    // left by a 16-bit bitswap1 directly in front of lz4: hashes of the 1 KiB pieces of the plane stream
     const uint32_t* lz4_dup_of = nullptr;        // chunks that are byte-identical to an earlier chunk share its frame
     const sqy::Lz4Block* lz4_blocks = nullptr;   // block-linked frames (nthreads == 1, or chunks of several LZ4 blocks): the block list in HBM
+    // frames in place: chunk k of the plane stream sits at d_dst + inplace_t0 + 11 + k * lz4_in_stride
+    bool lz4_inplace = false;
+    uint64_t lz4_in_stride = 0, inplace_t0 = 0;
+    uint64_t* lz4_tail_info = nullptr;
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
     for (size_t si = 0; si < pipe.stages.size(); ++si) {
         Stage& st = pipe.stages[si];
         switch (st.kind) {
             case StageKind::bitswap1: {
-                uint8_t* out = next_buf(cur_len * cur_elem);
-                if (!out) return 1;
                 // lz4 right behind: leave piece hashes for its duplicate-chunk detection (bit planes of small values repeat)
                 uint32_t* ph = nullptr;
+                uint64_t gap_chunk = 0;
                 if (cur_elem == 2 && si + 1 < pipe.stages.size() && pipe.stages[si + 1].kind == StageKind::lz4) {
-                    const uint64_t words = sqy::bitswap1_piece_hash_words(cur, out, cur_len);
+                    const uint64_t words = sqy::bitswap1_piece_hash_words(cur, cur, cur_len);         // (0 unless whole tiles, 16-byte aligned input)
                     const uint64_t total = cur_len * 2;
                     const uint64_t chunk = pipe.stages[si + 1].lz4.bytes_per_chunk(total);
                     const bool chunked = chunk <= pipe.stages[si + 1].lz4.block_bytes() && !(pipe.nthreads == 1 && total > chunk);
@@ -352,11 +360,29 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         if (ws->dedupe.ensure(ph_bytes + sqy::lz4_dedupe_work_bytes(nch) + nch * 4)) return 1;
                         ph = static_cast<uint32_t*>(ws->dedupe.p);
                         lz4_piece_hash = ph;
+                        // frames in place: lz4 is the last stage, chunks a power of two, the caller takes the blob where it ends up,
+                        // and the destination holds frame headers in front of and end marks behind every chunk
+                        if (dstoffset && si + 2 == pipe.stages.size() && (chunk & (chunk - 1)) == 0) {
+                            // room in front for the sqy header (its length depends on the payload size: take the longest)
+                            const uint64_t hdr_max = sqy::header_pack(elem_size, false, dims, pipe.name(), (uint64_t)INT_MAX).size() + 2;
+                            uint64_t t0 = hdr_max;
+                            while ((reinterpret_cast<uintptr_t>(d_dst) + t0 + 11) & 15) ++t0;          // body of chunk 0 on a 16-byte boundary
+                            if (t0 + nch * (chunk + 15) <= dst_capacity) {
+                                gap_chunk = chunk;
+                                inplace_t0 = t0;
+                                lz4_in_stride = chunk + 15;
+                                lz4_inplace = true;
+                            }
+                        }
                     }
                 }
+                uint8_t* out = gap_chunk ? static_cast<uint8_t*>(d_dst) + inplace_t0 + 11 : next_buf(cur_len * cur_elem);
+                if (!out) return 1;
+                if (!gap_chunk && ph && (reinterpret_cast<uintptr_t>(out) & 15)) { ph = nullptr; lz4_piece_hash = nullptr; }
                 ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
                 if (cur_elem == 2)
-                    SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream, ph));
+                    SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream, ph,
+                                                     (uint32_t)gap_chunk));
                 else
                     SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
                 cur = out;
@@ -591,14 +617,15 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     lz4_stride = (lz4_chunk + 15) & ~(uint64_t)15;
                     if (ws->lz4_scratch.ensure(std::max<uint64_t>(lz4_nchunks * lz4_stride, 16))) return 1;
                     if (ws->csize.ensure(std::max<uint64_t>(lz4_nchunks, 1) * sizeof(uint32_t))) return 1;
-                    if (ws->frame_off.ensure((lz4_nchunks + 1) * sizeof(uint64_t))) return 1;
+                    if (ws->frame_off.ensure((lz4_nchunks + 1 + 4) * sizeof(uint64_t))) return 1;
+                    if (lz4_inplace) lz4_tail_info = static_cast<uint64_t*>(ws->frame_off.p) + lz4_nchunks + 1;
                     if (lz4_piece_hash && si > 0 && pipe.stages[si - 1].kind == StageKind::bitswap1) {
                         const uint64_t words = sqy::bitswap1_piece_hash_words(cur, cur, cur_len);     // (same count as when they were made)
                         const uint64_t ph_bytes = (words * 4 + 63) & ~(uint64_t)63;
                         uint8_t* base = static_cast<uint8_t*>(ws->dedupe.p) + ph_bytes;
                         uint32_t* d_dup = reinterpret_cast<uint32_t*>(base + sqy::lz4_dedupe_work_bytes(lz4_nchunks));
                         ProfScope ps("lz4_dedupe", stream, pend);
-                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream));
+                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride));
                         lz4_dup_of = d_dup;
                     }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
@@ -606,7 +633,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     {
                         ProfScope ps("lz4_chunks", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo, lz4_dup_of));
+                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo, lz4_dup_of,
+                                                       lz4_in_stride));
                     }
                     SQY_HIP(hipMemcpyAsync(ws->pinned, d_redo, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     SQY_HIP(hipStreamSynchronize(stream));
@@ -614,7 +642,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     if (n_redo) {
                         ProfScope ps("lz4_chunks_dense", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks_dense(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                             static_cast<uint32_t*>(ws->csize.p), d_redo, n_redo, stream, lz4_frame_map, lz4_frame_bytes));
+                                                             static_cast<uint32_t*>(ws->csize.p), d_redo, n_redo, stream, lz4_frame_map, lz4_frame_bytes,
+                                                             lz4_in_stride));
                     }
                 } else if (lz4_total) {
                     // block-linked frames: the serial layout (nthreads == 1) or chunks that span several LZ4 blocks.  The table
@@ -648,7 +677,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 {
                     ProfScope ps("lz4_frame_scan", stream, pend);
                     SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
-                                                       static_cast<uint64_t*>(ws->frame_off.p), stream, lz4_blocks, lz4_dup_of));
+                                                       static_cast<uint64_t*>(ws->frame_off.p), stream, lz4_blocks, lz4_dup_of, lz4_tail_info));
                 }
                 payload_is_lz4 = true;
                 break;
@@ -660,9 +689,15 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     }
 
     // ---- payload size ----
+    uint64_t tail_j = 0, tail_head_bytes = 0, tail_raw_head = 0;
     if (payload_is_lz4) {
         if (lz4_nchunks == 0) {
             payload_bytes = 7 + 4;                     // empty input: frame header + end mark
+        } else if (lz4_inplace) {
+            SQY_HIP(hipMemcpyAsync(ws->pinned, lz4_tail_info, 4 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+            SQY_HIP(hipStreamSynchronize(stream));
+            const uint64_t* ti = static_cast<const uint64_t*>(ws->pinned);
+            tail_j = ti[0]; tail_head_bytes = ti[1]; tail_raw_head = ti[2]; payload_bytes = ti[3];
         } else {
             SQY_HIP(hipMemcpyAsync(ws->pinned, static_cast<uint64_t*>(ws->frame_off.p) + lz4_nchunks, sizeof(uint64_t),
                                    hipMemcpyDeviceToHost, stream));
@@ -688,6 +723,37 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
         return 1;
     }
     uint8_t* out = static_cast<uint8_t*>(d_dst);
+    if (lz4_inplace) {
+        // the run of stored chunks j.. that ends the payload stays where the bit-plane transpose put it; frames 0..j-1 are
+        // gathered so that they end where frame j begins, the header goes in front of them
+        const uint64_t frame_j = inplace_t0 + tail_j * lz4_in_stride;
+        if (tail_head_bytes + hdr.size() > frame_j) { std::fprintf(stderr, "[sqeazy]\t internal error: frames in place overlap the header\n"); return 1; }
+        const uint64_t payload_at = frame_j - tail_head_bytes, blob_at = payload_at - hdr.size();
+        const unsigned char fd[2] = {0x40, (unsigned char)(lz4p->block_id << 4)};
+        const uint32_t hc = (sqy::xxh32(fd, 2, 0) >> 8) & 0xff;
+        uint8_t* body0 = out + inplace_t0 + 11;
+        {
+            ProfScope ps("lz4_tail_marks", stream, pend);
+            SQY_HIP(sqy::launch_lz4_tail_marks(body0, lz4_in_stride, lz4_total, (uint32_t)lz4_chunk, lz4_nchunks, fd[1], hc, lz4_tail_info, stream));
+        }
+        if (tail_raw_head) {
+            ProfScope ps("lz4_stash_raw", stream, pend);
+            SQY_HIP(sqy::launch_lz4_stash_raw(body0, lz4_in_stride, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
+                                              static_cast<uint32_t*>(ws->csize.p), lz4_dup_of, tail_j, stream));
+        }
+        if (tail_j) {
+            ProfScope ps("lz4_frame_gather", stream, pend);
+            SQY_HIP(sqy::launch_lz4_frame_gather(body0, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
+                                                 static_cast<uint32_t*>(ws->csize.p), static_cast<uint64_t*>(ws->frame_off.p), out + payload_at, fd[1], hc,
+                                                 tail_j, stream, nullptr, 0, nullptr, lz4_dup_of, lz4_in_stride, tail_raw_head != 0));
+        }
+        SQY_HIP(hipMemcpyAsync(out + blob_at, hdr.data(), hdr.size(), hipMemcpyHostToDevice, stream));
+        SQY_HIP(hipStreamSynchronize(stream));
+        if (g_prof_on.load()) prof_collect(cx.pending);
+        *dstoffset = (long)blob_at;
+        *dstlength = (long)blob_bytes;
+        return 0;
+    }
     SQY_HIP(hipMemcpyAsync(out, hdr.data(), hdr.size(), hipMemcpyHostToDevice, stream));
     if (payload_is_lz4) {
         const unsigned char fd[2] = {0x40, (unsigned char)(lz4p->block_id << 4)};
@@ -752,10 +818,10 @@ int encode_from_host(const char* pipeline, const char* src, long* shape, unsigne
     int dev_id = 0;
     SQY_HIP(hipGetDevice(&dev_id));
     if (!lease.ctx->stager.copy(ws->io_src.p, const_cast<char*>(src), raw, true, dev_id)) { std::fprintf(stderr, "[sqeazy]\t host to device transfer failed\n"); return 1; }
-    long out_len = 0;
-    const int rc = encode_on_device(*lease.ctx, pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, stream);
+    long out_len = 0, out_at = 0;
+    const int rc = encode_on_device(*lease.ctx, pipeline, ws->io_src.p, shape, rank, elem_size, ws->io_dst.p, bound, &out_len, nthreads, stream, &out_at);
     if (rc) return rc;                  // (returns with the blob complete: the stream has been synchronised)
-    if (!lease.ctx->stager.copy(ws->io_dst.p, dst, (size_t)out_len, false, dev_id)) { std::fprintf(stderr, "[sqeazy]\t device to host transfer failed\n"); return 1; }
+    if (!lease.ctx->stager.copy(static_cast<char*>(ws->io_dst.p) + out_at, dst, (size_t)out_len, false, dev_id)) { std::fprintf(stderr, "[sqeazy]\t device to host transfer failed\n"); return 1; }
     *dstlength = out_len;
     return 0;
 }
@@ -1326,6 +1392,94 @@ int SQYAMD_PipelineEncode_UI8_Device(const char* pipeline, const void* d_src, co
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream));
+    });
+}
+
+int SQYAMD_PipelineEncode_UI16_DeviceAt(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
+                                        long dst_capacity, long* dstoffset, long* dstlength, int nthreads, void* hip_stream)
+{
+    return guarded([&]() -> int {
+    if (!dstoffset) return 1;
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+                            static_cast<hipStream_t>(hip_stream), dstoffset);
+    });
+}
+
+int SQYAMD_PipelineEncode_UI8_DeviceAt(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
+                                       long dst_capacity, long* dstoffset, long* dstlength, int nthreads, void* hip_stream)
+{
+    return guarded([&]() -> int {
+    if (!dstoffset) return 1;
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+                            static_cast<hipStream_t>(hip_stream), dstoffset);
+    });
+}
+
+// A volume as `nslabs` independent z-slab blobs, `inflight` slab calls at a time on library-owned streams (one host thread, context
+// and stream per call in flight -- what three caller threads would do, available to a plain C caller with one call).
+static int encode_slabs(const char* pipeline, const void* d_src, const long* shape, unsigned rank, int elem_size, int nslabs, void* d_dst,
+                        long slab_capacity, long* offsets, long* lengths, int nthreads, int inflight)
+{
+    if (!pipeline || !d_src || !shape || !d_dst || !offsets || !lengths || rank == 0 || nslabs <= 0 || slab_capacity <= 0) return 1;
+    for (unsigned i = 0; i < rank; ++i) if (shape[i] <= 0) return 1;
+    if ((long)nslabs > shape[0]) { std::fprintf(stderr, "[sqeazy]\t more slabs (%d) than frames (%ld)\n", nslabs, shape[0]); return 1; }
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    uint64_t per_frame = (uint64_t)elem_size;
+    for (unsigned i = 1; i < rank; ++i) per_frame *= (uint64_t)shape[i];
+    const long base = shape[0] / nslabs, rem = shape[0] % nslabs;           // the first Z % nslabs slabs get one frame more
+    if (inflight <= 0) inflight = 3;
+    if (inflight > nslabs) inflight = nslabs;
+    if (inflight > (int)kMaxCtxPerDev) inflight = (int)kMaxCtxPerDev;
+    std::atomic<int> first_error(0);
+    auto worker = [&](int t) {
+        if (hipSetDevice(dev) != hipSuccess) { int z = 0; first_error.compare_exchange_strong(z, 1); return; }
+        for (int i = t; i < nslabs && first_error.load() == 0; i += inflight) {
+            const long z0 = (long)i * base + std::min<long>(i, rem), nz = base + (i < rem ? 1 : 0);
+            std::vector<long> shp(shape, shape + rank);
+            shp[0] = nz;
+            long at = 0, len = 0;
+            int rc;
+            {
+                ContextLease lease;
+                if (!lease.ctx) rc = 1;
+                else {
+                    hipStream_t stream = lease.ctx->own_stream();
+                    rc = stream ? encode_on_device(*lease.ctx, pipeline, static_cast<const char*>(d_src) + (uint64_t)z0 * per_frame, shp.data(), rank,
+                                                   elem_size, static_cast<char*>(d_dst) + (uint64_t)i * (uint64_t)slab_capacity,
+                                                   (uint64_t)slab_capacity, &len, nthreads, stream, &at)
+                                : 1;
+                }
+            }
+            if (rc) { int z = 0; first_error.compare_exchange_strong(z, rc); return; }
+            offsets[i] = (long)((uint64_t)i * (uint64_t)slab_capacity) + at;
+            lengths[i] = len;
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < inflight; ++t) th.emplace_back([&, t]() { guarded([&]() -> int { worker(t); return 0; }); });
+    worker(0);
+    for (auto& x : th) x.join();
+    return first_error.load();
+}
+
+int SQYAMD_PipelineEncode_Slabs_UI16_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, int nslabs,
+                                            void* d_dst, long slab_capacity, long* offsets, long* lengths, int nthreads, int inflight)
+{
+    return guarded([&]() -> int {
+    return encode_slabs(pipeline, d_src, shape, shape_size, 2, nslabs, d_dst, slab_capacity, offsets, lengths, nthreads, inflight);
+    });
+}
+
+int SQYAMD_PipelineEncode_Slabs_UI8_Device(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, int nslabs,
+                                           void* d_dst, long slab_capacity, long* offsets, long* lengths, int nthreads, int inflight)
+{
+    return guarded([&]() -> int {
+    return encode_slabs(pipeline, d_src, shape, shape_size, 1, nslabs, d_dst, slab_capacity, offsets, lengths, nthreads, inflight);
     });
 }
 

@@ -10,13 +10,18 @@ namespace sqy {
 // bitswap1: bit-plane transpose of `len` elements (encoders/bitswap_scheme_impl.hpp:97-145)
 // piece_hash != nullptr (bitswap1_piece_hash_words(..) words, only offered when that is non-zero): a hash of every 1 KiB piece of
 // plane data is left there for launch_lz4_dedupe
-hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash = nullptr);
+// gap_chunk != 0 ("frames in place", see launch_lz4_tail_marks): the plane stream is written as the bodies of the LZ4 frames it
+// will be cut into -- chunk k (gap_chunk bytes, a power of two) at out + k * (gap_chunk + 15), `out` any alignment; needs
+// len % 8192 == 0
+hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash = nullptr,
+                               uint32_t gap_chunk = 0);
 uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len);
 // duplicate chunks of a plane stream (chunk a multiple of 1 KiB): dup_of[k] = the earliest chunk with the same bytes (k itself when
 // there is none); the hashes only nominate, a byte compare decides.  work: lz4_dedupe_work_bytes(nchunks) bytes
 uint64_t lz4_dedupe_work_bytes(uint64_t nchunks);
+// in_stride (all LZ4 launchers; 0 = chunk): chunk k of the stream starts at in + k * in_stride
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream);
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0);
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
 
 // diff3x3x1 on a {Z,Y,X} volume of 1- or 2-byte unsigned voxels (encoders/diff_scheme_impl.hpp:78-139)
@@ -30,10 +35,10 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 // there (redo[0] = count, redo[1..] = chunk numbers); launch_lz4_chunks_dense then parses exactly those
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr);
+                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr, uint64_t in_stride = 0);
 hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                                    uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
-                                   const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0);
+                                   const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0, uint64_t in_stride = 0);
 // One block of a block-linked LZ4 frame (liblz4's LZ4F_blockLinked, what lz4::encode_serial produces: lz4_utils.hpp:99-173):
 // where it sits in the stream and how far liblz4's backward catch-up may move a match that starts inside the block
 // (low_in) or in the history in front of it (low_dict); stream offsets, may lie below `start - 64 KiB`.
@@ -52,12 +57,22 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
 // if it closes one)
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
                                  uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks = nullptr,
-                                 const uint32_t* dup_of = nullptr);
+                                 const uint32_t* dup_of = nullptr, uint64_t* tail_info = nullptr);
+// Frames in place (chunked layout; the stage in front wrote chunk k of the stream at body0 + k * in_stride, in_stride = chunk + 15):
+// tail_info (4 words, from the scan) = {j, bytes of frames 0..j-1, stored chunks among them, payload bytes}, j = first chunk of
+// the run of stored chunks that ends the stream.  Those are final where they stand: tail_marks writes header / size field / end
+// mark around them.  The frames in front are gathered (launch_lz4_frame_gather over j chunks) to END at body0 - 11 + j * in_stride;
+// stored chunks among THEM are first put aside in their scratch slots (stash_raw; gather then with raw_from_scratch).
+hipError_t launch_lz4_tail_marks(uint8_t* body0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks, uint32_t bd_byte,
+                                 uint32_t hc_byte, const uint64_t* tail_info, hipStream_t stream);
+hipError_t launch_lz4_stash_raw(const uint8_t* body0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
+                                const uint32_t* csize, const uint32_t* dup_of, uint64_t nhead, hipStream_t stream);
 // writes [04 22 4D 18 | 40 | BD | HC][u32 size][data][00 00 00 00] per chunk at out + frame_off[k]
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
                                    uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                                   uint64_t frame_bytes = 0, const Lz4Block* blocks = nullptr, const uint32_t* dup_of = nullptr);
+                                   uint64_t frame_bytes = 0, const Lz4Block* blocks = nullptr, const uint32_t* dup_of = nullptr,
+                                   uint64_t in_stride = 0, bool raw_from_scratch = false);
 
 // quantiser: 65536-bin histogram of u16 voxels (histo is zeroed by the launcher), and out[i] = lut[in[i]]
 hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);

@@ -147,9 +147,14 @@ __device__ __forceinline__ void transpose16x16_pairs(uint32_t r[16])
 // still finds room (wave slots and registers only).
 // piece_hash != nullptr: a 32-bit hash of every 1 KiB piece of plane data the wave writes goes to piece_hash (four partial
 // sums per piece, one per 16-lane row) -- what the LZ4 stage's duplicate-chunk detection is built on (lz4_dedupe_*).
+// GAP (frames in place, see lz4_tail_*): the plane stream is written as the BODIES of the LZ4 frames it will be cut into --
+// chunk k of 2^gap_shift bytes starts at out + k * (chunk + 15), the 15 bytes in between being the frame header, size field and
+// end mark of a stored frame.  A chunk the LZ4 stage stores raw then never moves again.  The 1 KiB pieces land 0..15 bytes
+// off a 16-byte boundary; plain unaligned 16-byte stores (measured within 8 % of aligned ones, tools/ubench_align.hip).
+template <bool GAP>
 __global__ __launch_bounds__(256)
 void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words,
-                       uint32_t* __restrict__ piece_hash)
+                       uint32_t* __restrict__ piece_hash, uint32_t gap_shift)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -177,9 +182,15 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
         }
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
             const v4u val = {pl[b][0], pl[b][1], pl[b][2], pl[b][3]};
-            __builtin_nontemporal_store(val, dst + lane);
+            if (GAP) {
+                const uint64_t B = (uint64_t)(15 - b) * seg_words * 2u + tile * 1024u;      // byte offset of the piece in the plane stream
+                uint8_t* dst = reinterpret_cast<uint8_t*>(out) + B + (B >> gap_shift) * 15u;
+                *reinterpret_cast<v4u_any*>(dst + lane * 16) = val;
+            } else {
+                v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
+                __builtin_nontemporal_store(val, dst + lane);
+            }
         }
         if (piece_hash) {
             const uint32_t pm = 2u * (uint32_t)lane + 1u;                // position inside the piece
@@ -244,7 +255,7 @@ void lz4_dedupe_key_kernel(const uint32_t* __restrict__ piece_hash, uint32_t pie
 
 constexpr uint32_t DEDUPE_THREADS = 256;
 __global__ __launch_bounds__(DEDUPE_THREADS)
-void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, uint64_t nchunks_full, uint64_t nchunks,
+void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, uint64_t in_stride, uint64_t nchunks_full, uint64_t nchunks,
                               const uint64_t* __restrict__ chunk_key, const uint64_t* __restrict__ tab_key,
                               const uint32_t* __restrict__ tab_val, uint32_t tab_mask, uint32_t* __restrict__ dup_of)
 {
@@ -269,19 +280,20 @@ void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, ui
     const uint32_t r = s_rep;
     if (r >= k) { if (threadIdx.x == 0) dup_of[k] = (uint32_t)k; return; }     // (uniform) first of its kind
     if (chunk_key[k] == 1ull) { if (threadIdx.x == 0) dup_of[k] = r; return; } // all zero, exactly: equal to the first all-zero chunk
-    // compare chunk k with chunk r (chunk is a multiple of 1 KiB here; plane streams are 16-byte aligned)
-    const uint4* a = reinterpret_cast<const uint4*>(in + k * chunk);
-    const uint4* b = reinterpret_cast<const uint4*>(in + (uint64_t)r * chunk);
+    // compare chunk k with chunk r (chunk is a multiple of 1 KiB here; chunk bodies may sit at any byte alignment)
+    const v4u_any* a = reinterpret_cast<const v4u_any*>(in + k * in_stride);
+    const v4u_any* b = reinterpret_cast<const v4u_any*>(in + (uint64_t)r * in_stride);
     const uint32_t nvec = chunk >> 4;
     uint32_t diff = 0;
     for (uint32_t i = threadIdx.x; i < nvec; i += DEDUPE_THREADS * 4u) {
         // four independent 16-byte pairs in flight per thread
-        uint4 x[4], y[4];
+        v4u x[4], y[4];
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t j = i + u * DEDUPE_THREADS;
-            x[u] = j < nvec ? a[j] : make_uint4(0, 0, 0, 0);
-            y[u] = j < nvec ? b[j] : make_uint4(0, 0, 0, 0);
+            const v4u zero = {0, 0, 0, 0};
+            x[u] = j < nvec ? (v4u)a[j] : zero;
+            y[u] = j < nvec ? (v4u)b[j] : zero;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) diff |= (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y) | (x[u].z ^ y[u].z) | (x[u].w ^ y[u].w);
@@ -728,7 +740,7 @@ constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positio
 // free of the dense batches' registers (and the dense batches free to use a larger window).
 template <bool LINKED, bool DENSE>
 __global__ __launch_bounds__(64)
-void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk,
+void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk, uint64_t in_stride,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
@@ -768,7 +780,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         // frame_shuffle in front of the sink: the stream is the frames of `in` in the order fmap gives (a chunk never straddles
         // two frames, the host checks fbytes % chunk == 0), read in place instead of gathered into a copy first
         const uint64_t lin = blk * chunk;
-        src = fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin;
+        // (in_stride: chunk k of the stream starts at in + k * in_stride -- chunk bytes apart, or chunk + 15 when the stage in
+        // front wrote the stream as frame bodies in place)
+        src = fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + blk * in_stride;
         const uint64_t left = total - blk * chunk;
         n = (uint32_t)(left < chunk ? left : chunk);
     }
@@ -1542,21 +1556,25 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 // ------------------------------------------------------------------------------------------------
 // blocks == nullptr: every chunk is a single-block frame.  Otherwise block k of the list contributes its 4-byte size
 // field and body, plus the 7-byte frame header when it opens a frame and the 4-byte end mark when it closes one.
+// tail_info != nullptr (frames in place): [0] = j, the first chunk of the run of stored chunks that ends the stream (nchunks when
+// the last chunk compressed), [1] = bytes of the frames in front of it, [2] = stored chunks among those, [3] = payload bytes
 __global__ __launch_bounds__(1024)
 void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
                            uint64_t* __restrict__ frame_off /* nchunks + 1 */, const Lz4Block* __restrict__ blocks,
-                           const uint32_t* __restrict__ dup_of)
+                           const uint32_t* __restrict__ dup_of, uint64_t* __restrict__ tail_info)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
+    __shared__ uint32_t last_comp_s, raw_head_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) carry_s = 0;
+    if (tid == 0) { carry_s = 0; last_comp_s = 0; raw_head_s = 0; }
     __syncthreads();
     for (uint64_t base = 0; base < nchunks; base += 1024) {
         const uint64_t k = base + tid;
         uint64_t sz = 0;
         if (k < nchunks) {
             const uint32_t c = csize[dup_of ? dup_of[k] : k];
+            if (tail_info && c) atomicMax(&last_comp_s, (uint32_t)k + 1u);
             if (blocks) {
                 const Lz4Block bd = blocks[k];
                 sz = ((bd.flags & 1u) ? 7 : 0) + 4 + (c ? c : bd.n) + ((bd.flags & 2u) ? 4 : 0);
@@ -1584,6 +1602,61 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
         __syncthreads();
     }
     if (tid == 0) frame_off[nchunks] = carry_s;
+    if (tail_info) {
+        __syncthreads();
+        const uint32_t j = last_comp_s;
+        uint32_t nraw = 0;
+        for (uint64_t k = tid; k < j; k += 1024) nraw += csize[dup_of ? dup_of[k] : k] == 0u ? 1u : 0u;
+        if (nraw) atomicAdd(&raw_head_s, nraw);
+        __syncthreads();
+        if (tid == 0) {
+            tail_info[0] = j;
+            tail_info[1] = frame_off[j];
+            tail_info[2] = raw_head_s;
+            tail_info[3] = carry_s;
+        }
+    }
+}
+
+// Frames in place: the stage in front of lz4 wrote chunk k of the stream at body0 + k * in_stride (in_stride = chunk + 15).  The
+// stored chunks that END the stream (k >= tail_info[0]) are final where they are -- they only get their 7-byte frame header,
+// size field and end mark written around them; the frames in front are gathered so that they end where that run begins.
+__global__ __launch_bounds__(256)
+void lz4_tail_marks_kernel(uint8_t* __restrict__ body0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
+                           uint32_t bd_byte, uint32_t hc_byte, const uint64_t* __restrict__ tail_info)
+{
+    const uint64_t k = tail_info[0] + (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k >= nchunks) return;
+    const uint64_t left = total - k * chunk;
+    const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
+    uint8_t* b = body0 + k * in_stride;
+    const uint32_t field = nk | 0x80000000u;
+    b[-11] = 0x04; b[-10] = 0x22; b[-9] = 0x4D; b[-8] = 0x18; b[-7] = 0x40; b[-6] = (uint8_t)bd_byte; b[-5] = (uint8_t)hc_byte;
+    b[-4] = (uint8_t)field; b[-3] = (uint8_t)(field >> 8); b[-2] = (uint8_t)(field >> 16); b[-1] = (uint8_t)(field >> 24);
+    b[nk] = 0; b[nk + 1] = 0; b[nk + 2] = 0; b[nk + 3] = 0;
+}
+
+// Stored chunks IN FRONT of that run move (towards higher addresses, over their own and their neighbours' old places): they are
+// first put aside in their -- unused -- compressed-output slots; the gather then reads every frame body from the scratch.
+__global__ __launch_bounds__(256)
+void lz4_stash_raw_kernel(const uint8_t* __restrict__ body0, uint64_t in_stride, uint64_t total, uint32_t chunk,
+                          uint8_t* __restrict__ scratch, uint64_t stride, const uint32_t* __restrict__ csize,
+                          const uint32_t* __restrict__ dup_of, uint32_t slices_per_chunk)
+{
+    const uint64_t k = blockIdx.x / slices_per_chunk;
+    const uint32_t slice = blockIdx.x % slices_per_chunk;
+    if (csize[dup_of ? dup_of[k] : k] != 0u) return;
+    const uint64_t left = total - k * chunk;
+    const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
+    const uint32_t begin = slice * 32768u;
+    if (begin >= nk) return;
+    const uint32_t end = begin + 32768u < nk ? begin + 32768u : nk;
+    const uint8_t* __restrict__ sp = body0 + k * in_stride + begin;
+    uint8_t* __restrict__ dp = scratch + k * stride + begin;            // 16-byte aligned (stride and slices are)
+    const uint32_t len = end - begin, nvec = len >> 4;
+    for (uint32_t i = threadIdx.x; i < nvec; i += 256) *reinterpret_cast<uint4*>(dp + (size_t)i * 16) = ld_u128(sp + (size_t)i * 16);
+    const uint32_t done = nvec << 4;
+    if (threadIdx.x < len - done) dp[done + threadIdx.x] = sp[done + threadIdx.x];
 }
 
 // one workgroup per (chunk, slice): copies its slice of the frame body, slice 0 also writes header/trailer
@@ -1595,7 +1668,7 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
                              const uint32_t* __restrict__ csize, const uint64_t* __restrict__ frame_off,
                              uint8_t* __restrict__ out, uint32_t bd_byte, uint32_t hc_byte, uint32_t slices_per_chunk,
                              const uint64_t* __restrict__ fmap, uint64_t fbytes, const Lz4Block* __restrict__ blocks,
-                             const uint32_t* __restrict__ dup_of)
+                             const uint32_t* __restrict__ dup_of, uint64_t in_stride, int raw_from_scratch)
 {
     const uint64_t k = blockIdx.x / slices_per_chunk;
     const uint32_t slice = blockIdx.x % slices_per_chunk;
@@ -1610,7 +1683,12 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
     const uint64_t ks = dup_of ? dup_of[k] : k;                      // the chunk whose compressed bytes this one shares
     const uint32_t c = csize[ks];
     const uint32_t body = c ? c : nk;
-    const uint8_t* __restrict__ s = c ? scratch + ks * stride : (fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes : in + lin);
+    // a stored chunk: from the stream (chunk k at in + k * in_stride in the chunked layout), or from its own scratch slot when
+    // it was put aside there (lz4_stash_raw_kernel)
+    const uint8_t* __restrict__ s = c ? scratch + ks * stride
+                                      : raw_from_scratch ? scratch + k * stride
+                                      : fmap ? in + fmap[lin / fbytes] * fbytes + lin % fbytes
+                                      : blocks ? in + lin : in + k * in_stride;
     uint8_t* __restrict__ d = out + frame_off[k];
     const int tid = threadIdx.x;
     const uint32_t hdr = (flags & 1u) ? 7u : 0u;                     // frame header in front of the block's size field
@@ -3387,9 +3465,18 @@ static inline int num_cus()
     return cus;
 }
 
-hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash)
+hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash, uint32_t gap_chunk)
 {
     if (len == 0) return hipSuccess;
+    if (gap_chunk) {
+        // frames in place: whole tiles only, chunks a power of two of at least one piece, `out` = body of chunk 0 (any alignment)
+        if (len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || gap_chunk < 1024u || (gap_chunk & (gap_chunk - 1u)))
+            return hipErrorInvalidValue;
+        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 3) / 4, cap = (uint64_t)num_cus() * 16;
+        hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, in, out, n_tiles, len / 16,
+                           piece_hash, (uint32_t)__builtin_ctz(gap_chunk));
+        return hipGetLastError();
+    }
     const uint64_t seg_words = len / 16;
     uint64_t n_tiles = 0;
     const bool aligned = (seg_words % 8 == 0) && ((reinterpret_cast<uintptr_t>(in) & 15) == 0) &&
@@ -3403,7 +3490,7 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         const uint64_t want = (n_tiles + 3) / 4;
         const uint64_t cap = (uint64_t)num_cus() * 16;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
-        hipLaunchKernelGGL(bitswap1_u16_regs, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words, piece_hash);
+        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u);
     }
     const uint64_t first_word = n_tiles * (BSW_TILE_VOX / 16);
     const uint64_t rest_words = seg_words - first_word;
@@ -3425,11 +3512,12 @@ uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len
 }
 
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream)
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride)
 {
     const uint64_t nchunks = (total + chunk - 1) / chunk, nfull = total / chunk;
     if (nchunks == 0) return hipSuccess;
-    if (chunk % 1024 != 0 || (reinterpret_cast<uintptr_t>(in) & 15)) return hipErrorInvalidValue;
+    if (in_stride == 0) in_stride = chunk;
+    if (chunk % 1024 != 0) return hipErrorInvalidValue;
     uint32_t tab = 64;
     while (tab < 2 * nchunks) tab <<= 1;
     uint64_t* chunk_key = static_cast<uint64_t*>(work);
@@ -3442,7 +3530,7 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
     if (nfull)
         hipLaunchKernelGGL(lz4_dedupe_key_kernel, dim3((unsigned)nfull), dim3(64), 0, stream, piece_hash, chunk / 1024u, nfull, chunk_key, tab_key,
                            tab_val, tab - 1u);
-    hipLaunchKernelGGL(lz4_dedupe_verify_kernel, dim3((unsigned)nchunks), dim3(DEDUPE_THREADS), 0, stream, in, chunk, nfull, nchunks, chunk_key,
+    hipLaunchKernelGGL(lz4_dedupe_verify_kernel, dim3((unsigned)nchunks), dim3(DEDUPE_THREADS), 0, stream, in, chunk, in_stride, nfull, nchunks, chunk_key,
                        tab_key, tab_val, tab - 1u, dup_of);
     return hipGetLastError();
 }
@@ -3499,25 +3587,27 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                             uint32_t* redo, const uint32_t* dup_of)
+                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride)
 {
     if (nchunks == 0) return hipSuccess;
+    if (in_stride == 0) in_stride = chunk;
     if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
     if (redo) {
         const hipError_t e = hipMemsetAsync(redo, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+    hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
                        frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                                    uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
-                                   const uint64_t* frame_map, uint64_t frame_bytes)
+                                   const uint64_t* frame_map, uint64_t frame_bytes, uint64_t in_stride)
 {
     if (redo_count == 0) return hipSuccess;
-    hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, scratch, stride, csize,
+    if (in_stride == 0) in_stride = chunk;
+    hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
                        frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr SQY_DIAG_NULL);
     return hipGetLastError();
 }
@@ -3527,27 +3617,48 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
 {
     if (nframes == 0) return hipSuccess;
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, scratch, stride, csize,
+    hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
                        (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks, const uint32_t* dup_of)
+                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks, const uint32_t* dup_of, uint64_t* tail_info)
 {
-    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of);
+    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of, tail_info);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_tail_marks(uint8_t* body0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks, uint32_t bd_byte,
+                                 uint32_t hc_byte, const uint64_t* tail_info, hipStream_t stream)
+{
+    if (nchunks == 0) return hipSuccess;
+    hipLaunchKernelGGL(lz4_tail_marks_kernel, dim3((unsigned)((nchunks + 255) / 256)), dim3(256), 0, stream, body0, in_stride, total, chunk,
+                       nchunks, bd_byte, hc_byte, tail_info);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_stash_raw(const uint8_t* body0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
+                                const uint32_t* csize, const uint32_t* dup_of, uint64_t nhead, hipStream_t stream)
+{
+    if (nhead == 0) return hipSuccess;
+    const uint32_t slices = (chunk + 32767u) / 32768u;
+    hipLaunchKernelGGL(lz4_stash_raw_kernel, dim3((unsigned)(nhead * slices)), dim3(256), 0, stream, body0, in_stride, total, chunk, scratch,
+                       stride, csize, dup_of, slices);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t chunk, const uint8_t* scratch, uint64_t stride,
                                    const uint32_t* csize, const uint64_t* frame_off, uint8_t* out, uint32_t bd_byte,
                                    uint32_t hc_byte, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                                   const Lz4Block* blocks, const uint32_t* dup_of)
+                                   const Lz4Block* blocks, const uint32_t* dup_of, uint64_t in_stride, bool raw_from_scratch)
 {
     if (nchunks == 0) return hipSuccess;
+    if (in_stride == 0) in_stride = chunk;
     const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;      // (chunk = largest block of the list when `blocks`)
     hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(nchunks * slices)), dim3(256), 0, stream, in, total, chunk,
-                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes, blocks, dup_of);
+                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes, blocks, dup_of, in_stride,
+                       raw_from_scratch ? 1 : 0);
     return hipGetLastError();
 }
 

@@ -1,0 +1,68 @@
+"""GPU parity of the "frames in place" path (SQYAMD_PipelineEncode_UI16_DeviceAt and the host-pointer entry points on top of
+it): a 16-bit bitswap1 in front of lz4 writes the plane stream as the bodies of its future LZ4 frames, the stored frames that
+end the payload stay where they are, the frames in front are gathered up against them.  Blob bytes against the oracle."""
+import numpy as np
+import pytest
+
+from sqeazy_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _cases():
+    rng = np.random.default_rng(11)
+    shape = (32, 128, 128)                                          # 1 MiB: four 256 KiB chunks, every chunk spans four bit planes
+    yield "synth", "bitswap1->lz4", synth.stack(shape, np.uint16)                               # compressed head, stored tail
+    yield "synth_big", "bitswap1->lz4", synth.stack((64, 256, 512), np.uint16)                  # 16 MiB, 64 chunks, duplicate chunks
+    yield "zeros", "bitswap1->lz4", np.zeros(shape, np.uint16)                                  # nothing stored: everything is gathered
+    yield "random", "bitswap1->lz4", rng.integers(0, 65536, shape, dtype=np.uint16)             # everything stored: nothing moves
+    yield "stored_in_front", "bitswap1->lz4", (rng.integers(0, 2, (64, 256, 256)) * 0x8000).astype(np.uint16)   # plane 15 noise, the rest zero
+    mixed = rng.integers(0, 2, (64, 256, 256)).astype(np.uint16) * 0x8000                       # stored, compressed, stored, compressed, stored
+    mixed |= (rng.integers(0, 2, (64, 256, 256)).astype(np.uint16) << 7) | rng.integers(0, 4, (64, 256, 256)).astype(np.uint16)
+    yield "stored_compressed_alternating", "bitswap1->lz4", mixed
+    yield "diff", "diff3x3x1->bitswap1->lz4", synth.stack((32, 128, 256), np.uint16)
+    yield "small_chunks", "bitswap1->lz4(blocksize_kb=64,framestep_kb=64)", synth.stack(shape, np.uint16)
+    yield "ragged_last_chunk", "bitswap1->lz4", synth.stack((33, 64, 128), np.uint16)           # 528 KiB: two chunks and a bit
+    yield "not_in_place_odd_tiles", "bitswap1->lz4", synth.stack((3, 50, 70), np.uint16)        # no whole tiles: the ordinary path, offset 0
+    yield "not_in_place_serial", "bitswap1->lz4", synth.stack(shape, np.uint16)                 # nthreads = 1 (below): one linked frame
+
+
+@pytest.mark.parametrize("name,pipeline,vol", list(_cases()), ids=[c[0] for c in _cases()])
+def test_blob_in_place_equals_oracle(sqy, oracle, name, pipeline, vol):
+    import torch
+    dev = torch.device("cuda", 0)
+    nthreads = 1 if name.endswith("serial") else 2
+    want = oracle.pipeline_encode(pipeline, vol, nthreads=nthreads)
+    d_vol = torch.from_numpy(vol.copy()).to(dev)
+    cap = sqy.max_compressed_length(pipeline, vol.shape, vol.dtype)
+    out = torch.full((cap,), 0xA5, dtype=torch.uint8, device=dev)
+    rc, off, n = sqy.encode_device_at(pipeline, d_vol.data_ptr(), vol.shape, vol.dtype, out.data_ptr(), cap, nthreads=nthreads)
+    assert rc == 0
+    assert 0 <= off and off + n <= cap
+    got = bytes(out[off:off + n].cpu().numpy().tobytes())
+    assert len(got) == len(want)
+    assert got == want
+    if name.startswith("not_in_place"):
+        assert off == 0
+    elif name not in ("zeros",):
+        assert off > 0
+    # the plain device entry point (blob at the start of the destination) and the host-pointer one give the same bytes
+    rc, n2 = sqy.encode_device(pipeline, d_vol.data_ptr(), vol.shape, vol.dtype, out.data_ptr(), cap, nthreads=nthreads)
+    assert rc == 0 and bytes(out[:n2].cpu().numpy().tobytes()) == want
+    rc, blob = sqy.encode(pipeline, vol, nthreads=nthreads)
+    assert rc == 0 and blob == want
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+
+
+def test_in_place_needs_room(sqy, oracle):
+    """a destination that holds the blob but not the frames in place: the ordinary path is taken, same bytes"""
+    import torch
+    dev = torch.device("cuda", 0)
+    vol = synth.stack((32, 128, 128), np.uint16)
+    want = oracle.pipeline_encode("bitswap1->lz4", vol)
+    d_vol = torch.from_numpy(vol.copy()).to(dev)
+    cap = len(want) + 64
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    rc, off, n = sqy.encode_device_at("bitswap1->lz4", d_vol.data_ptr(), vol.shape, vol.dtype, out.data_ptr(), cap)
+    assert rc == 0 and off == 0 and bytes(out[:n].cpu().numpy().tobytes()) == want

@@ -26,10 +26,10 @@ int main(int argc, char** argv)
     for (int rep = 0; rep < 3; ++rep) {
         CK(hipEventRecord(e0, 0));
         CK(hipMemset(dredo, 0, 4));
-        hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, false>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
+        hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, false>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, (uint64_t)chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
                            (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, (const uint32_t*)nullptr, ddg);
         uint32_t nredo = 0; CK(hipMemcpy(&nredo, dredo, 4, hipMemcpyDeviceToHost));
-        if (nredo) hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, true>), dim3(nredo), dim3(64), 0, 0, din, (uint64_t)n, chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
+        if (nredo) hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, true>), dim3(nredo), dim3(64), 0, 0, din, (uint64_t)n, chunk, (uint64_t)chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
                            (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, (const uint32_t*)nullptr, ddg);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
