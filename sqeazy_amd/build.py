@@ -33,6 +33,7 @@ def needs_build():
         return True
     t = min(os.path.getmtime(LIB), os.path.getmtime(CLI))
     deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS + ["sqy_cli.cpp", "sqy_h5_filter.c"]] + [os.path.abspath(__file__)]   # (FLAGS live here)
+    deps += [os.path.join(HERE, "..", "tools", f) for f in ("slabs_c_test.c", "h5_roundtrip.c")]
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
@@ -60,6 +61,14 @@ def build(force=False, verbose=False):
     os.makedirs(BINDIR, exist_ok=True)
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", os.path.join(CSRC, "sqy_cli.cpp"), "-o", CLI, "-L" + LIBDIR, "-lsqeazy_amd",
            "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath-link," + os.path.join(os.environ.get("ROCM_PATH", "/opt/rocm"), "lib")]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    # a plain C caller of the throughput entry point (tools/slabs_c_test.c): C compiler, HIP runtime API for device memory only
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cmd = ["gcc", "-O2", "-fopenmp", "-Wall", "-I" + os.path.join(rocm, "include"), os.path.join(HERE, "..", "tools", "slabs_c_test.c"), "-o",
+           os.path.join(BINDIR, "slabs_c_test"), "-L" + LIBDIR, "-lsqeazy_amd", "-L" + os.path.join(rocm, "lib"), "-lamdhip64",
+           "-Wl,-rpath,$ORIGIN/../lib", "-Wl,-rpath," + os.path.join(rocm, "lib")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
