@@ -12,6 +12,7 @@
 //
 // No CUDA compatibility layer, no dual paths: this file only targets gfx950.
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <mutex>
 #include <stdint.h>
 #include <cstdlib>
@@ -3182,12 +3183,13 @@ void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out
 // round trip from store to use, instead of four with a counter published behind the data (drain the stores, publish, poll, load).
 // Two slots per edge, by frame parity: a strip overwrites a slot only after it has received the neighbour's next frame, which the
 // neighbour computed after reading that slot.  The buffer starts as all-ones (tag 0xffff is never used).
-// All workgroups must be resident at once: the launcher sizes the grid to the chip; a wait that does not end (the chip shared so
-// that some strips cannot start) raises the abort word behind the exchange buffer and the launcher falls back to per-frame kernels.
+// All workgroups must be resident at once: the launcher bounds the grid by the occupancy the runtime reports and launches it
+// COOPERATIVELY (refused at launch when it does not fit, one cooperative grid at a time per device); a wait that does not end
+// all the same raises the abort word behind the exchange buffer (a guard) and the launcher falls back to per-frame kernels.
 constexpr uint32_t DIFFDEC_NT = 1024;         // threads per strip: the stage is instruction issue, so every SIMD gets 4 waves to interleave
 constexpr uint32_t DIFFDEC_MAXV = 2;          // 16-byte vectors per thread and frame
 constexpr uint32_t DIFFDEC_MAXQ = 2;          // exchange words per thread and halo row (rows of up to 6144 voxels)
-constexpr uint64_t DIFFDEC_MAX_STRIPS = 256;  // one workgroup per CU: all resident whatever else the stream's neighbours run
+constexpr uint64_t DIFFDEC_MAX_STRIPS = 256;  // at most one workgroup per CU
 
 // workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global access in flight (vmcnt(0)),
 // here the frame fetched ahead and the stores of the frame before -- an HBM round trip per barrier
@@ -3933,27 +3935,49 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
         const uint64_t lds = (R + 4) * X * 2;             // the strip of the last frame + 2 halo rows + 2 rows on their way out
         const uint64_t NQ = (X + 2) / 3;
         if (lds <= 65536 && R * (X / 8) <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXV && NQ <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXQ) {
-            // one strips kernel at a time per process: two fit the chip side by side, three dispatched from three host threads
-            // at once could each end up half resident and wait for strips that cannot start (until the poll limit, ~1 s)
-            static std::mutex strips_mu;
-            std::lock_guard<std::mutex> strips_lock(strips_mu);
+            // The strips wait for each other, so ALL of them must be resident at once.  That is what a cooperative launch is for:
+            // it is refused at launch time when the grid does not fit the device (instead of half-residing and spinning), and the
+            // runtime runs one cooperative grid at a time per device -- two decodes in flight (this process or another one) can no
+            // longer each hold half the chip and wait for strips that cannot start.  (Round 2 used a plain launch behind a
+            // process-local mutex; the poll limit + abort word below stay as a guard only.)  Other kernels on the chip -- LZ4
+            // chunk waves of an encode in flight -- finish on their own, a strip that has to wait for their LDS is late, not stuck.
+            int dev = 0, coop = 0, occ = 0;
+            hipError_t e = hipGetDevice(&dev);
+            if (e == hipSuccess) e = hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
+            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, diff3x3x1_decode_strips_kernel, (int)DIFFDEC_NT, (size_t)lds);
+            static std::atomic<uint32_t> strips_refused[16];                 // per device: the one-launch path failed before, do not try again
+            const bool usable = e == hipSuccess && coop && occ >= 1 && G <= (uint64_t)num_cus() * (uint64_t)occ && dev >= 0 && dev < 16 &&
+                                strips_refused[dev].load() == 0;
+            (void)hipGetLastError();
+            if (usable) {
             const uint64_t exch_bytes = G * 4 * NQ * 8;
             uint32_t* const abort_word = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + exch_bytes);
-            hipError_t e = hipMemsetAsync(scratch, 0xff, exch_bytes, stream);
+            e = hipMemsetAsync(scratch, 0xff, exch_bytes, stream);
             if (e != hipSuccess) return e;
             e = hipMemsetAsync(abort_word, 0, 64, stream);
             if (e != hipSuccess) return e;
-            hipLaunchKernelGGL(diff3x3x1_decode_strips_kernel, dim3((unsigned)G), dim3(DIFFDEC_NT), (size_t)lds, stream, (const uint16_t*)in,
-                               (uint16_t*)out, (uint32_t)Z, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)R,
-                               static_cast<uint64_t*>(scratch), abort_word);
-            e = hipGetLastError();
-            if (e != hipSuccess) return e;
+            const uint16_t* a_in = (const uint16_t*)in;
+            uint16_t* a_out = (uint16_t*)out;
+            uint32_t a_Z = (uint32_t)Z, a_Y = (uint32_t)Y, a_X = (uint32_t)X, a_hx = (uint32_t)hx, a_zlim = (uint32_t)zlim, a_R = (uint32_t)R;
+            uint64_t* a_exch = static_cast<uint64_t*>(scratch);
+            uint32_t* a_abort = abort_word;
+            void* args[] = {&a_in, &a_out, &a_Z, &a_Y, &a_X, &a_hx, &a_zlim, &a_R, &a_exch, &a_abort};
+            e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(diff3x3x1_decode_strips_kernel), dim3((unsigned)G), dim3(DIFFDEC_NT), args,
+                                           (unsigned)lds, stream);
+            if (e != hipSuccess) {
+                // refused (grid too large for what is free, no cooperative queue): the per-frame kernels below, from now on
+                (void)hipGetLastError();
+                strips_refused[dev].store(1);
+            } else {
             uint32_t aborted = 0;
             e = hipMemcpyAsync(&aborted, abort_word, sizeof(aborted), hipMemcpyDeviceToHost, stream);
             if (e != hipSuccess) return e;
             e = hipStreamSynchronize(stream);
             if (e != hipSuccess) return e;
             if (!aborted) return hipSuccess;
+            strips_refused[dev].store(1);                                     // (the guard fired: never again on this device)
+            }
+            }
         }
     }
     // per frame; the last X + 1 voxels of a frame read the frame's own first voxels when rows spill over (see the kernel)

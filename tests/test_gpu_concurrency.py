@@ -66,3 +66,37 @@ def test_concurrent_full_width_diff_decodes(sqy, oracle):
         th.join(timeout=600)
     assert not errors, errors[:3]
     assert time.perf_counter() - t0 < 60, "decodes stalled (strip kernels waiting for strips that could not start?)"
+
+
+def test_diff_decode_next_to_encodes_in_flight(sqy, oracle):
+    """the one-launch diff3x3x1 decode (strips that wait for each other: a cooperative launch) while encodes of a large stack keep
+    the chip's LDS full of LZ4 chunk waves on other streams: the decode may be late, it must not stall or go wrong"""
+    import time
+    vol = synth.stack((48, 1024, 256), np.uint16)
+    blob = oracle.pipeline_encode("diff3x3x1->bitswap1->lz4", vol)
+    big = synth.stack((64, 1024, 1024), np.uint16)                     # 128 MiB: 512 chunks per encode
+    want_big = oracle.pipeline_encode("bitswap1->lz4", big)
+    errors, stop = [], threading.Event()
+
+    def encoder(t):
+        try:
+            while not stop.is_set():
+                rc, b = sqy.encode("bitswap1->lz4", big, nthreads=0)
+                assert rc == 0 and b == want_big, ("encode", t)
+        except Exception as e:   # pragma: no cover
+            errors.append(repr(e))
+
+    enc = [threading.Thread(target=encoder, args=(t,)) for t in range(2)]
+    for th in enc:
+        th.start()
+    t0 = time.perf_counter()
+    try:
+        for _ in range(6):
+            rc, dec = sqy.decode(blob)
+            assert rc == 0 and np.array_equal(dec, vol)
+    finally:
+        stop.set()
+        for th in enc:
+            th.join(timeout=600)
+    assert not errors, errors[:3]
+    assert time.perf_counter() - t0 < 120

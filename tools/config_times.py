@@ -10,12 +10,12 @@ def run(pipeline, shape, dtype, reps=3, extra=0):
     vol = synth.stack_torch(shape, dtype, dev)
     cap = sqeazy_amd.max_compressed_length(pipeline, shape, dtype) + extra
     out = torch.empty(cap, dtype=torch.uint8, device=dev)
-    rc, m = sqeazy_amd.encode_device(pipeline, vol.data_ptr(), shape, dtype, out.data_ptr(), cap); assert rc == 0
+    rc, off, m = sqeazy_amd.encode_device_at(pipeline, vol.data_ptr(), shape, dtype, out.data_ptr(), cap); assert rc == 0
     sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
     import time
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
-        rc, m = sqeazy_amd.encode_device(pipeline, vol.data_ptr(), shape, dtype, out.data_ptr(), cap)
+        rc, off, m = sqeazy_amd.encode_device_at(pipeline, vol.data_ptr(), shape, dtype, out.data_ptr(), cap)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
     sqeazy_amd.profile_enable(False)
     p = sqeazy_amd.profile_get()
@@ -26,10 +26,10 @@ def run(pipeline, shape, dtype, reps=3, extra=0):
     back = torch.empty(nb, dtype=torch.uint8, device=dev)
     L = sqeazy_amd.lib(); import ctypes
     fn = L.SQYAMD_Decode_UI16_Device if np.dtype(dtype) == np.uint16 else L.SQYAMD_Decode_UI8_Device
-    rc = fn(ctypes.c_void_p(out.data_ptr()), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
+    rc = fn(ctypes.c_void_p(out.data_ptr() + off), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
     sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
     torch.cuda.synchronize(); t0 = time.perf_counter()
-    rc = fn(ctypes.c_void_p(out.data_ptr()), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
+    rc = fn(ctypes.c_void_p(out.data_ptr() + off), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
     torch.cuda.synchronize(); dd = time.perf_counter() - t0
     sqeazy_amd.profile_enable(False)
     pd = sqeazy_amd.profile_get()
