@@ -113,6 +113,19 @@ SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_DeviceAt(const char* pipeline
 SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_DeviceAt(const char* pipeline, const void* d_src, const long* shape,
                                                            unsigned shape_size, void* d_dst, long dst_capacity, long* dstoffset,
                                                            long* dstlength, int nthreads, void* hip_stream);
+/* As _DeviceAt; additionally tells where every `every`-th LZ4 frame of the payload starts (pipelines that end in lz4 in the
+ * chunked layout, one frame per chunk: encoders/lz4_utils.hpp:193-274): frame_offsets[i] = start of frame i * every relative to
+ * the blob start, i = 0 .. *count - 1, and frame_offsets[*count] = the blob length (max_entries >= *count + 1, else 1).  With
+ * every = chunks per bit plane this is the byte range of every bit plane of a `bitswap1->lz4` blob -- what the single-blob mode of
+ * the multi-GPU path re-orders (the frame sizes come from the encoder's own table in HBM, nobody walks the frames). */
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_DeviceAt_Frames(const char* pipeline, const void* d_src, const long* shape,
+                                                                   unsigned shape_size, void* d_dst, long dst_capacity,
+                                                                   long* dstoffset, long* dstlength, int nthreads, void* hip_stream,
+                                                                   int every, long* frame_offsets, int max_entries, int* count);
+SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_DeviceAt_Frames(const char* pipeline, const void* d_src, const long* shape,
+                                                                  unsigned shape_size, void* d_dst, long dst_capacity,
+                                                                  long* dstoffset, long* dstlength, int nthreads, void* hip_stream,
+                                                                  int every, long* frame_offsets, int max_entries, int* count);
 /* A whole volume as `nslabs` independent z-slab blobs with ONE call (the reference encodes one volume of < 2^31 voxels per call,
  * src/sqeazy.cpp:108-142; larger volumes are cut into z-slabs by its callers).  shape is the WHOLE volume {z,y,x}; slab i holds
  * frames [i*(Z/n) + min(i, Z%n), ...) -- the first Z % nslabs slabs get one frame more -- and is encoded exactly as
@@ -135,6 +148,27 @@ SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_Cap(const char* pipeline, cons
 
 SQY_FUNCTION_PREFIX int SQYAMD_Decode_UI16_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream);
 SQY_FUNCTION_PREFIX int SQYAMD_Decode_UI8_Device(const void* d_src, long srclength, void* d_dst, long dst_capacity, void* hip_stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Section C -- several GPUs (no reference counterpart: sqeazy is a single process with OpenMP loops)
+ *
+ * z-slabs of a volume are independent sqeazy blobs (one encode call per slab, one process per GPU); the only exchange step
+ * of the path is the final gather of the compressed slabs to one rank over RCCL / xGMI.  RCCL is loaded at first use.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* A communicator over `world` ranks, one per GPU (wraps ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy, so that a C caller
+ * needs no RCCL header): rank 0 makes the 128-byte id, hands it to the other ranks by whatever means it has (MPI, a file, a
+ * socket), every rank then calls Comm_Init with its HIP device current. */
+SQY_FUNCTION_PREFIX int SQYAMD_Comm_UniqueId(char* id128);
+SQY_FUNCTION_PREFIX int SQYAMD_Comm_Init(void** comm, int world, int rank, const char* id128);
+SQY_FUNCTION_PREFIX int SQYAMD_Comm_Destroy(void* comm);
+/* Variable-length gather to `root`: every rank passes its blob (device pointer, nbytes); sizes[0..world) (host, out on EVERY rank)
+ * are the blob sizes in rank order -- the index of a sharded container --; the root receives the blobs back to back, in rank order,
+ * at d_recv (blob r at the sum of the sizes in front of it).  One 8-byte all-gather + grouped ncclSend / ncclRecv (point to point
+ * over xGMI) on hip_stream; returns when the bytes have arrived.  A root buffer that is too small makes EVERY rank return 1 (the
+ * ranks agree before anybody sends).  d_recv / recv_capacity are only read on the root. */
+SQY_FUNCTION_PREFIX int SQYAMD_Gather_Blobs(void* comm, int root, const void* d_blob, long nbytes, void* d_recv, long recv_capacity,
+                                            long* sizes, void* hip_stream);
 
 /* per-kernel device timing (hipEvents on the call's stream), for bench.py's roofline line.
  *   enable != 0 starts collecting, Reset clears.  Get: i-th kernel name seen since the last reset

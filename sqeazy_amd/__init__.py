@@ -25,11 +25,13 @@ EXPORTED_SYMBOLS = (
     "SQY_Decompressed_Length", "SQY_Decode_UI16", "SQY_Decode_UI8",
     "SQYAMD_PipelineEncode_UI16_Device", "SQYAMD_PipelineEncode_UI8_Device",
     "SQYAMD_PipelineEncode_UI16_DeviceAt", "SQYAMD_PipelineEncode_UI8_DeviceAt",
+    "SQYAMD_PipelineEncode_UI16_DeviceAt_Frames", "SQYAMD_PipelineEncode_UI8_DeviceAt_Frames",
     "SQYAMD_PipelineEncode_Slabs_UI16_Device", "SQYAMD_PipelineEncode_Slabs_UI8_Device",
     "SQYAMD_PipelineEncode_UI16_Cap", "SQYAMD_PipelineEncode_UI8_Cap",
     "SQYAMD_Decode_UI16_Device", "SQYAMD_Decode_UI8_Device",
     "SQYAMD_Profile_Enable", "SQYAMD_Profile_Reset", "SQYAMD_Profile_Get",
     "SQYAMD_Release_Workspace", "SQYAMD_Version", "SQYAMD_Header_Pipeline", "SQYAMD_Header_Build",
+    "SQYAMD_Comm_UniqueId", "SQYAMD_Comm_Init", "SQYAMD_Comm_Destroy", "SQYAMD_Gather_Blobs",
 )
 
 
@@ -170,6 +172,23 @@ def encode_device_at(pipeline, d_src, shape, dtype, d_dst, dst_capacity, nthread
         pipeline.encode(), ctypes.c_void_p(int(d_src)), _longs(shape), ctypes.c_uint(len(shape)), ctypes.c_void_p(int(d_dst)),
         ctypes.c_long(int(dst_capacity)), ctypes.byref(doff), ctypes.byref(dlen), ctypes.c_int(nthreads), ctypes.c_void_p(stream or 0))
     return rc, doff.value, dlen.value
+
+
+def encode_device_at_frames(pipeline, d_src, shape, dtype, d_dst, dst_capacity, every, nthreads=0, stream=None):
+    """SQYAMD_PipelineEncode_*_DeviceAt_Frames: returns (rc, offset, bytes, frame_offsets) -- frame_offsets[i] = start of LZ4
+    frame i * every relative to the blob start, the last entry is the blob length."""
+    nvox = 1
+    for d in shape:
+        nvox *= int(d)
+    max_entries = nvox * np.dtype(dtype).itemsize // (64 << 10) // max(int(every), 1) + 4
+    fo = (ctypes.c_long * max_entries)()
+    cnt = ctypes.c_int(0)
+    dlen, doff = ctypes.c_long(0), ctypes.c_long(0)
+    rc = getattr(lib(), "SQYAMD_PipelineEncode_%s_DeviceAt_Frames" % _suffix(dtype))(
+        ctypes.c_char_p(pipeline.encode()), ctypes.c_void_p(int(d_src)), _longs(shape), ctypes.c_uint(len(shape)), ctypes.c_void_p(int(d_dst)),
+        ctypes.c_long(int(dst_capacity)), ctypes.byref(doff), ctypes.byref(dlen), ctypes.c_int(nthreads), ctypes.c_void_p(stream or 0),
+        ctypes.c_int(int(every)), fo, ctypes.c_int(max_entries), ctypes.byref(cnt))
+    return rc, doff.value, dlen.value, list(fo[:cnt.value + 1])
 
 
 def encode_slabs_device(pipeline, d_src, shape, dtype, nslabs, d_dst, slab_capacity, nthreads=0, inflight=3):

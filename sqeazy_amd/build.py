@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libsqeazy_amd.so")
-SOURCES = ["sqy_kernels.hip", "sqy_pipeline.cpp", "sqy_capi.cpp"]
+SOURCES = ["sqy_kernels.hip", "sqy_pipeline.cpp", "sqy_capi.cpp", "sqy_rccl.cpp"]
 HEADERS = ["sqy_kernels.h", "sqy_pipeline.hpp", os.path.join("..", "..", "include", "sqeazy_amd.h")]
 ARCH = "gfx950"
 # the one and only configuration of libsqeazy_amd.so; kernel experiments live in tools/ and build their own binaries
@@ -53,7 +53,7 @@ def build(force=False, verbose=False):
             print(" ".join(cmd))
         subprocess.check_call(cmd)
         objs.append(obj)
-    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs
+    cmd = [_hipcc(), "--offload-arch=" + ARCH, "-shared", "-fPIC", "-o", LIB] + objs + ["-ldl"]     # (RCCL is dlopen'ed at first use: sqy_rccl.cpp)
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -278,8 +278,18 @@ bool device_present()
 // *dstoffset says where ("frames in place": a 16-bit bitswap1 in front of lz4 writes the plane stream straight into d_dst as
 // the bodies of the LZ4 frames it will become; the stored frames that end the payload -- the noise planes, 98 % of the bytes of
 // a microscopy stack -- then never move, only the compressed frames in front are gathered up against them).
+// Where every `every`-th LZ4 frame of the payload starts (chunked layout): what a caller needs to re-order byte ranges of slab
+// blobs into one blob (single-blob mode of the multi-GPU path) without walking the frames itself.
+struct FrameQuery {
+    int every = 0;              // 0: not asked for
+    long* offsets = nullptr;    // out, relative to the blob start: frames 0, every, 2 every, ..; then the blob length
+    int max_entries = 0;
+    int count = 0;              // out: frames listed (the end entry comes on top)
+};
+
 int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, const long* shape, unsigned rank, int elem_size,
-                     void* d_dst, uint64_t dst_capacity, long* dstlength, int nthreads, hipStream_t stream, long* dstoffset = nullptr)
+                     void* d_dst, uint64_t dst_capacity, long* dstlength, int nthreads, hipStream_t stream, long* dstoffset = nullptr,
+                     FrameQuery* fq = nullptr)
 {
     if (!pipeline_c || !d_src || !shape || !d_dst || !dstlength) return 1;
     if (dstoffset) *dstoffset = 0;
@@ -716,6 +726,19 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
 
     // ---- header (written after encoding, as the reference rewrites it: dynamic_pipeline.hpp:599-612) ----
     const std::string hdr = sqy::header_pack(elem_size, false, dims, pipe.name(), payload_bytes);
+    if (fq && fq->every > 0) {
+        if (!payload_is_lz4 || lz4_blocks || !fq->offsets) { std::fprintf(stderr, "[sqeazy]\t frame offsets: the payload is not one LZ4 frame per chunk\n"); return 1; }
+        const uint64_t cnt = (lz4_nchunks + (uint64_t)fq->every - 1) / (uint64_t)fq->every;
+        if (cnt + 1 > (uint64_t)std::max(fq->max_entries, 0)) { std::fprintf(stderr, "[sqeazy]\t frame offsets: %llu entries do not fit\n", (unsigned long long)(cnt + 1)); return 1; }
+        std::vector<uint64_t> fo(cnt + 1, 0);
+        if (cnt)
+            SQY_HIP(hipMemcpy2DAsync(fo.data(), sizeof(uint64_t), ws->frame_off.p, (size_t)fq->every * sizeof(uint64_t), sizeof(uint64_t), cnt,
+                                     hipMemcpyDeviceToHost, stream));
+        SQY_HIP(hipStreamSynchronize(stream));
+        for (uint64_t i = 0; i < cnt; ++i) fq->offsets[i] = (long)(fo[i] + hdr.size());
+        fq->offsets[cnt] = (long)(hdr.size() + payload_bytes);
+        fq->count = (int)cnt;
+    }
     const uint64_t blob_bytes = hdr.size() + payload_bytes;
     if (blob_bytes > dst_capacity) {
         std::fprintf(stderr, "[sqeazy]\t destination buffer too small (%llu > %llu bytes)\n", (unsigned long long)blob_bytes,
@@ -1404,6 +1427,40 @@ int SQYAMD_PipelineEncode_UI16_DeviceAt(const char* pipeline, const void* d_src,
     if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
     return encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
                             static_cast<hipStream_t>(hip_stream), dstoffset);
+    });
+}
+
+int SQYAMD_PipelineEncode_UI16_DeviceAt_Frames(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
+                                               long dst_capacity, long* dstoffset, long* dstlength, int nthreads, void* hip_stream, int every,
+                                               long* frame_offsets, int max_entries, int* count)
+{
+    return guarded([&]() -> int {
+    if (!dstoffset || every <= 0 || !frame_offsets || !count) return 1;
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    FrameQuery fq;
+    fq.every = every; fq.offsets = frame_offsets; fq.max_entries = max_entries;
+    const int rc = encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 2, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+                                    static_cast<hipStream_t>(hip_stream), dstoffset, &fq);
+    *count = fq.count;
+    return rc;
+    });
+}
+
+int SQYAMD_PipelineEncode_UI8_DeviceAt_Frames(const char* pipeline, const void* d_src, const long* shape, unsigned shape_size, void* d_dst,
+                                              long dst_capacity, long* dstoffset, long* dstlength, int nthreads, void* hip_stream, int every,
+                                              long* frame_offsets, int max_entries, int* count)
+{
+    return guarded([&]() -> int {
+    if (!dstoffset || every <= 0 || !frame_offsets || !count) return 1;
+    ContextLease lease;
+    if (!lease.ctx) { std::fprintf(stderr, "[sqeazy]\t no usable HIP device\n"); return 1; }
+    FrameQuery fq;
+    fq.every = every; fq.offsets = frame_offsets; fq.max_entries = max_entries;
+    const int rc = encode_on_device(*lease.ctx, pipeline, d_src, shape, shape_size, 1, d_dst, (uint64_t)std::max(dst_capacity, 0l), dstlength, nthreads,
+                                    static_cast<hipStream_t>(hip_stream), dstoffset, &fq);
+    *count = fq.count;
+    return rc;
     });
 }
 

@@ -47,10 +47,13 @@ def gather_blobs(blob, nbytes, dst_buffer=None, group=None, root=0):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
+    # one all_gather, one read-back (nbytes < 0 is the poison value of a rank that failed earlier: every rank raises together)
     size_t = torch.tensor([int(nbytes)], dtype=torch.int64, device=blob.device)
-    sizes_t = [torch.zeros(1, dtype=torch.int64, device=blob.device) for _ in range(world)]
-    dist.all_gather(sizes_t, size_t, group=group)
-    sizes = [int(s.item()) for s in sizes_t]
+    sizes_t = torch.zeros(world, dtype=torch.int64, device=blob.device)
+    dist.all_gather_into_tensor(sizes_t, size_t, group=group)
+    sizes = [int(v) for v in sizes_t.tolist()]
+    if min(sizes) < 0:
+        raise RuntimeError("rank %d reported a failed encode / gather: no blobs are exchanged" % sizes.index(min(sizes)))
     if world == 1:
         return sizes, blob[:nbytes]
     if rank == root:
@@ -93,6 +96,7 @@ class SlabGatherer:
         self.done = 0                    # gathers completed
         self.last = None                 # (sizes, flat view into one of the ingress buffers) of the newest completed gather, on root
         self.error = None
+        self._poisoned = False
         self._q = queue.Queue()
         self._t = threading.Thread(target=self._run, daemon=True)
         self._t.start()
@@ -107,11 +111,15 @@ class SlabGatherer:
                 if item is None:
                     return
                 blob, nbytes, on_done = item
-                if self.error is None:
-                    try:
-                        dst = self.bufs[self.done % len(self.bufs)] if self.is_root else None
-                        self.last = gather_blobs(blob, nbytes, dst_buffer=dst, group=self.group, root=self.root)
-                    except Exception as e:      # pragma: no cover
+                # a rank that failed keeps taking part in the size exchange with the poison value -1: its peers then raise in the
+                # same gather instead of waiting for sends that never come (until the RCCL time-out)
+                try:
+                    dst = self.bufs[self.done % len(self.bufs)] if self.is_root else None
+                    res = gather_blobs(blob, nbytes if self.error is None else -1, dst_buffer=dst, group=self.group, root=self.root)
+                    if self.error is None:
+                        self.last = res
+                except Exception as e:
+                    if self.error is None:
                         self.error = e
                 self.done += 1
                 if on_done is not None:
@@ -120,7 +128,15 @@ class SlabGatherer:
                 self._q.task_done()
 
     def post(self, blob, nbytes, on_done=None):
-        """queue `blob[:nbytes]` (must stay untouched until on_done runs) for the gather; returns at once"""
+        """queue `blob[:nbytes]` (must stay untouched until on_done runs) for the gather; returns at once.
+        Raises what an earlier gather hit (on every rank: see _run), after which nothing more is queued."""
+        if self.error is not None:
+            # the peers post in step with this rank: its next gather still takes place, with the poison size, so that they
+            # raise there as well; nothing is queued after that
+            if not self._poisoned:
+                self._poisoned = True
+                self._q.put((blob, -1, on_done))
+            raise self.error
         self._q.put((blob, int(nbytes), on_done))
 
     def drain(self):
@@ -267,29 +283,45 @@ def assemble_single_blob(shape, dtype, slab_blobs, ranges, pipeline=SINGLE_BLOB_
     return out
 
 
-def gather_single_blob(blob, nbytes, shape, dtype, group=None, root=0, pipeline=SINGLE_BLOB_PIPELINE):
+def plane_ranges_from_frame_offsets(frame_offsets, planes):
+    """(header bytes, [(offset, length) per bit plane]) from the table SQYAMD_PipelineEncode_*_DeviceAt_Frames returns with
+    every = chunks per bit plane: frame_offsets[p] = start of plane p's first frame, the last entry = blob length"""
+    fo = [int(v) for v in frame_offsets]
+    if len(fo) != planes + 1:
+        raise ValueError("%d frame offsets where %d planes + 1 were expected" % (len(fo), planes))
+    return fo[0], [(fo[p], fo[p + 1] - fo[p]) for p in range(planes)]
+
+
+def gather_single_blob(blob, nbytes, shape, dtype, group=None, root=0, pipeline=SINGLE_BLOB_PIPELINE, frame_offsets=None):
     """Every rank passes the blob of ITS slab (slab_range of shape[0]); `root` gets the single blob of the whole volume
     (uint8 tensor on its device), everybody else None.  Exchange: one all_gather of 1 + W plane sizes, then the
-    variable-length gather of the slab blobs (compressed bytes only)."""
+    variable-length gather of the slab blobs (compressed bytes only).
+    frame_offsets: what sqeazy_amd.encode_device_at_frames(..., every = chunks per bit plane) returned for this slab -- the plane
+    ranges then come from the encoder's own frame table in HBM (W + 1 integers).  Without it the blob is copied to the host and
+    its LZ4 frames are walked there (CPU tests, blobs from elsewhere)."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     rank = dist.get_rank(group)
     if not single_blob_possible(shape, dtype, world):
-        raise ValueError("slabs of %r over %d ranks are not whole LZ4 chunks per bit plane" % (list(shape), world))
+        raise ValueError("slabs of %r over %d ranks are not whole LZ4 chunks per bit plane (or the volume has 2^31 or more voxels)" % (list(shape), world))
     _, nz = slab_range(shape[0], rank, world)
     W = np.dtype(dtype).itemsize * 8
-    hdr, rr = plane_ranges(blob[:nbytes].cpu().numpy().tobytes(), (nz, shape[1], shape[2]), dtype)
+    if frame_offsets is not None:
+        hdr, rr = plane_ranges_from_frame_offsets(frame_offsets, W)
+    else:
+        hdr, rr = plane_ranges(blob[:nbytes].cpu().numpy().tobytes(), (nz, shape[1], shape[2]), dtype)
     mine = torch.tensor([hdr] + [v for pr in rr for v in pr], dtype=torch.int64, device=blob.device)
-    table = [torch.zeros_like(mine) for _ in range(world)]
-    dist.all_gather(table, mine, group=group)
+    table_t = torch.zeros(world * mine.numel(), dtype=torch.int64, device=blob.device)
+    dist.all_gather_into_tensor(table_t, mine, group=group)
     sizes, flat = gather_blobs(blob, nbytes, group=group, root=root)
     if rank != root:
         return None
+    table = np.asarray(table_t.tolist(), dtype=np.int64).reshape(world, -1)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     blobs, ranges = [], []
     for r in range(world):
-        t = [int(v) for v in table[r].tolist()]
+        t = [int(v) for v in table[r]]
         blobs.append(flat[int(offs[r]):int(offs[r + 1])])
         ranges.append([(t[1 + 2 * p], t[2 + 2 * p]) for p in range(W)])
     return assemble_single_blob(shape, dtype, blobs, ranges, pipeline)

@@ -223,3 +223,56 @@ def test_overlapped_gather_diff_pipeline(world):
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(world)], res
+
+
+def _worker_gatherer_failure(rank, world, port, q):
+    """one rank's encode fails between two steps: its next post still takes part in the size exchange (poison value), so that
+    EVERY rank raises in that gather instead of waiting for sends that never come"""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from sqeazy_amd import multi
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = multi.SlabGatherer(world * 64, torch.device("cpu"))
+        t = torch.arange(64, dtype=torch.uint8)
+        g.post(t, 10 + rank)
+        g.drain()
+        if rank == 0:
+            assert g.last[0] == [10 + r for r in range(world)]
+        raised = []
+        if rank == world - 1:
+            g.error = RuntimeError("encode of step 1 failed on rank %d" % rank)        # what a failed C-ABI call leaves behind
+        try:
+            g.post(t, 20)
+        except RuntimeError as e:
+            raised.append("post: %s" % e)
+        try:
+            g.drain()
+        except RuntimeError as e:
+            raised.append("drain: %s" % e)
+        g.close()
+        assert raised, "rank %d did not learn of the failure" % rank
+        if rank != world - 1:
+            assert "rank %d reported a failed" % (world - 1) in raised[0], raised
+        q.put((rank, "ok"))
+    except Exception as e:   # pragma: no cover
+        q.put((rank, repr(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gatherer_failure_reaches_every_rank():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_gatherer_failure, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(r, "ok") for r in range(3)], res
