@@ -235,6 +235,31 @@ int sqo_diff3x3x1_decode_u8(const uint8_t* in, uint8_t* out, const size_t shape[
 #undef BODY_STORE
 }
 
+/* diff3x3x1 as a TAIL filter: the sink's output type is `char` (sqeazy_pipelines.hpp:64-77), i.e. T = char, signed on x86.
+ * naive_sum accumulates in `char` (wraps), and sum_type = add_unsigned<twice_as_wide<char>>::type = unsigned short
+ * (diff_scheme_impl.hpp:24, traits.hpp:29): the char sum is SIGN-EXTENDED into the unsigned short before the division by 9
+ * (a sum of -5 divides as 65531).  Bytes in, bytes out here; everything else as the 8-bit head filter above. */
+#undef SQO_DIFF_PARALLEL
+#define SQO_DIFF_PARALLEL 1
+int sqo_diff3x3x1_encode_i8(const uint8_t* in, uint8_t* out, const size_t shape[3])
+{
+    if (shape[0] > 127 || shape[1] > 127 || shape[2] > 127) return 1;
+    const uint8_t* src = in;
+#define BODY_STORE out[idx] = (uint8_t)((unsigned)(int)(int8_t)in[idx] - (unsigned)(unsigned short)(short)(int8_t)local_sum / 9u);
+    SQO_DIFF_BODY(uint8_t, int8_t, unsigned short)
+#undef BODY_STORE
+}
+#undef SQO_DIFF_PARALLEL
+#define SQO_DIFF_PARALLEL 0
+int sqo_diff3x3x1_decode_i8(const uint8_t* in, uint8_t* out, const size_t shape[3])
+{
+    if (shape[0] > 127 || shape[1] > 127 || shape[2] > 127) return 1;
+    const uint8_t* src = out;
+#define BODY_STORE out[idx] = (uint8_t)((unsigned)(int)(int8_t)in[idx] + (unsigned)(unsigned short)(short)(int8_t)local_sum / 9u);
+    SQO_DIFF_BODY(uint8_t, int8_t, unsigned short)
+#undef BODY_STORE
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* LZ4 block compressor -- liblz4 1.9.3, LZ4_compress_generic(byU32, limitedOutput, accel 1)   */
 /* as reached from LZ4F_compressUpdate -> LZ4F_makeBlock -> LZ4_compress_fast_continue on a    */

@@ -36,6 +36,9 @@ int sqo_diff3x3x1_encode_u16(const uint16_t* in, uint16_t* out, const size_t sha
 int sqo_diff3x3x1_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3]);
 int sqo_diff3x3x1_decode_u16(const uint16_t* in, uint16_t* out, const size_t shape[3]);
 int sqo_diff3x3x1_decode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3]);
+/* tail filter forms on `char` (signed): bytes in, bytes out */
+int sqo_diff3x3x1_encode_i8(const uint8_t* in, uint8_t* out, const size_t shape[3]);
+int sqo_diff3x3x1_decode_i8(const uint8_t* in, uint8_t* out, const size_t shape[3]);
 /* number of row offsets the reference's halo::compute_offsets_in_x yields, and the i-th one */
 size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, size_t* halo_size_x);
 
@@ -76,6 +79,7 @@ int sqo_frame_shuffle_encode_u16(const uint16_t* in, uint16_t* out, const size_t
 /* raster_reorder (raster_reorder_utils.hpp:36-367); -1 for the geometries the reference leaves undefined */
 int sqo_raster_reorder(const void* in, void* out, const size_t shape[3], size_t tile_size, int elem_size, int decode);
 int sqo_frame_shuffle_encode_u8(const uint8_t* in, uint8_t* out, const size_t shape[3], uint64_t* decode_map);
+int sqo_frame_shuffle_encode_i8(const int8_t* in, int8_t* out, const size_t shape[3], uint64_t* decode_map);
 
 /* ---- base64 : base64.hpp:135-162 (RFC 4648, '=' padded) ---- */
 size_t sqo_base64_encode(const uint8_t* src, size_t n, char* dst);

@@ -120,12 +120,15 @@ def _shape3(shape):
     return (ctypes.c_size_t * 3)(*[int(s) for s in shape])
 
 
-def diff3x3x1_encode(a):
+def diff3x3x1_encode(a, char=False):
+    """char=True: the tail filter form on the sink's `char` output (signed bytes: the sum is sign-extended before the division)"""
     a = np.ascontiguousarray(a)
     if a.ndim != 3:
         raise ValueError("diff3x3x1 needs a 3D shape (diff_scheme_impl.hpp:84-87)")
     out = np.empty_like(a)
-    if a.dtype == np.uint16:
+    if char:
+        rc = lib().sqo_diff3x3x1_encode_i8(_ptr(a.view(np.uint8), _u8p), _ptr(out.view(np.uint8), _u8p), _shape3(a.shape))
+    elif a.dtype == np.uint16:
         rc = lib().sqo_diff3x3x1_encode_u16(_ptr(a, _u16p), _ptr(out, _u16p), _shape3(a.shape))
     else:
         rc = lib().sqo_diff3x3x1_encode_u8(_ptr(a, _u8p), _ptr(out, _u8p), _shape3(a.shape))
@@ -134,10 +137,12 @@ def diff3x3x1_encode(a):
     return out
 
 
-def diff3x3x1_decode(a):
+def diff3x3x1_decode(a, char=False):
     a = np.ascontiguousarray(a)
     out = np.empty_like(a)
-    if a.dtype == np.uint16:
+    if char:
+        rc = lib().sqo_diff3x3x1_decode_i8(_ptr(a.view(np.uint8), _u8p), _ptr(out.view(np.uint8), _u8p), _shape3(a.shape))
+    elif a.dtype == np.uint16:
         rc = lib().sqo_diff3x3x1_decode_u16(_ptr(a, _u16p), _ptr(out, _u16p), _shape3(a.shape))
     else:
         rc = lib().sqo_diff3x3x1_decode_u8(_ptr(a, _u8p), _ptr(out, _u8p), _shape3(a.shape))
@@ -511,13 +516,18 @@ def bitshuffle(a, block_size=0, decode=False):
     return out.view(a.dtype).reshape(a.shape)
 
 
-def frame_shuffle_encode(a):
+def frame_shuffle_encode(a, char=False):
+    """char=True: the tail filter form (frames of signed bytes: the metric sums values from -128 to 127)"""
     a = np.ascontiguousarray(a)
     if a.ndim != 3:
         raise ValueError("frame_shuffle needs a 3D shape")
     out = np.empty_like(a)
     dmap = np.zeros(a.shape[0], dtype=np.uint64)
-    if a.dtype == np.uint16:
+    if char:
+        i8p = ctypes.POINTER(ctypes.c_int8)
+        rc = lib().sqo_frame_shuffle_encode_i8(a.view(np.int8).ctypes.data_as(i8p), out.view(np.int8).ctypes.data_as(i8p),
+                                               _shape3(a.shape), _ptr(dmap, _u64p))
+    elif a.dtype == np.uint16:
         rc = lib().sqo_frame_shuffle_encode_u16(_ptr(a, _u16p), _ptr(out, _u16p), _shape3(a.shape), _ptr(dmap, _u64p))
     else:
         rc = lib().sqo_frame_shuffle_encode_u8(_ptr(a.view(np.uint8), _u8p), _ptr(out.view(np.uint8), _u8p),
@@ -811,11 +821,15 @@ def pipeline_encode(pipeline, vol, nthreads=2):
         if s.name == "bitswap1":
             cur = bitswap1_encode(cur)
         elif s.name == "diff3x3x1":
-            if cur.dtype == np.int8 or (seen_sink and cur.dtype == np.uint8):
-                raise NotImplementedError("diff3x3x1 on char is not restated")
-            cur = diff3x3x1_encode(cur)
+            # behind a sink the stream is `char`; it keeps the volume's shape only when the sink wrote one byte per voxel
+            # (dynamic_pipeline.hpp:658-666: otherwise {1, 1, bytes}, which diff3x3x1 cannot take)
+            if seen_sink and cur.shape != vol.shape:
+                raise ValueError("diff3x3x1: shape outside the reference's defined behaviour")
+            cur = diff3x3x1_encode(cur, char=seen_sink)
         elif s.name == "frame_shuffle":
-            cur, dmap = frame_shuffle_encode(cur)
+            if seen_sink and cur.shape != vol.shape:
+                cur = cur.reshape(1, 1, -1)
+            cur, dmap = frame_shuffle_encode(cur, char=seen_sink)
             s.map = to_verbatim(dmap)
         elif s.name == "raster_reorder":
             if seen_sink:
@@ -880,7 +894,10 @@ def pipeline_decode(blob):
             t = np.uint8 if after_sink else dtype
             cur = bitswap1_decode(np.ascontiguousarray(cur).view(t))
         elif s.name == "diff3x3x1":
-            cur = diff3x3x1_decode(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]))
+            if after_sink:
+                cur = diff3x3x1_decode(np.ascontiguousarray(cur).view(np.uint8).reshape(h["shape"]), char=True)
+            else:
+                cur = diff3x3x1_decode(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]))
         elif s.name == "quantiser":
             import base64
             if "decode_lut_path" in s.cmap:                    # quantiser_scheme_impl.hpp:83-85 (constructor): the file wins
@@ -908,7 +925,11 @@ def pipeline_decode(blob):
             import base64
             m = s.map[len("<verbatim>"):-len("</verbatim>")]
             dmap = np.frombuffer(base64.b64decode(m), dtype=np.uint64)
-            v = np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
+            if after_sink:
+                v = np.ascontiguousarray(cur).view(np.uint8)
+                v = v.reshape(h["shape"]) if v.size == n else v.reshape(1, 1, -1)
+            else:
+                v = np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
             out = np.empty_like(v)
             out[dmap.astype(np.int64)] = v
             cur = out

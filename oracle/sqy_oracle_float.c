@@ -169,3 +169,9 @@ int sqo_frame_shuffle_encode_u8(const uint8_t* in, uint8_t* out, const size_t sh
 {
     SQO_FRAME_SHUFFLE_BODY(uint8_t)
 }
+
+/* frame_shuffle as a TAIL filter (T = char, signed on x86: the bytes of a sink's output count from -128 to 127) */
+int sqo_frame_shuffle_encode_i8(const int8_t* in, int8_t* out, const size_t shape[3], uint64_t* decode_map)
+{
+    SQO_FRAME_SHUFFLE_BODY(int8_t)
+}

@@ -509,7 +509,11 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     std::fprintf(stderr, "[diff_scheme] unable to process input data that is not 3D\n");
                     return 1;
                 }
-                const uint64_t Z = dims[0], Y = dims[1], X = dims[2];
+                // as a tail filter the stream is the sink's `char` output: the volume's shape when that is one byte per voxel, else
+                // {1, 1, bytes} (dynamic_pipeline.hpp:658-666), which the stage cannot take
+                const bool tail = pipe.sink_index >= 0 && (int)si > pipe.sink_index;
+                const bool flat = tail && cur_len * (uint64_t)cur_elem != len;
+                const uint64_t Z = flat ? 1 : dims[0], Y = flat ? 1 : dims[1], X = flat ? cur_len : dims[2];
                 if ((int64_t)(X - 1) * (int64_t)(Y - 2) <= 1 || Y < 3 || X < 2) {
                     std::fprintf(stderr, "[sqeazy]\t diff3x3x1: shape %llux%llux%llu reads out of bounds in the reference; refused\n",
                                  (unsigned long long)Z, (unsigned long long)Y, (unsigned long long)X);
@@ -522,7 +526,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
                 ProfScope ps("diff3x3x1", stream, pend);
-                SQY_HIP(sqy::launch_diff3x3x1(cur, out, Z, Y, X, cur_elem, stream));
+                SQY_HIP(sqy::launch_diff3x3x1(cur, out, Z, Y, X, cur_elem, stream, tail));
                 cur = out;
                 break;
             }
@@ -531,7 +535,10 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     std::fprintf(stderr, "[sqeazy::detail::frame_shuffle::encode] received non-3D shape which is currently unsupported!\n");
                     return 1;
                 }
-                const uint64_t Z = dims[0], per_frame = dims[1] * dims[2];
+                // (tail filter: signed bytes; ONE frame {1, 1, bytes} when the sink did not write one byte per voxel)
+                const bool tail = pipe.sink_index >= 0 && (int)si > pipe.sink_index;
+                const bool flat = tail && cur_len * (uint64_t)cur_elem != len;
+                const uint64_t Z = flat ? 1 : dims[0], per_frame = flat ? cur_len : dims[1] * dims[2];
                 if (ws->small.ensure(std::max<uint64_t>(Z * 16, 4096))) return 1;
                 float* d_sums = static_cast<float*>(ws->small.p);
                 uint64_t* d_map = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(ws->small.p) + ((Z * 4 + 15) & ~(uint64_t)15));
@@ -539,7 +546,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     const uint64_t fm_bytes = sqy::frame_metric_scratch_bytes(Z, per_frame, cur_elem);
                     if (ws->lz4_scratch.ensure(std::max<uint64_t>(fm_bytes, 16))) return 1;      // free until the sink runs
                     ProfScope ps("frame_metric", stream, pend);
-                    SQY_HIP(sqy::launch_frame_metric(cur, Z, per_frame, cur_elem, d_sums, stream, ws->lz4_scratch.p, fm_bytes));
+                    SQY_HIP(sqy::launch_frame_metric(cur, Z, per_frame, cur_elem, d_sums, stream, ws->lz4_scratch.p, fm_bytes, tail));
                 }
                 std::vector<float> sums(Z);
                 std::vector<uint64_t> map(Z);
@@ -1142,11 +1149,15 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
             }
             case StageKind::diff3x3x1: {
                 if (h.shape.size() != 3) return 1;
+                // as a tail filter (behind the sink) the stream is `char` and has the volume's shape only when the sink wrote one
+                // byte per voxel (dynamic_pipeline.hpp:658-666); anything else the encoder refused
+                const bool tail = sink_index >= 0 && (int)si > sink_index;
+                if (tail && (n_in != n || e_in != 1)) return stage_error(si);
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 if (ws->lz4_scratch.ensure(sqy::diff3x3x1_decode_scratch_bytes(h.shape[2]))) return 1;
                 ProfScope ps("diff3x3x1_decode", stream, pend);
-                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, ws->lz4_scratch.p, stream));
+                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, ws->lz4_scratch.p, stream, tail));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }
@@ -1165,7 +1176,10 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
             case StageKind::frame_shuffle: {
                 if (h.shape.size() != 3) return 1;
                 auto it = st.cfg.find("reorder_map");
-                const uint64_t Z = h.shape[0];
+                // (as a tail filter behind a sink that did not write one byte per voxel the stream is ONE frame: {1, 1, bytes})
+                const bool one_frame = sink_index >= 0 && (int)si > sink_index && n_in != n;
+                const uint64_t Z = one_frame ? 1 : h.shape[0];
+                const uint64_t frame_bytes_dec = one_frame ? stage_in_bytes : h.shape[1] * h.shape[2] * (uint64_t)e_in;
                 if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: no reorder_map in the header\n"); return 1; }
                 const std::vector<unsigned char> mapb = sqy::base64_decode(it->second.substr(10, it->second.size() - 21));
                 if (mapb.size() != Z * 8) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: malformed reorder_map\n"); return 1; }
@@ -1179,7 +1193,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (!out) return 1;
                 {
                     ProfScope ps("frame_scatter", stream, pend);
-                    SQY_HIP(sqy::launch_frame_scatter(cur, out, Z, h.shape[1] * h.shape[2] * (uint64_t)e_in, static_cast<const uint64_t*>(ws->small.p), stream));
+                    SQY_HIP(sqy::launch_frame_scatter(cur, out, Z, frame_bytes_dec, static_cast<const uint64_t*>(ws->small.p), stream));
                 }
                 SQY_HIP(hipStreamSynchronize(stream));
                 cur = out; cur_bytes = stage_in_bytes;

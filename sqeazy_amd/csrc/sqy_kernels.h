@@ -25,7 +25,9 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
 
 // diff3x3x1 on a {Z,Y,X} volume of 1- or 2-byte unsigned voxels (encoders/diff_scheme_impl.hpp:78-139)
-hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream);
+// schar (8-bit only): the stage as a tail filter on the sink's `char` output -- signed bytes, the sum sign-extended before the division
+hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream,
+                            bool schar = false);
 
 // LZ4: every `chunk` bytes of in[0,total) compressed on its own into scratch + k*stride (capacity chunk-1);
 // csize[k] = compressed bytes, 0 when the chunk has to be stored raw.
@@ -88,8 +90,9 @@ hipError_t launch_raster_reorder(const void* in, void* out, uint64_t Z, uint64_t
 hipError_t launch_bitshuffle(const void* in, void* out, uint64_t n_elems, int elem_size, uint64_t block_elems, bool decode, hipStream_t stream);
 
 // frame_shuffle: per-frame mean in the reference's sequential binary32 order; frame gather out[i] = in[map[i]]
+// schar (8-bit only): frames of signed bytes (the stage as a tail filter)
 hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream,
-                               void* scratch = nullptr, uint64_t scratch_bytes = 0);
+                               void* scratch = nullptr, uint64_t scratch_bytes = 0, bool schar = false);
 // scratch that lets long frames take the block-parallel path (16 bytes per 4 KiB block)
 uint64_t frame_metric_scratch_bytes(uint64_t Z, uint64_t per_frame, int elem_size);
 hipError_t launch_frame_gather(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
@@ -115,7 +118,7 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
 // synchronises the stream when the one-launch kernel is used
 uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X);
 hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
-                                   hipStream_t stream);
+                                   hipStream_t stream, bool schar = false);
 hipError_t launch_quantiser_decode(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
 hipError_t launch_frame_scatter(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
 

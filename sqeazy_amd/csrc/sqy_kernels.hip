@@ -381,7 +381,10 @@ __device__ __forceinline__ bool diff_touched(uint64_t idx, uint64_t length, uint
     return idx - s < reach;
 }
 
-template <typename T, typename ST>
+// SCHAR: the stage as a TAIL filter on the sink's `char` output (src/sqeazy_pipelines.hpp:64-77; char is signed): the wrapping
+// 8-bit sum is SIGN-EXTENDED into the reference's unsigned short sum_type (diff_scheme_impl.hpp:24, traits.hpp:29) before the
+// division -- a sum of -5 divides as 65531.
+template <typename T, typename ST, bool SCHAR = false>
 __global__ __launch_bounds__(256)
 void diff3x3x1_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t Z, uint64_t Y, uint64_t X,
                       uint64_t hx, uint64_t zlim, int single)
@@ -396,8 +399,7 @@ void diff3x3x1_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t Z,
             sum = (T)(sum + p[-(int64_t)X - 1]); sum = (T)(sum + p[-(int64_t)X]); sum = (T)(sum + p[-(int64_t)X + 1]);
             sum = (T)(sum + p[-1]);              sum = (T)(sum + p[0]);           sum = (T)(sum + p[1]);
             sum = (T)(sum + p[X - 1]);           sum = (T)(sum + p[X]);           sum = (T)(sum + p[X + 1]);
-            // 8-bit: sum_type = unsigned short of a `char`-typed... the C-ABI only feeds unsigned pixel types here
-            const uint32_t mean = (uint32_t)sum / 9u;
+            const uint32_t mean = SCHAR ? (uint32_t)(uint16_t)(int16_t)(int8_t)sum / 9u : (uint32_t)sum / 9u;
             v = (T)(ST)((uint32_t)v - mean);
         }
         out[idx] = v;
@@ -1905,6 +1907,36 @@ void frame_metric_kernel(const T* __restrict__ in, uint64_t Z, uint64_t per_fram
     metric[z] = sum;                           // the division by Y*X happens on the host (sqy::frame_shuffle_order)
 }
 
+// frames of SIGNED bytes (frame_shuffle as a tail filter on the sink's `char` output): the running sum is not monotone, the
+// block-parallel evaluation below does not apply -- one lane adds one frame in index order
+__global__ __launch_bounds__(64)
+void frame_metric_i8_kernel(const int8_t* __restrict__ in, uint64_t Z, uint64_t per_frame, float* __restrict__ metric)
+{
+    const uint64_t z = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (z >= Z) return;
+    const int8_t* __restrict__ p = in + z * per_frame;
+    float sum = 0.f;
+    uint64_t i = 0;
+    if ((reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+        const uint4* pv = reinterpret_cast<const uint4*>(p);
+        const uint64_t nv = per_frame / 16;
+        for (uint64_t v = 0; v < nv; ++v) {
+            const uint4 x = pv[v];
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                sum = sum + (float)(int8_t)(w[j] & 0xffu);
+                sum = sum + (float)(int8_t)((w[j] >> 8) & 0xffu);
+                sum = sum + (float)(int8_t)((w[j] >> 16) & 0xffu);
+                sum = sum + (float)(int8_t)(w[j] >> 24);
+            }
+        }
+        i = nv * 16;
+    }
+    for (; i < per_frame; ++i) sum = sum + (float)p[i];
+    metric[z] = sum;
+}
+
 // Block-parallel EXACT evaluation of the same sequential binary32 sum.
 // While the running sum S (an integer) stays inside one binade [2^e, 2^(e+1)) with ulp u = 2^(e-23) >= 2, adding an
 // integer v rounds S+v to a multiple of u (ties to the even multiple).  With r = v mod u, d = v div u and p = parity of
@@ -3151,7 +3183,7 @@ void bitswap1_decode_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restr
 // i.e. indices idx - frame - X - 1 .. idx - frame + X + 1.  Those lie in frame z-1 -- except for the last X + 1 voxels of a
 // frame, whose lower neighbours are the first voxels of frame z itself (they are rewritten only in geometries whose rows' reach
 // spills over the row end: Z - 2 > X - 1, or the single-row case).  The launcher therefore decodes such frames in two steps.
-template <typename T, typename ST>
+template <typename T, typename ST, bool SCHAR = false>
 __global__ __launch_bounds__(256)
 void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t z, uint64_t length, uint64_t Y, uint64_t X,
                                    uint64_t hx, uint64_t zlim, int single, uint64_t r0, uint64_t r1)
@@ -3167,7 +3199,7 @@ void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out
         sum = (T)(sum + p[-(int64_t)X - 1]); sum = (T)(sum + p[-(int64_t)X]); sum = (T)(sum + p[-(int64_t)X + 1]);
         sum = (T)(sum + p[-1]);              sum = (T)(sum + p[0]);           sum = (T)(sum + p[1]);
         sum = (T)(sum + p[X - 1]);           sum = (T)(sum + p[X]);           sum = (T)(sum + p[X + 1]);
-        v = (T)((uint32_t)(int32_t)(ST)v + (uint32_t)sum / 9u);
+        v = (T)((uint32_t)(int32_t)(ST)v + (SCHAR ? (uint32_t)(uint16_t)(int16_t)(int8_t)sum / 9u : (uint32_t)sum / 9u));
     }
     out[idx] = v;
 }
@@ -3554,7 +3586,7 @@ hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hip
     return hipGetLastError();
 }
 
-hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream)
+hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream, bool schar)
 {
     // geometry of the reference's halo (neighborhood_utils.hpp:160-240), see the kernel header comment
     const uint64_t length = Z * Y * X;
@@ -3575,6 +3607,9 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
     if (elem_size == 2)
         hipLaunchKernelGGL((diff3x3x1_kernel<uint16_t, int16_t>), dim3((unsigned)blocks), dim3(256), 0, stream,
                            (const uint16_t*)in, (uint16_t*)out, Z, Y, X, hx, zlim, single);
+    else if (schar)
+        hipLaunchKernelGGL((diff3x3x1_kernel<uint8_t, int8_t, true>), dim3((unsigned)blocks), dim3(256), 0, stream,
+                           (const uint8_t*)in, (uint8_t*)out, Z, Y, X, hx, zlim, single);
     else
         hipLaunchKernelGGL((diff3x3x1_kernel<uint8_t, int8_t>), dim3((unsigned)blocks), dim3(256), 0, stream,
                            (const uint8_t*)in, (uint8_t*)out, Z, Y, X, hx, zlim, single);
@@ -3695,9 +3730,14 @@ uint64_t frame_metric_scratch_bytes(uint64_t Z, uint64_t per_frame, int elem_siz
 }
 
 hipError_t launch_frame_metric(const void* in, uint64_t Z, uint64_t per_frame, int elem_size, float* metric, hipStream_t stream,
-                               void* scratch, uint64_t scratch_bytes)
+                               void* scratch, uint64_t scratch_bytes, bool schar)
 {
     if (Z == 0) return hipSuccess;
+    if (schar) {
+        if (elem_size != 1) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(frame_metric_i8_kernel, dim3((unsigned)((Z + 63) / 64)), dim3(64), 0, stream, (const int8_t*)in, Z, per_frame, metric);
+        return hipGetLastError();
+    }
     const bool vector_ok = (per_frame * (uint64_t)elem_size) % 16 == 0 && (reinterpret_cast<uintptr_t>(in) & 15) == 0 && Z <= 0x7fffffffull &&
                            per_frame * (elem_size == 2 ? 65535ull : 255ull) < (1ull << 39);
     const uint64_t blk = 4096 / (uint64_t)elem_size;
@@ -3918,7 +3958,7 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
 uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X) { return DIFFDEC_MAX_STRIPS * 4 * ((X + 2) / 3) * 8 + 64; }
 
 hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
-                                   hipStream_t stream)
+                                   hipStream_t stream, bool schar)
 {
     const uint64_t length = Z * Y * X, frame = Y * X;
     if (length == 0) return hipSuccess;
@@ -3991,6 +4031,9 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
             if (elem_size == 2)
                 hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint16_t, int16_t>), dim3(blocks), dim3(256), 0, stream, (const uint16_t*)in,
                                    (uint16_t*)out, z, length, Y, X, hx, zlim, single, r0, r1);
+            else if (schar)
+                hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint8_t, int8_t, true>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)in,
+                                   (uint8_t*)out, z, length, Y, X, hx, zlim, single, r0, r1);
             else
                 hipLaunchKernelGGL((diff3x3x1_decode_plane_kernel<uint8_t, int8_t>), dim3(blocks), dim3(256), 0, stream, (const uint8_t*)in,
                                    (uint8_t*)out, z, length, Y, X, hx, zlim, single, r0, r1);

@@ -412,10 +412,8 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
         switch (st.kind) {
             case StageKind::bitswap1: break;
             case StageKind::diff3x3x1:
-                if (after_sink) return fail("diff3x3x1 as a tail filter (on char) is not implemented on MI355X");
-                break;
+                break;                                                           // (head filter, or tail filter on the sink's char output)
             case StageKind::frame_shuffle: {
-                if (after_sink) return fail("frame_shuffle as a tail filter is not implemented on MI355X");
                 auto c = st.cfg.find("frame_chunk_size");
                 if (c != st.cfg.end() && std::atoi(c->second.c_str()) != 1)
                     return fail("frame_shuffle: only frame_chunk_size=1 is implemented on MI355X");
