@@ -349,6 +349,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     // frames in place: chunk k of the plane stream sits at d_dst + inplace_t0 + 11 + k * lz4_in_stride
     bool lz4_inplace = false;
     uint64_t lz4_in_stride = 0, inplace_t0 = 0;
+    // diff3x3x1 directly in front of a 16-bit bitswap1: only the columns the stage can touch are computed (compact side buffer)
+    const uint16_t* bsw_side = nullptr;
+    uint32_t bsw_side_w = 0, bsw_side_X = 0;
     uint64_t* lz4_tail_info = nullptr;
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
@@ -392,7 +395,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
                 if (cur_elem == 2)
                     SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream, ph,
-                                                     (uint32_t)gap_chunk));
+                                                     (uint32_t)gap_chunk, bsw_side, bsw_side_w, bsw_side_X));
                 else
                     SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
                 cur = out;
@@ -522,6 +525,21 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 if (cur_elem == 1 && (Z > 127 || Y > 127 || X > 127)) {
                     std::fprintf(stderr, "[sqeazy]\t diff3x3x1 on 8-bit voxels: extents > 127 overflow the reference's char coordinates; refused\n");
                     return 1;
+                }
+                {
+                    const uint32_t sw = (!tail && si + 1 < pipe.stages.size() && pipe.stages[si + 1].kind == StageKind::bitswap1 &&
+                                         (reinterpret_cast<uintptr_t>(cur) & 15) == 0)
+                                            ? sqy::diff3x3x1_side_width(Z, Y, X, cur_elem) : 0;
+                    if (sw) {
+                        uint8_t* side = next_buf(Z * Y * (uint64_t)sw * 2);
+                        if (!side) return 1;
+                        ProfScope ps("diff3x3x1", stream, pend);
+                        SQY_HIP(sqy::launch_diff3x3x1_side(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(side), Z, Y, X, sw, stream));
+                        bsw_side = reinterpret_cast<const uint16_t*>(side);
+                        bsw_side_w = sw;
+                        bsw_side_X = (uint32_t)X;
+                        break;                                              // (`cur` stays the stage's input: the transpose reads both)
+                    }
                 }
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;

@@ -13,8 +13,9 @@ namespace sqy {
 // gap_chunk != 0 ("frames in place", see launch_lz4_tail_marks): the plane stream is written as the bodies of the LZ4 frames it
 // will be cut into -- chunk k (gap_chunk bytes, a power of two) at out + k * (gap_chunk + 15), `out` any alignment; needs
 // len % 8192 == 0
+// side != nullptr (launch_diff3x3x1_side): columns x < side_w of every row of X voxels are read from the compact buffer `side`
 hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash = nullptr,
-                               uint32_t gap_chunk = 0);
+                               uint32_t gap_chunk = 0, const uint16_t* side = nullptr, uint32_t side_w = 0, uint32_t X = 0);
 uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len);
 // duplicate chunks of a plane stream (chunk a multiple of 1 KiB): dup_of[k] = the earliest chunk with the same bytes (k itself when
 // there is none); the hashes only nominate, a byte compare decides.  work: lz4_dedupe_work_bytes(nchunks) bytes
@@ -25,6 +26,12 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
 
 // diff3x3x1 on a {Z,Y,X} volume of 1- or 2-byte unsigned voxels (encoders/diff_scheme_impl.hpp:78-139)
+// diff3x3x1 with a 16-bit bit-plane transpose right behind it: the stage can only touch columns x < 1 + hx, hx = Z - 2 (the reference
+// takes the row extent from the DEPTH).  side_width = those columns rounded up to the 128 voxels a lane of the transpose
+// owns (0: not applicable -- other geometry, 8-bit, or no column left out); launch_diff3x3x1_side writes just them (rows side_w
+// voxels apart, Z*Y*side_w voxels), launch_bitswap1_u16(.., side, side_w, X) reads them from there and the rest from the input.
+uint32_t diff3x3x1_side_width(uint64_t Z, uint64_t Y, uint64_t X, int elem_size);
+hipError_t launch_diff3x3x1_side(const uint16_t* in, uint16_t* side, uint64_t Z, uint64_t Y, uint64_t X, uint32_t side_w, hipStream_t stream);
 // schar (8-bit only): the stage as a tail filter on the sink's `char` output -- signed bytes, the sum sign-extended before the division
 hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream,
                             bool schar = false);

@@ -152,16 +152,24 @@ __device__ __forceinline__ void transpose16x16_pairs(uint32_t r[16])
 // chunk k of 2^gap_shift bytes starts at out + k * (chunk + 15), the 15 bytes in between being the frame header, size field and
 // end mark of a stored frame.  A chunk the LZ4 stage stores raw then never moves again.  The 1 KiB pieces land 0..15 bytes
 // off a 16-byte boundary; plain unaligned 16-byte stores (measured within 8 % of aligned ones, tools/ubench_align.hip).
+// side != nullptr (diff3x3x1 right in front, see diff3x3x1_u16_rows_kernel): columns x < side_w of every row (X voxels, a multiple
+// of the 128 a lane owns) come from the compact buffer `side` (rows side_w voxels apart), everything else from `in`.
 template <bool GAP>
 __global__ __launch_bounds__(256)
 void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words,
-                       uint32_t* __restrict__ piece_hash, uint32_t gap_shift)
+                       uint32_t* __restrict__ piece_hash, uint32_t gap_shift, const uint16_t* __restrict__ side, uint32_t side_w, uint32_t X)
 {
     const int lane = threadIdx.x & 63;
     const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
         const v4u* src = reinterpret_cast<const v4u*>(in + tile * BSW_TILE_VOX) + lane * 16;
+        if (side) {
+            const uint64_t i0 = tile * BSW_TILE_VOX + (uint64_t)lane * 128u;
+            const uint64_t row = i0 / X;
+            const uint32_t x0 = (uint32_t)(i0 - row * X);
+            if (x0 < side_w) src = reinterpret_cast<const v4u*>(side + row * side_w + x0);
+        }
         v4u v[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) v[j] = src[j];
@@ -409,17 +417,23 @@ void diff3x3x1_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t Z,
 // 16-bit fast path for the common geometry (every row's reach 1 + hx stays inside its row, i.e. Z-2 <= X-1):
 // thread = 8 consecutive voxels of one row (one 16-byte load per source row), grid = (row pieces, Y, Z), so no
 // coordinate is ever recovered by division.  Rewritten voxels: 1 <= z < zlim, 1 <= y <= Y-2, 1 <= x < 1 + hx.
+// out_stride / xlim: the output rows are out_stride voxels apart and only columns below xlim are written (X / X: the whole volume,
+// the stage on its own).  With a bit-plane transpose right behind, only the columns the stage can touch at all -- x < 1 + hx,
+// and hx comes from the DEPTH of the stack -- go to a compact side buffer, the transpose takes everything else
+// from the stage's input: for a 2048 x 2048 x 256 slab that is 1/8 of the volume instead of a full read-and-write pass.
 __global__ __launch_bounds__(256)
 void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint32_t Y, uint32_t X,
-                               uint32_t hx, uint32_t zlim)
+                               uint32_t hx, uint32_t zlim, uint32_t out_stride, uint32_t xlim, uint32_t rows_per_block)
 {
-    const uint32_t z = blockIdx.z, y = blockIdx.y;
-    const uint32_t x0 = (blockIdx.x * 256u + threadIdx.x) * 8u;
-    if (x0 >= X) return;
+    // rows_per_block (a power of two up to 16): a block covers that many rows with 256 / rows_per_block threads each (narrow xlim)
+    const uint32_t tpr = 256u / rows_per_block;
+    const uint32_t z = blockIdx.z, y = blockIdx.y * rows_per_block + threadIdx.x / tpr;
+    const uint32_t x0 = (blockIdx.x * tpr + threadIdx.x % tpr) * 8u;
+    if (x0 >= xlim || y >= Y) return;
     const uint64_t frame = (uint64_t)Y * X;
     const uint64_t row = (uint64_t)z * frame + (uint64_t)y * X;
     const uint16_t* __restrict__ cur = in + row;
-    uint16_t* __restrict__ dst = out + row;
+    uint16_t* __restrict__ dst = out + ((uint64_t)z * Y + y) * out_stride;
     const bool full = x0 + 8u <= X;
     uint32_t v[8];
     if (full && (((uintptr_t)(cur + x0)) & 15) == 0) {
@@ -936,6 +950,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             if (DENSE && U == 0 && dense_next) {
                 for (;;) {
                     if (!(P >= w.wlo + 4u && P + 112u <= w.hi_valid() && P + 112u <= matchlimit)) { dense_next = false; break; }
+                    SQY_STAMP(20);
                     if (pend) { emit_pending(); if (failed) break; }
                     const uint32_t pos = P + (uint32_t)lane;
                     const uint32_t wlo4 = w.wlo + 4u;
@@ -973,30 +988,39 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     const uint32_t d = first_diff16(s16, c16);                          // 0..16 equal bytes forward
                     const uint32_t xb = b4 ^ cb4;
                     const uint32_t bkv = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;  // equal bytes in front, 4 = maybe more
-                    // what the walk needs of a lane in one word: forward bytes | bytes in front << 5 | "candidate within 15 bytes of
-                    // the chunk start" << 8 (the catch-up limit then needs care: left to the other paths) | offset << 16
-                    const uint32_t info = d | (bkv << 5) | (old < 16u ? 0x100u : 0u) | ((pos - old) << 16);
+                    // what the walk needs of a lane in one word: forward bytes | bytes in front << 5 | literal limit << 8 | offset << 16.
+                    // The literal limit folds every reason to leave the dense batches into one compare per sequence: fewer than 15
+                    // literals; fewer than 5 when the catch-up may run past the 4 bytes looked at; none at all (0: the match goes to
+                    // the lean / generic paths) when it runs past the 16 bytes looked at or its candidate sits within 15 bytes of the
+                    // chunk start (the catch-up limit needs care there).
+                    const uint32_t maxlit1 = (d == 16u || old < 16u) ? 0u : (bkv == 4u ? 5u : 15u);
+                    const uint32_t info = d | (bkv << 5) | (maxlit1 << 8) | ((pos - old) << 16);
                     const uint64_t M = ballot(near && d >= 4u);
                     const uint64_t D = ballot(dup);
-                    // ---- the walk: uniform, registers only ----
+                    SQY_STAMP(21);
+                    // ---- the walk: uniform, registers only.  (Profiled in round 3: three quarters of a batch's time -- ~75 scalar
+                    // instructions per sequence at the 6..8 cycles a lone wave gets per instruction; now ~40: one folded exit test,
+                    // the record written with v_writelane, the inserted-probes mask derived after the walk from what it skipped.)
                     uint32_t cur = 0, anc = 0, nseq = 0;                                // lane units; anchor == P on entry
-                    uint64_t ins = 0;                                                   // probes the parse passed over (they enter the table)
+                    uint64_t nins = 0;                                                  // probes INSIDE matches: the ones that do not enter the table
                     uint32_t q_rec = 0;                                                 // lane k: sequence k, packed
                     bool keep_dense = true;
                     uint64_t evm = M | D;                                               // lanes the walk has to look at
                     while (cur < 64u && nseq < 16u) {
-                        const uint64_t ev = evm & (~0ull << cur);
+                        const uint64_t ev = evm >> cur;
                         if (!ev) break;                                                 // nothing more in this batch
-                        const uint32_t fq = ctz64(ev);
+                        const uint32_t fq = cur + ctz64(ev);
                         bool is_hit = (M >> fq) & 1ull;
                         uint32_t inf = lane_read(info, fq);
+                        SQY_REASON(13);
                         if ((D >> fq) & 1ull) {
+                            SQY_REASON(14);
                             // an earlier lane of this batch hashes to the same bucket.  If one of them has entered the table by
                             // now (a probe the parse passed over, or an ip - 2), the LATEST such lane is this probe's true
                             // candidate -- both sequences sit in registers, compare them right here
                             const uint32_t hf = lane_read(h, fq);
-                            const uint64_t passed = ins | (((1ull << fq) - 1ull) & (~0ull << cur));
-                            const uint64_t mates = ballot(h == hf) & ((1ull << fq) - 1ull) & passed;
+                            const uint64_t passed = ~nins & ((1ull << fq) - 1ull);       // every probe in front of fq that is not inside a match
+                            const uint64_t mates = ballot(h == hf) & passed;
                             if (mates) {
                                 const uint32_t qm = 63u - (uint32_t)__builtin_clzll(mates);
                                 const uint32_t x0 = lane_read(s16.x, fq) ^ lane_read(s16.x, qm);
@@ -1008,27 +1032,38 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                                 const uint32_t dq = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
                                                   : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
                                 const uint32_t bq = xbq ? ((uint32_t)__builtin_clz(xbq) >> 3) : 4u;
-                                inf = dq | (bq << 5) | (P + qm < 16u ? 0x100u : 0u) | ((fq - qm) << 16);
+                                const uint32_t ml1 = (dq == 16u || P + qm < 16u) ? 0u : (bq == 4u ? 5u : 15u);
+                                inf = dq | (bq << 5) | (ml1 << 8) | ((fq - qm) << 16);
                                 SQY_REASON(10);
                             }
                         }
                         if (!is_hit) { evm &= ~(1ull << fq); continue; }                 // (a same-bucket lane that is no match: one more probe passed)
-                        const uint32_t df = inf & 31u, bkf = (inf >> 5) & 7u;
                         const uint32_t lit = fq - anc;
-                        if (lit >= 15u || df == 16u || (bkf == 4u && lit > 4u) || (inf & 0x100u)) { keep_dense = false; SQY_REASON(11); break; }
+                        if (lit >= ((inf >> 8) & 15u)) { keep_dense = false; SQY_REASON(11); break; }
+                        const uint32_t df = inf & 31u, bkf = (inf >> 5) & 7u;
                         const uint32_t back = bkf < lit ? bkf : lit;
-                        const uint32_t ml = df - 4u;
                         // sequence k in lane k: literals | match code << 4 | anchor (lane units) << 8 | offset << 16
-                        if ((uint32_t)lane == nseq) q_rec = (lit - back) | ((ml + back) << 4) | (anc << 8) | (inf & 0xffff0000u);
-                        ins |= ((2ull << fq) - 1ull) & (~0ull << cur);                  // probes cur .. fq
-                        const uint32_t ipn = fq + 4u + ml;                              // behind the match (may lie beyond the batch)
-                        if (ipn - 2u < 64u) ins |= 1ull << (ipn - 2u);                  // LZ4_putPosition(ip - 2)
+                        {
+                            const uint32_t rec = (lit - back) | ((df - 4u + back) << 4) | (anc << 8) | (inf & 0xffff0000u);
+                            // (lane select through m0: two different SGPRs exceed the constant bus; "if (lane == nseq)" costs a compare
+                            // and a select plus their SGPR traffic)
+                            uint32_t keep_m0;
+                            asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                                : "+v"(q_rec), "=&s"(keep_m0) : "s"(rec), "s"(nseq));
+                        }
+                        const uint32_t ipn = fq + df;                                   // behind the match (may lie beyond the batch)
+                        // the probes inside the match, fq + 1 .. ipn - 1, are skipped -- but for ipn - 2 (LZ4_putPosition(ip - 2))
+                        const uint64_t upto = ipn < 64u ? (1ull << ipn) : 0ull;         // (0 - x = every bit from x on)
+                        nins |= (upto - (2ull << fq)) & ~(ipn - 2u < 64u ? 1ull << (ipn - 2u) : 0ull);
                         nseq += 1; anc = ipn; cur = ipn;
                     }
+                    // the probes the parse passed over enter the table: everything in front of the cursor that is not inside a match
+                    const uint64_t ins = ~nins & (cur < 64u ? (1ull << cur) - 1ull : ~0ull);
                     SQY_REASON(8);
 #ifdef SQY_LZ4_DIAG
                     dreason[9] += nseq;
 #endif
+                    SQY_STAMP(22);
                     if (nseq == 0) { dense_next = false; SQY_REASON(12); break; }        // (P - 2 is in the table: put2 stays empty)
                     if ((ins >> lane) & 1ull) atomicMax(&table[h], mine);
                     wave_lds_sync();
@@ -1084,6 +1119,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     anchor = P + cur;
                     put2 = anchor - 2u;                                                 // (already in the table when it lay inside the batch: harmless)
                     P = anchor;
+                    SQY_STAMP(23);
                     w.ensure(P);
                     if (!keep_dense) { dense_next = false; break; }
                 }
@@ -3499,16 +3535,20 @@ static inline int num_cus()
     return cus;
 }
 
-hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash, uint32_t gap_chunk)
+hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash, uint32_t gap_chunk,
+                               const uint16_t* side, uint32_t side_w, uint32_t X)
 {
     if (len == 0) return hipSuccess;
+    if (side && (X == 0 || X % 128u != 0 || side_w % 128u != 0 || side_w > X || len % X != 0 || (reinterpret_cast<uintptr_t>(side) & 15) ||
+                 len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || (!gap_chunk && (reinterpret_cast<uintptr_t>(out) & 15))))
+        return hipErrorInvalidValue;
     if (gap_chunk) {
         // frames in place: whole tiles only, chunks a power of two of at least one piece, `out` = body of chunk 0 (any alignment)
         if (len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || gap_chunk < 1024u || (gap_chunk & (gap_chunk - 1u)))
             return hipErrorInvalidValue;
         const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 3) / 4, cap = (uint64_t)num_cus() * 16;
         hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, in, out, n_tiles, len / 16,
-                           piece_hash, (uint32_t)__builtin_ctz(gap_chunk));
+                           piece_hash, (uint32_t)__builtin_ctz(gap_chunk), side, side_w, X);
         return hipGetLastError();
     }
     const uint64_t seg_words = len / 16;
@@ -3524,7 +3564,7 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         const uint64_t want = (n_tiles + 3) / 4;
         const uint64_t cap = (uint64_t)num_cus() * 16;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
-        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u);
+        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u, side, side_w, X);
     }
     const uint64_t first_word = n_tiles * (BSW_TILE_VOX / 16);
     const uint64_t rest_words = seg_words - first_word;
@@ -3586,6 +3626,34 @@ hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hip
     return hipGetLastError();
 }
 
+// the rows kernel's geometry (every row's reach 1 + hx stays inside its row) and the width of the compact side buffer a bit-plane
+// transpose right behind the stage can take the touched columns from: 0 = not applicable
+uint32_t diff3x3x1_side_width(uint64_t Z, uint64_t Y, uint64_t X, int elem_size)
+{
+    const uint64_t length = Z * Y * X;
+    if (length == 0 || elem_size != 2 || X % 128 != 0 || length % BSW_TILE_VOX != 0) return 0;
+    const uint64_t zlim = X < Z ? X : Z;
+    const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
+    if (noff == 1) return 0;
+    const uint64_t hx = Z >= 2 ? Z - 2 : 0;
+    if (!(hx + 2 <= X && Y <= 65535 && Z <= 65535 && X <= 0xffffffffull)) return 0;
+    const uint64_t w = ((1 + hx) + 127) / 128 * 128;                    // columns [0, 1 + hx) rounded up to whole lanes of the transpose
+    return w < X ? (uint32_t)w : 0;                                     // (no saving when every column can be touched)
+}
+
+hipError_t launch_diff3x3x1_side(const uint16_t* in, uint16_t* side, uint64_t Z, uint64_t Y, uint64_t X, uint32_t side_w, hipStream_t stream)
+{
+    if (!side_w || side_w != diff3x3x1_side_width(Z, Y, X, 2)) return hipErrorInvalidValue;
+    const uint64_t zlim = X < Z ? X : Z, hx = Z >= 2 ? Z - 2 : 0;
+    // 8 voxels per thread: a row of the side buffer is side_w / 8 threads; narrow buffers put several rows into one block
+    uint32_t rpb = 1;
+    while (rpb < 16u && (side_w / 8u) * rpb * 2u <= 256u) rpb *= 2u;
+    const unsigned bx = (unsigned)((side_w / 8u + (256u / rpb) - 1u) / (256u / rpb));
+    hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel, dim3(bx, (unsigned)((Y + rpb - 1) / rpb), (unsigned)Z), dim3(256), 0, stream, in, side, (uint32_t)Y,
+                       (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, side_w, side_w, rpb);
+    return hipGetLastError();
+}
+
 hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, hipStream_t stream, bool schar)
 {
     // geometry of the reference's halo (neighborhood_utils.hpp:160-240), see the kernel header comment
@@ -3598,7 +3666,7 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
     if (elem_size == 2 && !single && hx + 2 <= X && Y <= 65535 && Z <= 65535 && X <= 0xffffffffull) {   // reach stays inside the row, x+1 too
         const unsigned bx = (unsigned)((X + 2047) / 2048);
         hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel, dim3(bx, (unsigned)Y, (unsigned)Z), dim3(256), 0, stream, (const uint16_t*)in,
-                           (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim);
+                           (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)X, 1u);
         return hipGetLastError();
     }
     uint64_t blocks = (length + 255) / 256;

@@ -20,7 +20,10 @@ def _cases():
     mixed = rng.integers(0, 2, (64, 256, 256)).astype(np.uint16) * 0x8000                       # stored, compressed, stored, compressed, stored
     mixed |= (rng.integers(0, 2, (64, 256, 256)).astype(np.uint16) << 7) | rng.integers(0, 4, (64, 256, 256)).astype(np.uint16)
     yield "stored_compressed_alternating", "bitswap1->lz4", mixed
-    yield "diff", "diff3x3x1->bitswap1->lz4", synth.stack((32, 128, 256), np.uint16)
+    yield "diff", "diff3x3x1->bitswap1->lz4", synth.stack((32, 128, 256), np.uint16)      # (diff writes only the 128 columns it can touch)
+    yield "diff_wide_rows", "diff3x3x1->bitswap1->lz4", rng.integers(0, 65536, (20, 32, 1024), dtype=np.uint16)   # side buffer 1/8 of the rows, sums wrap
+    yield "diff_deep", "diff3x3x1->bitswap1->lz4", synth.stack((200, 16, 256), np.uint16)       # hx = 198: two of the rows' two lanes come from the side buffer -> none left out
+    yield "diff_two_lanes", "diff3x3x1->bitswap1->lz4", synth.stack((130, 16, 512), np.uint16)  # hx = 128: 129 columns -> 256 of 512
     yield "small_chunks", "bitswap1->lz4(blocksize_kb=64,framestep_kb=64)", synth.stack(shape, np.uint16)
     yield "ragged_last_chunk", "bitswap1->lz4", synth.stack((33, 64, 128), np.uint16)           # 528 KiB: two chunks and a bit
     yield "not_in_place_odd_tiles", "bitswap1->lz4", synth.stack((3, 50, 70), np.uint16)        # no whole tiles: the ordinary path, offset 0

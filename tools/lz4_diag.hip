@@ -54,8 +54,8 @@ int main(int argc, char** argv)
     CK(hipMemcpy(dg.data(), ddg, nch * 32 * 8, hipMemcpyDeviceToHost));
     unsigned long long acc = 0, cnt = 0, rs[16] = {0};
     for (uint64_t k = 0; k < nch; ++k) { acc += dg[k * 32]; cnt += dg[k * 32 + 1]; for (int i = 0; i < 16; ++i) rs[i] += dg[k * 32 + 8 + i]; }
-    if (std::getenv("SQY_DIAG_DENSE")) std::printf("dense: batches %llu, sequences %llu, ended by dup %llu, by long/lit/catch-up %llu, empty %llu | lean->generic U!=0 %llu U==0 %llu\n",
-                rs[8] / nch, rs[9] / nch, rs[10] / nch, rs[11] / nch, rs[12] / nch, rs[6] / nch, rs[7] / nch);
+    if (std::getenv("SQY_DIAG_DENSE")) std::printf("dense: batches %llu, sequences %llu, mates resolved %llu, ended by long/lit/catch-up %llu, empty %llu, walk steps %llu, of them same-bucket lanes %llu | lean->generic U!=0 %llu U==0 %llu\n",
+                rs[8] / nch, rs[9] / nch, rs[10] / nch, rs[11] / nch, rs[12] / nch, rs[13] / nch, rs[14] / nch, rs[6] / nch, rs[7] / nch);
     std::printf("region %2d -> %2d: kernel %.3f ms, %llu passes/chunk, avg %.0f cycles, total %.0f cycles/chunk | events/chunk: no-hit %llu f0>14 %llu far-fetch %llu hazard %llu long %llu slow-back %llu genericU!=0 %llu genericU==0 %llu\n",
                 SQY_DIAG_A, SQY_DIAG_B, best, cnt / nch, cnt ? (double)acc / cnt : 0.0, (double)acc / nch,
                 rs[0] / nch, rs[1] / nch, rs[2] / nch, rs[3] / nch, rs[4] / nch, rs[5] / nch, rs[6] / nch, rs[7] / nch);
