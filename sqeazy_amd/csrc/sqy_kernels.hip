@@ -755,18 +755,8 @@ constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positio
 // and parsed again by the DENSE = true kernel, which resolves several sequences per batch; the host launches that one over
 // exactly the listed chunks, and only when there are any.  Two kernels instead of one keep the lean loop of the first pass
 // free of the dense batches' registers (and the dense batches free to use a larger window).
-// EMITW (first pass only): TWO wavefronts per chunk.  A lone wavefront issues one instruction every 6..8 cycles, and a parse
-// iteration is ~200 of them -- the chunk's latency is the instruction count of the parser.  So the parser (wave 0) no longer
-// writes anything: every sequence it finds goes into a queue in LDS as a 32-byte record {anchor, literals, match code, offset,
-// up to 14 literal bytes}, and the emitter (wave 1, another SIMD of the same CU) does the output-limit checks, token / length
-// bytes, the stage and its flushes, and the last literals.  Records are taken in order; the emitter reports an output overflow
-// back ("stored raw"), the parser tells it when the parse is over or the chunk goes to the dense kernel.  Both waves belong to
-// one workgroup, so they are always resident together; neither ever waits for the other except on a full / empty queue.
-constexpr uint32_t LZ4_QN = 32;              // records in the queue
-constexpr uint32_t LZ4_OB_EMITW = 1024;      // the emitter's stage (the queue takes the other KiB of the 2 KiB the stage has otherwise)
-
-template <bool LINKED, bool DENSE, bool EMITW = false>
-__global__ __launch_bounds__(EMITW ? 128 : 64)
+template <bool LINKED, bool DENSE>
+__global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk, uint64_t in_stride,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
@@ -781,14 +771,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     constexpr uint32_t LZ4_WIN = DENSE ? LZ4_WIN_DENSE : LZ4_WIN_LEAN;
     typedef Lz4WindowT<LZ4_WIN> Lz4Window;
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
-    __shared__ __attribute__((aligned(16))) uint8_t stage[EMITW ? LZ4_OB_EMITW : LZ4_OB];
-    __shared__ __attribute__((aligned(16))) uint8_t queue[EMITW ? LZ4_QN * 32u : 16u];
-    __shared__ uint32_t qctl[8];             // [0] tail (parser), [1] head (emitter), [2] output overflow (emitter), [3] parse over: 1 finish / 2 abandon, [4] final anchor
-    static_assert(!EMITW || (!LINKED && !DENSE), "the emitter wave serves the first pass over independent chunks");
-    const int lane = threadIdx.x & 63;
-    const bool emitter = EMITW && threadIdx.x >= 64;
+    __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
+    const int lane = threadIdx.x;
     if (!LINKED && !DENSE && dup_of && dup_of[blockIdx.x] != blockIdx.x) return;     // byte-identical to an earlier chunk (lz4_dedupe_*): its frame is that chunk's
-    if (EMITW && threadIdx.x < 8) qctl[threadIdx.x] = 0;
     const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : (DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x);
     const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
     uint32_t n_prev = 0;
@@ -842,9 +827,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     const uint32_t tsh = 31u - pos_bits;                       // >= 8 for blocks up to 4 MiB
     const uint32_t tmask = (1u << tsh) - 1u;
     auto tag_of = [&](uint32_t seq32) -> uint32_t { return (seq32 * 2654435761u) >> (32u - tsh); };
-    if (emitter) {
-        // (nothing to set up: the barrier below, then the emitter's loop)
-    } else if (fresh) {
+    if (fresh) {
         const uint32_t e0 = (p0 << tsh) | (n >= 4 ? tag_of(glb_ld_u32((glb_u8*)src + p0)) : 0u);
         uint4* t4 = reinterpret_cast<uint4*>(table);
 #pragma unroll
@@ -867,118 +850,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     bool failed = false;
     bool redo_dense = false;             // first pass: this chunk is left to the DENSE kernel
 
-    if (EMITW && emitter) {
-        // ---------------------------------------------------------------------------------------
-        // the emitter wave: sequence records in, compressed bytes out (see the kernel's header comment)
-        // ---------------------------------------------------------------------------------------
-        Lz4Window gw;                        // a window with nothing resident: every literal it copies comes from global memory
-        gw.src = (glb_u8*)src; gw.win = (lds_u8*)ring; gw.n = pend; gw.whi = 0; gw.wlo = 0; gw.nif = 0; gw.lane16 = (uint32_t)lane * 16u; gw.pmin = 0;
-        uint32_t head = 0, fin = 0;
-        for (;;) {
-            const uint32_t tail = __hip_atomic_load(&qctl[0], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (head == tail) {
-                if (fin) break;                                                     // (the parser's last push comes before its "over")
-                fin = __hip_atomic_load(&qctl[3], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                if (!fin) __builtin_amdgcn_s_sleep(2);
-                continue;                                                           // once more with the tail re-read behind `fin`
-            }
-            const lds_u8* rec = (const lds_u8*)queue + (head & (LZ4_QN - 1u)) * 32u;
-            const v4u hd = *reinterpret_cast<const SQY_LDS v4u*>(rec);
-            const uint32_t r_anchor = sgpr(hd.x), lit = sgpr(hd.y), matchCode = sgpr(hd.z), offset = sgpr(hd.w);
-            const uint32_t litb = lds_ld_u8(rec + 16u + (((uint32_t)lane - 1u) & 15u));     // lane k: literal k - 1 (short literal runs)
-            wave_lds_sync();
-            head += 1;
-            if (lane == 0) __hip_atomic_store(&qctl[1], head, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);   // the slot is free again
-            if (failed) continue;                                                   // (an overflowing chunk is stored raw: drain the queue)
-            // upstream's two output-limit checks (token + literals, then offset + match length)
-            const uint32_t lit_ext = lit >= 15 ? (lit - 15) / 255 + 1 : 0;
-            const uint32_t ml_ext = (matchCode + 240u) / 255u;
-            if (op + 1 + lit + (2 + 1 + LZ4_LASTLITERALS) + lit / 255 > olimit ||
-                op + 1 + lit_ext + lit + 2 + (1 + LZ4_LASTLITERALS) + ml_ext > olimit) {
-                failed = true;
-                if (lane == 0) __hip_atomic_store(&qctl[2], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                continue;
-            }
-            const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (matchCode < 15 ? matchCode : 15u);
-            const uint32_t seq_bytes = 1 + lit_ext + lit + 2 + ml_ext;
-            if (seq_bytes <= 64 && lit < 15) {
-                // whole sequence at once into the LDS stage: lane k writes byte k; everything behind the literals is one
-                // little-endian value (offset, ml_ext - 1 bytes of 255, the rest)
-                if (op - o.base + seq_bytes > LZ4_OB_EMITW) o.flush(op);
-                const uint32_t rest = matchCode - 15u - (ml_ext - 1u) * 255u;       // (unused when ml_ext == 0)
-                uint32_t k = (uint32_t)lane;
-                uint32_t v = token;
-                v = (k - 1u) < lit ? litb : v;
-                const uint32_t j = k - (lit + 1u);
-                uint32_t tb = j == 0u ? (offset & 0xffu) : j == 1u ? (offset >> 8) : (j - 1u < ml_ext ? 255u : rest);
-                v = k > lit ? tb : v;
-                if (k < seq_bytes) *o.at(op + k) = (uint8_t)v;
-                op += seq_bytes;
-            } else {
-                o.flush(op);
-                if (lane == 0) dst[op] = (uint8_t)token;
-                op += 1;
-                if (lit >= 15) {
-                    const uint32_t rest = lit - 15;
-                    const uint32_t n255 = rest / 255;
-                    for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
-                    if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
-                    op += n255 + 1;
-                }
-                wave_copy(dst + op, gw, r_anchor, lit, lane);
-                op += lit;
-                if (lane == 0) { dst[op] = (uint8_t)offset; dst[op + 1] = (uint8_t)(offset >> 8); }
-                op += 2;
-                if (matchCode >= 15) {
-                    const uint32_t rest = matchCode - 15;
-                    const uint32_t n255 = rest / 255;
-                    for (uint32_t i = lane; i < n255; i += 64) dst[op + i] = 255;
-                    if (lane == 0) dst[op + n255] = (uint8_t)(rest - n255 * 255);
-                    op += n255 + 1;
-                }
-                o.base = op;
-            }
-        }
-        if (fin == 1u) {
-            // the parse is over: the last literals run from the parser's final anchor to the end of the chunk
-            const uint32_t f_anchor = __hip_atomic_load(&qctl[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (!failed) {
-                o.flush(op);
-                const uint32_t lastRun = pend - f_anchor;
-                if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
-                    failed = true;
-                } else {
-                    if (lastRun >= 15) {
-                        const uint32_t rest = lastRun - 15;
-                        const uint32_t n255 = rest / 255;
-                        if (lane == 0) dst[op] = 0xF0;
-                        for (uint32_t i = lane; i < n255; i += 64) dst[op + 1 + i] = 255;
-                        if (lane == 0) dst[op + 1 + n255] = (uint8_t)(rest - n255 * 255);
-                        op += n255 + 2;
-                    } else {
-                        if (lane == 0) dst[op] = (uint8_t)(lastRun << 4);
-                        op += 1;
-                    }
-                    wave_copy(dst + op, gw, f_anchor, lastRun, lane);
-                    op += lastRun;
-                }
-            }
-            if (lane == 0) csize[blk] = failed ? 0u : op;
-        }
-        return;                                                                     // (fin == 2: the chunk goes to the dense kernel, nothing is kept)
-    }
-    // the parser's side of the queue
-    uint32_t q_tail = 0, q_head_seen = 0;
-    auto push = [&](uint32_t r_anchor, uint32_t lit, uint32_t matchCode, uint32_t offset, uint32_t litbyte) {
-        while (q_tail - q_head_seen >= LZ4_QN) q_head_seen = __hip_atomic_load(&qctl[1], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        lds_u8* rec = (lds_u8*)queue + (q_tail & (LZ4_QN - 1u)) * 32u;
-        if (lane == 0) { const v4u hd = {r_anchor, lit, matchCode, offset}; *reinterpret_cast<SQY_LDS v4u*>(rec) = hd; }
-        if ((uint32_t)lane - 1u < 14u) rec[16u + (uint32_t)lane - 1u] = (uint8_t)litbyte;       // lane k: literal k - 1
-        q_tail += 1;
-        wave_lds_sync();
-        if (lane == 0) __hip_atomic_store(&qctl[0], q_tail, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    };
-
     if (n >= LZ4_MINLENGTH) {
         const uint32_t mflimitPlusOne = pend - LZ4_MFLIMIT + 1;
         const uint32_t matchlimit = pend - LZ4_LASTLITERALS;
@@ -998,7 +869,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         bool dense_next = DENSE;
         uint32_t shorts = 0;
         bool pend = false;
-        uint32_t pe_lit = 0, pe_mcode = 0, pe_off = 0, pe_anc = 0;
+        uint32_t pe_lit = 0, pe_mcode = 0, pe_off = 0;
         uint32_t pe_litv = 0;            // per lane: literal byte k-1 for lane k
         // two halves, so that the lean loop can run each in the shadow of a different LDS round trip: the output-limit checks
         // and the room in the stage (scalar), then the bytes (one per lane)
@@ -1034,7 +905,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             op += pe_bytes;
         };
         auto emit_pending = [&]() {
-            if (EMITW) { push(pe_anc, pe_lit, pe_mcode, pe_off, pe_litv); pend = false; return; }
             emit_pending_checks();
             if (failed) { pend = false; return; }
             emit_pending_bytes();
@@ -1283,13 +1153,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     // (the hash takes five bytes, the tag four: eight bytes per probe are all this batch reads of the sequence)
                     const uint64_t s8 = lds_ld_u64(w.win + o16);
                     const uint2 s16 = make_uint2((uint32_t)s8, (uint32_t)(s8 >> 32));
-                    // (in the shadow of those reads: limit checks / stage room of the sequence found in the last iteration -- or, with
-                    // an emitter wave, its record into the queue and a look at the emitter's overflow flag)
-                    if (EMITW) {
-                        const uint32_t ovf = *reinterpret_cast<const volatile SQY_LDS uint32_t*>((const lds_u8*)qctl + 8);
-                        if (pend) emit_pending();
-                        if (sgpr(ovf)) { failed = true; break; }
-                    } else if (pend) { emit_pending_checks(); if (failed) break; }
+                    // (in the shadow of those reads: limit checks / stage room of the sequence found in the last iteration)
+                    if (pend) { emit_pending_checks(); if (failed) break; }
                     SQY_STAMP(2);
                     const uint32_t h = lz4_hash5_32(s16.x, s16.y);
                     const uint32_t mytag = tag_of(s16.x);
@@ -1300,7 +1165,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     SQY_STAMP(3);
                     const uint32_t oe = table[h];
                     // (in the shadow of the table read: its bytes)
-                    if (!EMITW && pend) emit_pending_bytes();
+                    if (pend) emit_pending_bytes();
                     const uint32_t old = oe >> tsh;
                     // tag differs: the candidate's first four bytes differ, it cannot match.  Tag equal: they are equal but for
                     // one case in 2^tsh -- the FIRST such probe is taken as the winner right away and one wide round (64 lanes x
@@ -1376,7 +1241,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         batch_done = true;
                         break;
                     }
-                    pend = true; pe_lit = f0 - bck; pe_mcode = ml + bck; pe_off = ip0 - mt0; pe_anc = P;    // < 15 literals
+                    pend = true; pe_lit = f0 - bck; pe_mcode = ml + bck; pe_off = ip0 - mt0;    // < 15 literals
                     pe_litv = b4 >> 24;                                                 // literal k-1 sits at anchor + k - 1 = pos - 1
                     const uint32_t ipn = ip0 + 4u + ml;
                     anchor = ipn;
@@ -1625,16 +1490,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t matchCode = ml + back;                     // match length - MINMATCH as upstream counts it
             const uint32_t offset = ip0 - mt0;
 
-            if (EMITW) {
-                // the emitter wave writes it; short literal runs travel inside the record (lane k: literal k - 1)
-                uint32_t lb = 0;
-                if ((uint32_t)lane - 1u < lit && lit < 15u) {
-                    if (anchor >= w.wlo && ip0 <= w.hi_valid()) lb = w.lds8(anchor + (uint32_t)lane - 1u);   // uniform: literals resident
-                    else lb = w.rd8(anchor + (uint32_t)lane - 1u);
-                }
-                push(anchor, lit, matchCode, offset, lb);
-                if (__hip_atomic_load(&qctl[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) { failed = true; break; }
-            } else {
             // upstream's two output-limit checks (token + literals, then offset + match length)
             if (op + 1 + lit + (2 + 1 + LZ4_LASTLITERALS) + lit / 255 > olimit) { failed = true; break; }
             const uint32_t lit_ext = lit >= 15 ? (lit - 15) / 255 + 1 : 0;
@@ -1685,7 +1540,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 }
                 o.base = op;
             }
-            }
+            
 
             const uint32_t ipn = q + ml;                              // = original ip + 4 + forward count
             anchor = ipn;
@@ -1702,14 +1557,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         if (pend && !failed) emit_pending();
     }
 
-    if (EMITW) {
-        // over to the emitter: the last literals from `anchor` (1), or nothing at all (2: the dense kernel parses this chunk again)
-        wave_lds_sync();
-        if (lane == 0) {
-            __hip_atomic_store(&qctl[4], anchor, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            __hip_atomic_store(&qctl[3], redo_dense ? 2u : 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-    } else if (!failed && !redo_dense) {
+    if (!failed && !redo_dense) {
         o.flush(op);
         const uint32_t lastRun = pend - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
@@ -1733,7 +1581,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
     if (lane == 0) {
         if (!DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
-        else if (!EMITW) csize[blk] = failed ? 0u : op;                // (with an emitter wave the emitter knows the size)
+        else csize[blk] = failed ? 0u : op;
     }
     if (LINKED) __syncthreads();
   }
@@ -3853,7 +3701,7 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
         const hipError_t e = hipMemsetAsync(redo, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((lz4_chunks_kernel<false, false, true>), dim3((unsigned)nchunks), dim3(128), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
+    hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
                        frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of SQY_DIAG_NULL);
     return hipGetLastError();
 }
