@@ -2055,7 +2055,34 @@ struct FmBlock {
         }
         return delta;
     }
-    // both starting parities in one pass over the lanes (the block records of the planned path)
+    // The same for BOTH starting parities, as an ordered tree reduction instead of a walk over the 64 lanes: what a lane's elements
+    // do to the running sum is a map  parity in -> (parity out, delta)  -- without a tie  p -> (p ^ C0, D0), with one
+    // p -> (parity after its last tie, D0 +- half + Df), the sign from p ^ C0 -- and maps compose associatively: six rounds of
+    // "lower lane's map, then upper lane's map" leave the whole block's map in lane 0 (~70 instructions instead of ~1000).
+    static __device__ __forceinline__ void chain2_tree(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, int32_t& delta0, uint32_t& par0,
+                                                       int32_t& delta1, uint32_t& par1)
+    {
+        const int32_t half = (int32_t)((1u << k) >> 1);
+        const uint32_t seen = flags & 1u, C0 = (flags >> 1) & 1u, pc = (flags >> 2) & 1u;
+        // this lane's map: q = parity out for parity in 0 | parity in 1 << 1; d0 / d1 = delta for parity in 0 / 1
+        uint32_t q = seen ? (pc | (pc << 1)) : (C0 | ((C0 ^ 1u) << 1));
+        int32_t d0 = seen ? D0 + (C0 ? half : -half) + Df : D0;
+        int32_t d1 = seen ? D0 + (C0 ? -half : half) + Df : D0;
+#pragma unroll
+        for (int s_ = 1; s_ < 64; s_ <<= 1) {
+            // the map of the 2 s_ lanes that start here = (upper s_ lanes) after (lower s_ lanes); only lanes that are a multiple of
+            // 2 s_ hold a meaningful result, the others compute along
+            const uint32_t uq = (uint32_t)__shfl_down((int)q, s_);
+            const int32_t ud0 = __shfl_down(d0, s_), ud1 = __shfl_down(d1, s_);
+            const uint32_t m0 = q & 1u, m1 = (q >> 1) & 1u;               // parity between the halves for parity in 0 / 1
+            d0 += m0 ? ud1 : ud0;
+            d1 += m1 ? ud1 : ud0;
+            q = ((uq >> m0) & 1u) | (((uq >> m1) & 1u) << 1);
+        }
+        par0 = lane_read(q, 0) & 1u; par1 = (lane_read(q, 0) >> 1) & 1u;
+        delta0 = (int32_t)lane_read((uint32_t)d0, 0); delta1 = (int32_t)lane_read((uint32_t)d1, 0);
+    }
+    // both starting parities in one pass over the lanes (the serial form of chain2_tree)
     static __device__ __forceinline__ void chain2(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, int32_t& delta0, uint32_t& par0,
                                                   int32_t& delta1, uint32_t& par1)
     {
@@ -2176,7 +2203,7 @@ void frame_block_summaries_kernel(const T* __restrict__ in, uint64_t per_frame, 
             uint32_t flags; int32_t D0, Df;
             B::lanes(x, k, flags, D0, Df);
             uint32_t p0, p1;
-            B::chain2(flags, D0, Df, k, r.d0, p0, r.d1, p1);
+            B::chain2_tree(flags, D0, Df, k, r.d0, p0, r.d1, p1);
             r.info = 1u | (k << 8) | (p0 << 16) | (p1 << 17);
         }
     }
