@@ -1175,7 +1175,9 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (!out) return 1;
                 if (ws->lz4_scratch.ensure(sqy::diff3x3x1_decode_scratch_bytes(h.shape[2]))) return 1;
                 ProfScope ps("diff3x3x1_decode", stream, pend);
-                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, ws->lz4_scratch.p, stream, tail));
+                const bool side_ok = cx.ensure_side();
+                SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, ws->lz4_scratch.p, stream, tail,
+                                                     side_ok ? cx.side : nullptr, cx.fork, cx.join));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }

@@ -121,11 +121,12 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
 bool bitswap1_u8_decode_lut_possible(const void* in, const void* out, uint64_t len);
 hipError_t launch_bitswap1_u8_decode_lut(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
 hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int elem_size, hipStream_t stream);
-// scratch: diff3x3x1_decode_scratch_bytes(X) of device memory for the one-launch kernel (null: always one launch per frame);
-// synchronises the stream when the one-launch kernel is used
+// one launch per frame over the columns the stage can touch (frame z needs the decoded frame z-1), the other columns one plain copy
+// -- on copy_stream next to the chain when that, fork and join are given.  (scratch: unused since round 3)
 uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X);
 hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
-                                   hipStream_t stream, bool schar = false);
+                                   hipStream_t stream, bool schar = false, hipStream_t copy_stream = nullptr, hipEvent_t fork = nullptr,
+                                   hipEvent_t join = nullptr);
 hipError_t launch_quantiser_decode(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
 hipError_t launch_frame_scatter(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
 

@@ -421,14 +421,17 @@ void diff3x3x1_kernel(const T* __restrict__ in, T* __restrict__ out, uint64_t Z,
 // the stage on its own).  With a bit-plane transpose right behind, only the columns the stage can touch at all -- x < 1 + hx,
 // and hx comes from the DEPTH of the stack -- go to a compact side buffer, the transpose takes everything else
 // from the stage's input: for a 2048 x 2048 x 256 slab that is 1/8 of the volume instead of a full read-and-write pass.
+// DECODE: the inverse, one frame (or a run of untouched frames) per launch: voxel + mean of the DECODED frame z-1, read from `out`
+// (rows X apart there); frames z0 + blockIdx.z, columns [xbeg, xlim).
+template <bool DECODE>
 __global__ __launch_bounds__(256)
 void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint32_t Y, uint32_t X,
-                               uint32_t hx, uint32_t zlim, uint32_t out_stride, uint32_t xlim, uint32_t rows_per_block)
+                               uint32_t hx, uint32_t zlim, uint32_t out_stride, uint32_t xlim, uint32_t rows_per_block, uint32_t z0, uint32_t xbeg)
 {
     // rows_per_block (a power of two up to 16): a block covers that many rows with 256 / rows_per_block threads each (narrow xlim)
     const uint32_t tpr = 256u / rows_per_block;
-    const uint32_t z = blockIdx.z, y = blockIdx.y * rows_per_block + threadIdx.x / tpr;
-    const uint32_t x0 = (blockIdx.x * tpr + threadIdx.x % tpr) * 8u;
+    const uint32_t z = z0 + blockIdx.z, y = blockIdx.y * rows_per_block + threadIdx.x / tpr;
+    const uint32_t x0 = xbeg + (blockIdx.x * tpr + threadIdx.x % tpr) * 8u;
     if (x0 >= xlim || y >= Y) return;
     const uint64_t frame = (uint64_t)Y * X;
     const uint64_t row = (uint64_t)z * frame + (uint64_t)y * X;
@@ -450,10 +453,10 @@ void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __rest
         uint32_t colsum[10];
 #pragma unroll
         for (int j = 0; j < 10; ++j) colsum[j] = 0;
-        const uint16_t* __restrict__ up = in + row - frame;
+        const uint16_t* up = (DECODE ? (const uint16_t*)out : in) + row - frame;       // (decode: `out` holds whole frames, rows X apart)
 #pragma unroll
         for (int dy = -1; dy <= 1; ++dy) {
-            const uint16_t* __restrict__ r = up + (int64_t)dy * X;
+            const uint16_t* r = up + (int64_t)dy * X;
             uint32_t e[10];
             e[0] = (x0 > 0u) ? r[x0 - 1] : 0u;                       // only used for x = x0 >= 1
             if (full && (((uintptr_t)(r + x0)) & 15) == 0) {
@@ -474,7 +477,7 @@ void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __rest
             if (x >= 1u && x < 1u + hx && x < X) {
                 const uint32_t sum = (colsum[j] + colsum[j + 1] + colsum[j + 2]) & 0xffffu;   // T sum wraps mod 2^16
                 const uint32_t mean = (sum * 58255u) >> 19;                                    // sum / 9 for sum < 65536
-                v[j] = (v[j] - mean) & 0xffffu;
+                v[j] = (DECODE ? v[j] + mean : v[j] - mean) & 0xffffu;
             }
         }
     }
@@ -1268,6 +1271,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // generic path: any step schedule, chunk borders, hazards -- exact but slower
             // ---------------------------------------------------------------------------------------
             if (pend) { emit_pending(); if (failed) break; }
+            // (Round 3 tried a tags-only fast path for batches that find nothing -- data that does not compress, the step schedule at 16
+            // bytes and more: every probe enters itself with ds_max and the batch is PROVED empty from the tags in one LDS round trip.
+            // Exact, an incompressible chunk 0.091 -> 0.064 ms, the 8-bit stack's LZ4 -14 %; but with it in the kernel the
+            // sequence-heavy chunks of the 16-bit stacks run 4..8 % slower (A/B on one box), which costs more than it saves.)
             if (!batch_done) {
                 if (U != 0) SQY_REASON(6); else SQY_REASON(7);
                 const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
@@ -3267,237 +3274,13 @@ void diff3x3x1_decode_plane_kernel(const T* __restrict__ in, T* __restrict__ out
     out[idx] = v;
 }
 
-// inverse diff3x3x1 in ONE launch, for the geometry every real stack has (16-bit, Z <= X, rows of whole 16-byte vectors): a
-// rewritten voxel (1 <= z < zlim, 1 <= y <= Y-2, 1 <= x < Z-1) needs rows y-1..y+1 of the decoded frame z-1 only.  One workgroup
-// owns a strip of rows through all frames and keeps its decoded strip of the last frame in LDS; the two rows it lacks come from
-// the neighbouring strips.  Strips therefore run at most one frame apart: no grid-wide barrier, no launch per frame (255 launches
-// at ~10 us each were most of the 4 ms this stage took on a 256 x 2048^2 stack).
-// The hand-over decides the speed (a chain of dependent hand-overs, one per frame): an edge row travels through an exchange buffer
-// as 8-byte words of 3 voxels + a 16-bit frame tag, written and polled with agent-scope atomics (sc1: the neighbour may sit on
-// another XCD, whose L2 is not coherent with this one's for ordinary accesses).  The data carries its own "ready": one memory
-// round trip from store to use, instead of four with a counter published behind the data (drain the stores, publish, poll, load).
-// Two slots per edge, by frame parity: a strip overwrites a slot only after it has received the neighbour's next frame, which the
-// neighbour computed after reading that slot.  The buffer starts as all-ones (tag 0xffff is never used).
-// All workgroups must be resident at once: the launcher bounds the grid by the occupancy the runtime reports and launches it
-// COOPERATIVELY (refused at launch when it does not fit, one cooperative grid at a time per device); a wait that does not end
-// all the same raises the abort word behind the exchange buffer (a guard) and the launcher falls back to per-frame kernels.
-constexpr uint32_t DIFFDEC_NT = 1024;         // threads per strip: the stage is instruction issue, so every SIMD gets 4 waves to interleave
-constexpr uint32_t DIFFDEC_MAXV = 2;          // 16-byte vectors per thread and frame
-constexpr uint32_t DIFFDEC_MAXQ = 2;          // exchange words per thread and halo row (rows of up to 6144 voxels)
-constexpr uint64_t DIFFDEC_MAX_STRIPS = 256;  // at most one workgroup per CU
+// (Round 2 had a one-launch inverse here -- strips of rows that waited for their neighbours through an exchange buffer, all
+// workgroups resident at once.  A plain launch cannot promise that: two decodes in flight could each hold half the chip and wait
+// for strips that never start; a process-local mutex hid it.  A cooperative launch promises it, but concurrent cooperative
+// launches from several host threads crash the HIP runtime at process exit (ROCm 7.2, seen in round 3).  The inverse is now a
+// chain of ordinary launches, one per frame, over the columns the stage can touch -- no kernel of this library waits for another
+// workgroup any more.)
 
-// workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every global access in flight (vmcnt(0)),
-// here the frame fetched ahead and the stores of the frame before -- an HBM round trip per barrier
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-__global__ __launch_bounds__(DIFFDEC_NT)
-void diff3x3x1_decode_strips_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint32_t Z, uint32_t Y, uint32_t X, uint32_t hx,
-                                    uint32_t zlim, uint32_t R, uint64_t* __restrict__ exch, uint32_t* __restrict__ abort_word)
-{
-    typedef uint16_t T;
-    extern __shared__ uint4 diffdec_lds[];                       // (R + 2) rows of the decoded previous frame: row ry at (ry + 1) * X; + 2 rows
-    __shared__ uint32_t s_abort;
-    constexpr uint32_t V = 8;
-    T* const prev = reinterpret_cast<T*>(diffdec_lds);
-    const uint32_t tid = threadIdx.x, G = gridDim.x;
-    if (tid == 0) s_abort = 0;
-    // consecutive strips on one XCD (workgroups are dealt round-robin to the 8 XCDs): most hand-overs stay inside one die
-    uint32_t strip;
-    {
-        const uint32_t k = blockIdx.x % 8u, q = G / 8u, rem = G % 8u;
-        strip = k * q + (k < rem ? k : rem) + blockIdx.x / 8u;
-    }
-    const uint32_t y0 = strip * R, y1 = (y0 + R < Y) ? y0 + R : Y, nrows = y1 - y0;
-    const uint32_t XV = X / V, nvec = nrows * XV;
-    const uint32_t NQ = (X + 2u) / 3u;                           // exchange words per row
-    const uint64_t frame = (uint64_t)Y * X;
-    // exchange slot of (strip s, side, parity): side 0 = the strip's top row (for strip s-1), side 1 = its bottom row (for s+1)
-    auto slot = [&](uint32_t s_, uint32_t side, uint32_t par) { return exch + ((uint64_t)(s_ * 2u + side) * 2u + par) * NQ; };
-    uint32_t vry[DIFFDEC_MAXV], vx0[DIFFDEC_MAXV];
-#pragma unroll
-    for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
-        const uint32_t v = tid + i * DIFFDEC_NT;
-        vry[i] = v / XV;
-        vx0[i] = (v - vry[i] * XV) * V;
-    }
-    T* const edge_new = prev + (uint64_t)(R + 2) * X;              // the new frame's top and bottom row on their way out (2 rows)
-    auto publish = [&](uint32_t z_) {
-        const uint64_t tag = (uint64_t)(z_ + 1u) << 48;
-        uint64_t* const pt = slot(strip, 0u, z_ & 1u);
-        uint64_t* const pb = slot(strip, 1u, z_ & 1u);
-        const T* const top = edge_new, * const bot = edge_new + X;
-        for (uint32_t q = tid; q < NQ; q += DIFFDEC_NT) {
-            const uint32_t x = q * 3u;
-            const uint32_t x1 = x + 1u < X ? x + 1u : x, x2 = x + 2u < X ? x + 2u : x;
-            if (strip > 0) __hip_atomic_store(pt + q, (uint64_t)top[x] | ((uint64_t)top[x1] << 16) | ((uint64_t)top[x2] << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (strip + 1u < G) __hip_atomic_store(pb + q, (uint64_t)bot[x] | ((uint64_t)bot[x1] << 16) | ((uint64_t)bot[x2] << 32) | tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    };
-    lds_barrier();
-    uint4 vout[DIFFDEC_MAXV];                                      // the decoded frame z-1, on its way out
-    uint4 vnext[DIFFDEC_MAXV];                                     // the stored frame z+1, fetched a frame ahead
-#pragma unroll
-    for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
-        if (tid + i * DIFFDEC_NT < nvec) vnext[i] = *reinterpret_cast<const uint4*>(in + (uint64_t)y0 * X + (uint64_t)(tid + i * DIFFDEC_NT) * V);
-    for (uint32_t z = 0; z < Z; ++z) {
-        uint4 vin[DIFFDEC_MAXV];
-#pragma unroll
-        for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) vin[i] = vnext[i];
-        // global traffic that nobody waits for -- the decoded frame z-1 out, the stored frame z+1 in -- is issued right AFTER the
-        // wait for the neighbours' rows: memory operations complete in order, so anything issued just before that wait would
-        // be waited for as well (an HBM round trip on the hand-over chain, every frame)
-        auto background_traffic = [&]() {
-            if (z > 0) {
-                T* const d = out + (uint64_t)(z - 1) * frame + (uint64_t)y0 * X;
-#pragma unroll
-                for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
-                    if (tid + i * DIFFDEC_NT < nvec) *reinterpret_cast<uint4*>(d + (uint64_t)(tid + i * DIFFDEC_NT) * V) = vout[i];
-            }
-            if (z + 1 < Z) {
-                const T* const src = in + (uint64_t)(z + 1) * frame + (uint64_t)y0 * X;
-#pragma unroll
-                for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
-                    if (tid + i * DIFFDEC_NT < nvec) vnext[i] = *reinterpret_cast<const uint4*>(src + (uint64_t)(tid + i * DIFFDEC_NT) * V);
-            }
-        };
-        const bool rewritten = z >= 1 && z < zlim && hx > 0;
-        if (rewritten) {
-            // rows y0-1 and y1 of the decoded frame z-1 (none at the volume's top and bottom: rows 0 and Y-1 are never rewritten)
-            const uint32_t want = z;                             // tag of frame z-1 (tags are frame + 1)
-            const uint64_t* const qa = slot(strip - 1u, 1u, (z - 1u) & 1u);
-            const uint64_t* const qb = slot(strip + 1u, 0u, (z - 1u) & 1u);
-            const bool has_a = strip > 0, has_b = strip + 1u < G;
-            uint64_t wa[DIFFDEC_MAXQ], wb[DIFFDEC_MAXQ];
-            uint32_t spins = 0;
-            bool ok = true;
-            for (;;) {
-                bool all = true;
-#pragma unroll
-                for (uint32_t i = 0; i < DIFFDEC_MAXQ; ++i) {               // (every load in flight before the first is looked at)
-                    const uint32_t q = tid + i * DIFFDEC_NT;
-                    if (q < NQ && has_a) wa[i] = __hip_atomic_load(qa + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (q < NQ && has_b) wb[i] = __hip_atomic_load(qb + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-#pragma unroll
-                for (uint32_t i = 0; i < DIFFDEC_MAXQ; ++i) {
-                    const uint32_t q = tid + i * DIFFDEC_NT;
-                    if (q < NQ && has_a && (uint32_t)(wa[i] >> 48) != want) all = false;
-                    if (q < NQ && has_b && (uint32_t)(wb[i] >> 48) != want) all = false;
-                }
-                if (all) break;
-                if (++spins > (1u << 20) || ((spins & 255u) == 0 && __hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { ok = false; break; }
-                __builtin_amdgcn_s_sleep(1);
-            }
-            if (!ok) { __hip_atomic_store(abort_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); s_abort = 1; }
-            background_traffic();
-#pragma unroll
-            for (uint32_t i = 0; i < DIFFDEC_MAXQ; ++i) {
-                const uint32_t q = tid + i * DIFFDEC_NT;
-                if (q >= NQ) continue;
-#pragma unroll
-                for (uint32_t j = 0; j < 3; ++j) {
-                    const uint32_t x = q * 3u + j;
-                    if (x >= X) continue;
-                    if (has_a) prev[x] = (T)(wa[i] >> (16u * j));
-                    if (has_b) prev[(uint64_t)(nrows + 1) * X + x] = (T)(wb[i] >> (16u * j));
-                }
-            }
-            lds_barrier();
-            if (s_abort) return;                                 // (uniform: read after the barrier, never reset)
-            // one vector of 8 voxels: in + mean of the 3x3 neighbourhood one frame back (all sums mod 2^16, as the reference's
-            // pixel-typed accumulator).  Packed 16-bit arithmetic, two voxels per instruction: the stage is VALU work
-            // (one workgroup per CU), ~7 instructions a voxel this way against ~25 voxel by voxel.
-            auto decode_vec = [&](uint4& io, uint32_t ry, uint32_t x0) {
-                const uint32_t y = y0 + ry;
-                if (y < 1 || y + 2 > Y || x0 >= 1u + hx) return;                // row or vector without rewritten voxels
-                const T* const c = prev + (uint64_t)(ry + 1) * X + x0;          // this row of frame z-1; the rows above and below at -X, +X
-                const uint4 a = *reinterpret_cast<const uint4*>(c - X), b = *reinterpret_cast<const uint4*>(c), d = *reinterpret_cast<const uint4*>(c + X);
-                // (x0 = 0: column -1 belongs to voxel x = 0, never rewritten; x0 + V = X: to voxel X-1, never rewritten as Z <= X)
-                const uint32_t cm1 = x0 ? ((uint32_t)c[-(int64_t)X - 1] + c[-1] + c[(int64_t)X - 1]) & 0xffffu : 0u;
-                const uint32_t cp8 = x0 + V < X ? ((uint32_t)c[-(int64_t)X + V] + c[V] + c[X + V]) & 0xffffu : 0u;
-                typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
-                auto pk_add = [](uint32_t p, uint32_t q) -> uint32_t {
-                    const u16x2 r = __builtin_bit_cast(u16x2, p) + __builtin_bit_cast(u16x2, q);
-                    return __builtin_bit_cast(uint32_t, r);
-                };
-                const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, bw[4] = {b.x, b.y, b.z, b.w}, dw[4] = {d.x, d.y, d.z, d.w};
-                uint32_t C[6];                                                 // column sums, two per word: C[k+1] = columns 2k, 2k+1
-                C[0] = cm1 << 16;
-                C[5] = cp8;
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) C[k + 1] = pk_add(pk_add(aw[k], bw[k]), dw[k]);
-                uint32_t w[4] = {io.x, io.y, io.z, io.w};
-                const bool whole = x0 >= 1u && x0 + V <= 1u + hx;               // every voxel of the vector is rewritten
-#pragma unroll
-                for (uint32_t k = 0; k < 4; ++k) {
-                    const uint32_t left = __builtin_amdgcn_alignbit(C[k + 1], C[k], 16);       // columns 2k-1, 2k
-                    const uint32_t right = __builtin_amdgcn_alignbit(C[k + 2], C[k + 1], 16);  // columns 2k+1, 2k+2
-                    const uint32_t S = pk_add(pk_add(left, C[k + 1]), right);
-                    // x / 9 = (x * 58255) >> 19 for x < 2^16
-                    uint32_t m_lo = ((S & 0xffffu) * 58255u) >> 19, m_hi = ((S >> 16) * 58255u) >> 19;
-                    if (!whole) {
-                        const uint32_t xl = x0 + 2u * k, xh = xl + 1u;
-                        if (xl < 1u || xl >= 1u + hx) m_lo = 0;
-                        if (xh >= 1u + hx) m_hi = 0;
-                    }
-                    w[k] = pk_add(w[k], m_lo | (m_hi << 16));
-                }
-                io = make_uint4(w[0], w[1], w[2], w[3]);
-            };
-            // the strip's edge rows first: they go to the neighbours (staged in LDS, repacked into exchange words) while the
-            // rows in between are still being computed -- the hand-over chain sees two rows of work per frame, not the strip
-            const bool publish_now = z + 1 < zlim;
-#pragma unroll
-            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
-                if (tid + i * DIFFDEC_NT >= nvec) continue;
-                const bool top = vry[i] == 0, bot = vry[i] + 1 == nrows;
-                if (!top && !bot) continue;
-                decode_vec(vin[i], vry[i], vx0[i]);
-                if (publish_now) {
-                    if (top) *reinterpret_cast<uint4*>(edge_new + vx0[i]) = vin[i];
-                    if (bot) *reinterpret_cast<uint4*>(edge_new + X + vx0[i]) = vin[i];
-                }
-            }
-            if (publish_now) {
-                lds_barrier();
-                publish(z);
-            }
-#pragma unroll
-            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
-                if (tid + i * DIFFDEC_NT >= nvec) continue;
-                if (vry[i] == 0 || vry[i] + 1 == nrows) continue;
-                decode_vec(vin[i], vry[i], vx0[i]);
-            }
-            lds_barrier();                                                   // every read of frame z-1 is done
-        } else if (z + 1 < zlim && hx > 0) {
-            background_traffic();
-            // frame 0 (stored as it is): its edge rows go out all the same
-#pragma unroll
-            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) {
-                if (tid + i * DIFFDEC_NT >= nvec) continue;
-                if (vry[i] == 0) *reinterpret_cast<uint4*>(edge_new + vx0[i]) = vin[i];
-                if (vry[i] + 1 == nrows) *reinterpret_cast<uint4*>(edge_new + X + vx0[i]) = vin[i];
-            }
-            lds_barrier();
-            publish(z);
-        } else
-            background_traffic();
-        // the decoded strip: to LDS for the next frame, and (a frame later) to the output
-        if (z + 1 < zlim && hx > 0) {
-#pragma unroll
-            for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
-                if (tid + i * DIFFDEC_NT < nvec) *reinterpret_cast<uint4*>(prev + (uint64_t)(vry[i] + 1) * X + vx0[i]) = vin[i];
-        }
-#pragma unroll
-        for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i) vout[i] = vin[i];
-    }
-    if (Z > 0) {
-        T* const d = out + (uint64_t)(Z - 1) * frame + (uint64_t)y0 * X;
-#pragma unroll
-        for (uint32_t i = 0; i < DIFFDEC_MAXV; ++i)
-            if (tid + i * DIFFDEC_NT < nvec) *reinterpret_cast<uint4*>(d + (uint64_t)(tid + i * DIFFDEC_NT) * V) = vout[i];
-    }
-}
 
 // inverse quantiser: out[i] = lut_decode[in[i]]
 __global__ __launch_bounds__(256)
@@ -3676,8 +3459,8 @@ hipError_t launch_diff3x3x1_side(const uint16_t* in, uint16_t* side, uint64_t Z,
     uint32_t rpb = 1;
     while (rpb < 16u && (side_w / 8u) * rpb * 2u <= 256u) rpb *= 2u;
     const unsigned bx = (unsigned)((side_w / 8u + (256u / rpb) - 1u) / (256u / rpb));
-    hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel, dim3(bx, (unsigned)((Y + rpb - 1) / rpb), (unsigned)Z), dim3(256), 0, stream, in, side, (uint32_t)Y,
-                       (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, side_w, side_w, rpb);
+    hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<false>, dim3(bx, (unsigned)((Y + rpb - 1) / rpb), (unsigned)Z), dim3(256), 0, stream, in, side, (uint32_t)Y,
+                       (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, side_w, side_w, rpb, 0u, 0u);
     return hipGetLastError();
 }
 
@@ -3692,8 +3475,8 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
     const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
     if (elem_size == 2 && !single && hx + 2 <= X && Y <= 65535 && Z <= 65535 && X <= 0xffffffffull) {   // reach stays inside the row, x+1 too
         const unsigned bx = (unsigned)((X + 2047) / 2048);
-        hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel, dim3(bx, (unsigned)Y, (unsigned)Z), dim3(256), 0, stream, (const uint16_t*)in,
-                           (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)X, 1u);
+        hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<false>, dim3(bx, (unsigned)Y, (unsigned)Z), dim3(256), 0, stream, (const uint16_t*)in,
+                           (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)X, 1u, 0u, 0u);
         return hipGetLastError();
     }
     uint64_t blocks = (length + 255) / 256;
@@ -4050,70 +3833,59 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
 }
 
 // scratch for the one-launch kernel: 256 strips x 2 edges x 2 frame parities x ceil(X / 3) words, and the abort word
-uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X) { return DIFFDEC_MAX_STRIPS * 4 * ((X + 2) / 3) * 8 + 64; }
+uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X) { (void)X; return 0; }      // (the frame chain below needs none)
 
 hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
-                                   hipStream_t stream, bool schar)
+                                   hipStream_t stream, bool schar, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join)
 {
+    (void)scratch;
     const uint64_t length = Z * Y * X, frame = Y * X;
     if (length == 0) return hipSuccess;
     const uint64_t zlim = X < Z ? X : Z;
     const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
     const int single = (noff == 1);
     const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
-    // one launch for the usual geometry (see diff3x3x1_decode_strips_kernel); synchronises the stream to learn whether it ran through
-    // (16-bit only: the reference defines the 8-bit stage for extents <= 127 voxels)
-    if (scratch && elem_size == 2 && !single && noff > 0 && Z <= X && X % 8 == 0 && Y < (1ull << 31) && X < (1ull << 31) &&
+    // The usual geometry (16-bit, every row's reach inside its row): frame z needs the DECODED frame z-1 -- a chain of one launch
+    // per frame, in stream order.  Only columns x < 1 + hx can change (hx from the depth of the stack): those go
+    // through the chain (1 MiB per frame of a 2048 x 2048 x 256 slab: launch-bound, ~3.5 us each), everything to the right of
+    // them is ONE plain copy of all frames.  No workgroup waits for another one.
+    if (elem_size == 2 && !single && hx + 2 <= X && Y <= 65535 && Z <= 65535 && X <= 0xffffffffull && X % 8 == 0 &&
         ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15) == 0) {
-        const uint64_t R = (Y + DIFFDEC_MAX_STRIPS - 1) / DIFFDEC_MAX_STRIPS;
-        const uint64_t G = (Y + R - 1) / R;
-        const uint64_t lds = (R + 4) * X * 2;             // the strip of the last frame + 2 halo rows + 2 rows on their way out
-        const uint64_t NQ = (X + 2) / 3;
-        if (lds <= 65536 && R * (X / 8) <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXV && NQ <= (uint64_t)DIFFDEC_NT * DIFFDEC_MAXQ) {
-            // The strips wait for each other, so ALL of them must be resident at once.  That is what a cooperative launch is for:
-            // it is refused at launch time when the grid does not fit the device (instead of half-residing and spinning), and the
-            // runtime runs one cooperative grid at a time per device -- two decodes in flight (this process or another one) can no
-            // longer each hold half the chip and wait for strips that cannot start.  (Round 2 used a plain launch behind a
-            // process-local mutex; the poll limit + abort word below stay as a guard only.)  Other kernels on the chip -- LZ4
-            // chunk waves of an encode in flight -- finish on their own, a strip that has to wait for their LDS is late, not stuck.
-            int dev = 0, coop = 0, occ = 0;
-            hipError_t e = hipGetDevice(&dev);
-            if (e == hipSuccess) e = hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, dev);
-            if (e == hipSuccess) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, diff3x3x1_decode_strips_kernel, (int)DIFFDEC_NT, (size_t)lds);
-            static std::atomic<uint32_t> strips_refused[16];                 // per device: the one-launch path failed before, do not try again
-            const bool usable = e == hipSuccess && coop && occ >= 1 && G <= (uint64_t)num_cus() * (uint64_t)occ && dev >= 0 && dev < 16 &&
-                                strips_refused[dev].load() == 0;
-            (void)hipGetLastError();
-            if (usable) {
-            const uint64_t exch_bytes = G * 4 * NQ * 8;
-            uint32_t* const abort_word = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(scratch) + exch_bytes);
-            e = hipMemsetAsync(scratch, 0xff, exch_bytes, stream);
-            if (e != hipSuccess) return e;
-            e = hipMemsetAsync(abort_word, 0, 64, stream);
-            if (e != hipSuccess) return e;
-            const uint16_t* a_in = (const uint16_t*)in;
-            uint16_t* a_out = (uint16_t*)out;
-            uint32_t a_Z = (uint32_t)Z, a_Y = (uint32_t)Y, a_X = (uint32_t)X, a_hx = (uint32_t)hx, a_zlim = (uint32_t)zlim, a_R = (uint32_t)R;
-            uint64_t* a_exch = static_cast<uint64_t*>(scratch);
-            uint32_t* a_abort = abort_word;
-            void* args[] = {&a_in, &a_out, &a_Z, &a_Y, &a_X, &a_hx, &a_zlim, &a_R, &a_exch, &a_abort};
-            e = hipLaunchCooperativeKernel(reinterpret_cast<const void*>(diff3x3x1_decode_strips_kernel), dim3((unsigned)G), dim3(DIFFDEC_NT), args,
-                                           (unsigned)lds, stream);
-            if (e != hipSuccess) {
-                // refused (grid too large for what is free, no cooperative queue): the per-frame kernels below, from now on
-                (void)hipGetLastError();
-                strips_refused[dev].store(1);
-            } else {
-            uint32_t aborted = 0;
-            e = hipMemcpyAsync(&aborted, abort_word, sizeof(aborted), hipMemcpyDeviceToHost, stream);
-            if (e != hipSuccess) return e;
-            e = hipStreamSynchronize(stream);
-            if (e != hipSuccess) return e;
-            if (!aborted) return hipSuccess;
-            strips_refused[dev].store(1);                                     // (the guard fired: never again on this device)
-            }
-            }
+        // columns of the chain, whole 16-byte vectors: the touched ones and their right-hand neighbour (read from the frame before),
+        // so that the chain never reads what the copy writes
+        uint64_t w = ((2 + hx) + 7) / 8 * 8;
+        if (w > X) w = X;
+        hipStream_t cs = stream;
+        if (w < X && copy_stream && fork && join && hipEventRecord(fork, stream) == hipSuccess && hipStreamWaitEvent(copy_stream, fork, 0) == hipSuccess)
+            cs = copy_stream;                                                 // (the copy runs next to the chain)
+        if (w < X) {
+            // columns [w, X) of every frame: copy
+            const uint64_t cols = X - w;
+            uint32_t rpb = 1;
+            while (rpb < 16u && (cols / 8u) * rpb * 2u <= 256u) rpb *= 2u;
+            const unsigned bx = (unsigned)((cols / 8u + (256u / rpb) - 1u) / (256u / rpb));
+            hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, dim3(bx, (unsigned)((Y + rpb - 1) / rpb), (unsigned)Z), dim3(256), 0, cs,
+                               (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X, 0u, 0u, (uint32_t)X, (uint32_t)X, rpb, 0u, (uint32_t)w);
         }
+        uint32_t rpb = 1;
+        while (rpb < 16u && (w / 8u) * rpb * 2u <= 256u) rpb *= 2u;
+        const unsigned bx = (unsigned)((w / 8u + (256u / rpb) - 1u) / (256u / rpb));
+        const dim3 grid(bx, (unsigned)((Y + rpb - 1) / rpb), 1);
+        // frames that cannot change (z = 0, z >= zlim) in one launch each run, the others one by one
+        hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X,
+                           (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)w, rpb, 0u, 0u);
+        for (uint64_t z = 1; z < zlim; ++z)
+            hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X,
+                               (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)w, rpb, (uint32_t)z, 0u);
+        if (zlim < Z)
+            hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, dim3(grid.x, grid.y, (unsigned)(Z - zlim)), dim3(256), 0, stream, (const uint16_t*)in,
+                               (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)w, rpb, (uint32_t)zlim, 0u);
+        if (cs != stream) {
+            hipError_t e = hipEventRecord(join, cs);
+            if (e == hipSuccess) e = hipStreamWaitEvent(stream, join, 0);
+            if (e != hipSuccess) return e;
+        }
+        return hipGetLastError();
     }
     // per frame; the last X + 1 voxels of a frame read the frame's own first voxels when rows spill over (see the kernel)
     const bool spills = single || hx + 1 >= X;      // (hx = X-1: voxel X-1 of row Y-2 already reads voxel 0 of its own frame)

@@ -43,8 +43,8 @@ def test_many_threads_mixed_calls(sqy, oracle):
 
 
 def test_concurrent_full_width_diff_decodes(sqy, oracle):
-    """six host threads decode a volume whose diff3x3x1 stage takes the one-launch strip kernel with all 256 strips: the strips
-    of one launch wait for each other, so launches from different threads must not end up half resident side by side"""
+    """six host threads decode a volume with a diff3x3x1 stage at once (round 2: a one-launch kernel whose strips waited for each
+    other and could end up half resident side by side; now a chain of one ordinary launch per frame: nothing waits for a workgroup)"""
     import time
     vol = synth.stack((48, 1024, 256), np.uint16)
     blob = oracle.pipeline_encode("diff3x3x1->bitswap1->lz4", vol)
@@ -69,8 +69,8 @@ def test_concurrent_full_width_diff_decodes(sqy, oracle):
 
 
 def test_diff_decode_next_to_encodes_in_flight(sqy, oracle):
-    """the one-launch diff3x3x1 decode (strips that wait for each other: a cooperative launch) while encodes of a large stack keep
-    the chip's LDS full of LZ4 chunk waves on other streams: the decode may be late, it must not stall or go wrong"""
+    """the diff3x3x1 decode (a chain of 47 frame launches + a copy on a side stream) while encodes of a large stack keep the chip's LDS
+    full of LZ4 chunk waves on other streams: the decode may be late, it must not stall or go wrong"""
     import time
     vol = synth.stack((48, 1024, 256), np.uint16)
     blob = oracle.pipeline_encode("diff3x3x1->bitswap1->lz4", vol)
