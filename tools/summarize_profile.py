@@ -23,6 +23,8 @@ os.makedirs(dst, exist_ok=True)
 
 SHORT = {"lz4_chunks_kernel<false, false>": "lz4_chunks", "lz4_chunks_kernel<false, true>": "lz4_chunks_dense",
          "lz4_chunks_kernel<true, false>": "lz4_linked", "bitswap1_u16_regs": "bitswap1_u16",
+         "bitswap1_u16_regs<true>": "bitswap1_u16", "bitswap1_u16_regs<false>": "bitswap1_u16",
+         "lz4_tail_marks_kernel": "lz4_tail_marks", "lz4_stash_raw_kernel": "lz4_stash_raw",
          "lz4_frame_gather_kernel": "lz4_frame_gather", "lz4_frame_scan_kernel": "lz4_frame_scan",
          "bitswap1_u16_generic": "bitswap1_u16_generic", "lz4_dedupe_key_kernel": "lz4_dedupe_key",
          "lz4_dedupe_verify_kernel": "lz4_dedupe_verify"}
