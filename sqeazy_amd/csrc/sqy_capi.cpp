@@ -353,6 +353,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     const uint16_t* bsw_side = nullptr;
     uint32_t bsw_side_w = 0, bsw_side_X = 0;
     uint64_t* lz4_tail_info = nullptr;
+    uint64_t* lz4_holes = nullptr;               // frames in place: which 1 KiB pieces of the plane stream the transpose left unwritten (all zero)
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
     for (size_t si = 0; si < pipe.stages.size(); ++si) {
@@ -370,7 +371,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     if (words && chunked && chunk % 1024 == 0 && total > chunk) {
                         const uint64_t nch = (total + chunk - 1) / chunk;
                         const uint64_t ph_bytes = (words * 4 + 63) & ~(uint64_t)63;
-                        if (ws->dedupe.ensure(ph_bytes + sqy::lz4_dedupe_work_bytes(nch) + nch * 4)) return 1;
+                        if (ws->dedupe.ensure(ph_bytes + sqy::lz4_dedupe_work_bytes(nch) + ((nch * 4 + 7) & ~(uint64_t)7) + sqy::lz4_holes_map_bytes(nch, (uint32_t)chunk))) return 1;
                         ph = static_cast<uint32_t*>(ws->dedupe.p);
                         lz4_piece_hash = ph;
                         // frames in place: lz4 is the last stage, chunks a power of two, the caller takes the blob where it ends up,
@@ -659,8 +660,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         const uint64_t ph_bytes = (words * 4 + 63) & ~(uint64_t)63;
                         uint8_t* base = static_cast<uint8_t*>(ws->dedupe.p) + ph_bytes;
                         uint32_t* d_dup = reinterpret_cast<uint32_t*>(base + sqy::lz4_dedupe_work_bytes(lz4_nchunks));
+                        if (lz4_inplace) lz4_holes = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(d_dup) + ((lz4_nchunks * 4 + 7) & ~(uint64_t)7));
                         ProfScope ps("lz4_dedupe", stream, pend);
-                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride));
+                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride, lz4_holes));
                         lz4_dup_of = d_dup;
                     }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;

@@ -21,8 +21,12 @@ uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len
 // there is none); the hashes only nominate, a byte compare decides.  work: lz4_dedupe_work_bytes(nchunks) bytes
 uint64_t lz4_dedupe_work_bytes(uint64_t nchunks);
 // in_stride (all LZ4 launchers; 0 = chunk): chunk k of the stream starts at in + k * in_stride
+// holes (with gap_chunk): launch_bitswap1_u16 leaves the all-zero 1 KiB pieces of the stream UNWRITTEN (their hash is the exact zero
+// marker, 0); launch_lz4_dedupe(.., holes_map: scratch of lz4_holes_map_bytes) compares through the markers and then fills the pieces
+// in (writes into `in`) for every chunk anybody will read -- the bit planes above the data's range are neither written nor read
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0);
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0, uint64_t* holes_map = nullptr);
+uint64_t lz4_holes_map_bytes(uint64_t nchunks, uint32_t chunk);
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
 
 // diff3x3x1 on a {Z,Y,X} volume of 1- or 2-byte unsigned voxels (encoders/diff_scheme_impl.hpp:78-139)

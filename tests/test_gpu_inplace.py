@@ -20,6 +20,18 @@ def _cases():
     mixed = rng.integers(0, 2, (64, 256, 256)).astype(np.uint16) * 0x8000                       # stored, compressed, stored, compressed, stored
     mixed |= (rng.integers(0, 2, (64, 256, 256)).astype(np.uint16) << 7) | rng.integers(0, 4, (64, 256, 256)).astype(np.uint16)
     yield "stored_compressed_alternating", "bitswap1->lz4", mixed
+    # holes: all-zero 1 KiB pieces of the plane stream are never written by the transpose, the LZ4 stage fills them in
+    holes = rng.integers(0, 65536, (64, 256, 256), dtype=np.uint16)
+    holes.reshape(-1, 8192)[100::256] = 0                                                          # stored chunks with zero pieces inside
+    yield "holes_in_stored_chunks", "bitswap1->lz4", holes
+    twice = holes.copy()
+    twice[32:] = twice[:32]                                                                      # second chunk of every plane = the first: duplicates of stored chunks
+    yield "holes_in_duplicates_of_stored_chunks", "bitswap1->lz4", twice
+    low = (rng.integers(0, 256, (64, 256, 256)).astype(np.uint16))                               # planes 15..8 zero, the rest noise with gaps
+    low.reshape(-1, 8192)[1::3] = 0
+    low.reshape(-1, 8192)[5::11] = 3
+    yield "holes_low_planes", "bitswap1->lz4", low
+    yield "holes_diff", "diff3x3x1->bitswap1->lz4", low.reshape(64, 128, 512)
     yield "diff", "diff3x3x1->bitswap1->lz4", synth.stack((32, 128, 256), np.uint16)      # (diff writes only the 128 columns it can touch)
     yield "diff_wide_rows", "diff3x3x1->bitswap1->lz4", rng.integers(0, 65536, (20, 32, 1024), dtype=np.uint16)   # side buffer 1/8 of the rows, sums wrap
     yield "diff_deep", "diff3x3x1->bitswap1->lz4", synth.stack((200, 16, 256), np.uint16)       # hx = 198: two of the rows' two lanes come from the side buffer -> none left out
