@@ -160,8 +160,10 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
                        uint32_t* __restrict__ piece_hash, uint32_t gap_shift, const uint16_t* __restrict__ side, uint32_t side_w, uint32_t X)
 {
     const int lane = threadIdx.x & 63;
-    const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
+    // (the wave number through readfirstlane: tile and every piece address below are then scalar, the lane part a 32-bit offset)
+    const uint32_t wpb = blockDim.x >> 6;
+    const uint64_t wave_global = (uint64_t)blockIdx.x * wpb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t wave_stride = (uint64_t)gridDim.x * wpb;
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
         const v4u* src = reinterpret_cast<const v4u*>(in + tile * BSW_TILE_VOX) + lane * 16;
         if (side) {
@@ -193,6 +195,10 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
         for (int b = 0; b < 16; ++b) {
             const v4u val = {pl[b][0], pl[b][1], pl[b][2], pl[b][3]};
             if (GAP) {
+                // HOLES: a piece that is all zero is not written at all -- its hash says so (the exact zero marker below), and
+                // lz4_dedupe_verify_kernel fills such pieces in for the chunks somebody is going to read.  Chunks that are all
+                // zero are never read but for the first: bit planes above the largest voxel value are HBM traffic nobody needs.
+                if (ballot((pl[b][0] | pl[b][1] | pl[b][2] | pl[b][3]) != 0u) == 0ull) continue;
                 const uint64_t B = (uint64_t)(15 - b) * seg_words * 2u + tile * 1024u;      // byte offset of the piece in the plane stream
                 uint8_t* dst = reinterpret_cast<uint8_t*>(out) + B + (B >> gap_shift) * 15u;
                 *reinterpret_cast<v4u_any*>(dst + lane * 16) = val;
@@ -234,19 +240,33 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64)
 void lz4_dedupe_key_kernel(const uint32_t* __restrict__ piece_hash, uint32_t pieces_per_chunk, uint64_t nchunks_full,
-                           uint64_t* __restrict__ chunk_key, uint64_t* __restrict__ tab_key, uint32_t* __restrict__ tab_val, uint32_t tab_mask)
+                           uint64_t* __restrict__ chunk_key, uint64_t* __restrict__ tab_key, uint32_t* __restrict__ tab_val, uint32_t tab_mask,
+                           uint64_t* __restrict__ holes_map, uint32_t pieces_last)
 {
     const uint64_t k = blockIdx.x;
     const int lane = threadIdx.x;
     const uint32_t* ph = piece_hash + k * pieces_per_chunk * 4u;
-    uint32_t h1 = 0, h2 = 0, any = 0;
-    for (uint32_t i = lane; i < pieces_per_chunk; i += 64) {
-        const uint4 q = *reinterpret_cast<const uint4*>(ph + i * 4u);
-        any |= q.x | q.y | q.z | q.w;
-        const uint32_t s_ = q.x + q.y + q.z + q.w;
+    // (holes_map: the grid also covers the ragged last chunk, which takes no part in the duplicate search)
+    const uint32_t np = k < nchunks_full ? pieces_per_chunk : pieces_last;
+    uint64_t* hm = holes_map ? holes_map + k * (1u + (pieces_per_chunk + 63u) / 64u) : nullptr;
+    uint32_t h1 = 0, h2 = 0, any = 0, nzero = 0;
+    for (uint32_t base = 0; base < np; base += 64) {
+        const uint32_t i = base + (uint32_t)lane;
+        uint4 q = make_uint4(1u, 0u, 0u, 0u);
+        if (i < np) q = *reinterpret_cast<const uint4*>(ph + i * 4u);
+        any |= i < np ? (q.x | q.y | q.z | q.w) : 0u;
+        const uint32_t s_ = i < np ? q.x + q.y + q.z + q.w : 0u;
         h1 += s_ * ((2u * i + 1u) * 0x9E3779B1u);
         h2 += ((s_ << 13) | (s_ >> 19)) * ((2u * i + 3u) * 0x85EBCA77u);
+        if (hm) {
+            // which pieces are all zero (the exact marker) -- the pieces the transpose left unwritten, see lz4_dedupe_verify_kernel
+            const uint64_t zm = ballot((q.x | q.y | q.z | q.w) == 0u);
+            nzero += (uint32_t)__builtin_popcountll(zm);
+            if (lane == 0) hm[1u + base / 64u] = zm;
+        }
     }
+    if (hm && lane == 0) hm[0] = nzero;
+    if (k >= nchunks_full) return;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { h1 += __shfl_xor(h1, d); h2 += __shfl_xor(h2, d); }
     const bool some = ballot(any != 0u) != 0ull;
@@ -266,7 +286,8 @@ constexpr uint32_t DEDUPE_THREADS = 256;
 __global__ __launch_bounds__(DEDUPE_THREADS)
 void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, uint64_t in_stride, uint64_t nchunks_full, uint64_t nchunks,
                               const uint64_t* __restrict__ chunk_key, const uint64_t* __restrict__ tab_key,
-                              const uint32_t* __restrict__ tab_val, uint32_t tab_mask, uint32_t* __restrict__ dup_of)
+                              const uint32_t* __restrict__ tab_val, uint32_t tab_mask, uint32_t* __restrict__ dup_of,
+                              const uint32_t* __restrict__ piece_hash, const uint64_t* __restrict__ holes_map, uint64_t total)
 {
     const uint64_t k = blockIdx.x;
     __shared__ uint32_t s_rep;
@@ -287,13 +308,37 @@ void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, ui
     }
     __syncthreads();
     const uint32_t r = s_rep;
-    if (r >= k) { if (threadIdx.x == 0) dup_of[k] = (uint32_t)k; return; }     // (uniform) first of its kind
+    // HOLES (frames in place, see bitswap1_u16_regs): the all-zero 1 KiB pieces of the plane stream were never written; the map
+    // (lz4_dedupe_key_kernel: their number per chunk, then one bit per piece) says which.  They are filled in here for every chunk
+    // somebody is going to read: all but the chunks that are all zero AND a duplicate -- those are neither parsed (their frame is
+    // the first all-zero chunk's) nor ever stored raw.  Bit planes above the data's range are then neither written nor read; what
+    // is left to fill are the zero pieces inside chunks that also hold data.  (Nobody reads a hole before this kernel is over: the
+    // compare below goes by the markers.)
+    auto fill_holes = [&]() {
+        if (!holes_map) return;
+        const uint64_t left = total - k * chunk;
+        const uint32_t np = (uint32_t)((left < chunk ? left : chunk) >> 10);
+        const uint64_t* hm = holes_map + k * (1u + ((chunk >> 10) + 63u) / 64u);
+        if ((uint32_t)hm[0] == 0u) return;
+        uint8_t* body = const_cast<uint8_t*>(in) + k * in_stride;
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t pc = threadIdx.x >> 6; pc < np; pc += DEDUPE_THREADS / 64u) {
+            if (!((hm[1u + pc / 64u] >> (pc & 63u)) & 1ull)) continue;
+            const v4u zero = {0, 0, 0, 0};
+            *reinterpret_cast<v4u_any*>(body + (uint64_t)pc * 1024u + lane * 16u) = zero;
+        }
+    };
+    if (r >= k) { if (threadIdx.x == 0) dup_of[k] = (uint32_t)k; fill_holes(); return; }     // (uniform) first of its kind
     if (chunk_key[k] == 1ull) { if (threadIdx.x == 0) dup_of[k] = r; return; } // all zero, exactly: equal to the first all-zero chunk
+    fill_holes();
     // compare chunk k with chunk r (chunk is a multiple of 1 KiB here; chunk bodies may sit at any byte alignment)
     const v4u_any* a = reinterpret_cast<const v4u_any*>(in + k * in_stride);
     const v4u_any* b = reinterpret_cast<const v4u_any*>(in + (uint64_t)r * in_stride);
     const uint32_t nvec = chunk >> 4;
     uint32_t diff = 0;
+    // holes: pieces whose hash is the zero marker count as zeros, written or not (a wavefront's 64 x 16 bytes are exactly one piece)
+    const uint4* hk = reinterpret_cast<const uint4*>(piece_hash) + k * (chunk >> 10);
+    const uint4* hr = reinterpret_cast<const uint4*>(piece_hash) + (uint64_t)r * (chunk >> 10);
     for (uint32_t i = threadIdx.x; i < nvec; i += DEDUPE_THREADS * 4u) {
         // four independent 16-byte pairs in flight per thread
         v4u x[4], y[4];
@@ -301,8 +346,14 @@ void lz4_dedupe_verify_kernel(const uint8_t* __restrict__ in, uint32_t chunk, ui
         for (uint32_t u = 0; u < 4; ++u) {
             const uint32_t j = i + u * DEDUPE_THREADS;
             const v4u zero = {0, 0, 0, 0};
-            x[u] = j < nvec ? (v4u)a[j] : zero;
-            y[u] = j < nvec ? (v4u)b[j] : zero;
+            bool za = false, zb = false;
+            if (holes_map && j < nvec) {
+                const uint4 qa = hk[j >> 6], qb = hr[j >> 6];
+                za = (qa.x | qa.y | qa.z | qa.w) == 0u;
+                zb = (qb.x | qb.y | qb.z | qb.w) == 0u;
+            }
+            x[u] = (j < nvec && !za) ? (v4u)a[j] : zero;
+            y[u] = (j < nvec && !zb) ? (v4u)b[j] : zero;
         }
 #pragma unroll
         for (uint32_t u = 0; u < 4; ++u) diff |= (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y) | (x[u].z ^ y[u].z) | (x[u].w ^ y[u].w);
@@ -1408,31 +1459,38 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         continue;
                     }
                     if (qa + 4096u + 16u <= src_end) {
-                        // streaming: round k+1 is loaded while round k is compared
+                        // streaming: round k+1 is loaded while round k is compared.  Two register sets taking turns (the loop body
+                        // twice), both loaded unconditionally: handed over at the loop's end, or loaded under a condition ("maybe
+                        // defined" over the whole parse loop around this), the sets cost 64 registers more, and this cold loop
+                        // then sets the whole kernel's register count (172 -> 108) -- which decides how many waves of OTHER kernels
+                        // (the bit-plane transpose of the next call in flight) fit next to a resident chunk wave
                         uint4 ca[4], cb[4], na[4], nb[4];
+                        auto load_round = [&](uint4 (&xa)[4], uint4 (&xb)[4], uint32_t ipos) {
 #pragma unroll
-                        for (uint32_t t = 0; t < 4; ++t) {
-                            ca[t] = glb_ld_u128(w.src + qa + t * 1024u + (uint32_t)lane * 16u);
-                            cb[t] = glb_ld_u128(w.src + ra + t * 1024u + (uint32_t)lane * 16u);
-                        }
-                        bool stop = false;
-                        uint32_t at = qa;                                        // ip-side position of the round in ca/cb
-                        for (;;) {
-                            const bool more = at + 8192u + 16u <= src_end;       // another whole round behind this one
-                            if (more) {
-#pragma unroll
-                                for (uint32_t t = 0; t < 4; ++t) {
-                                    na[t] = glb_ld_u128(w.src + at + 4096u + t * 1024u + (uint32_t)lane * 16u);
-                                    nb[t] = glb_ld_u128(w.src + (at - qa + ra) + 4096u + t * 1024u + (uint32_t)lane * 16u);
-                                }
+                            for (uint32_t t = 0; t < 4; ++t) {
+                                xa[t] = glb_ld_u128(w.src + ipos + t * 1024u + (uint32_t)lane * 16u);
+                                xb[t] = glb_ld_u128(w.src + (ipos - qa + ra) + t * 1024u + (uint32_t)lane * 16u);
                             }
+                        };
+                        auto judge_round = [&](const uint4 (&xa)[4], const uint4 (&xb)[4]) -> bool {
 #pragma unroll
-                            for (uint32_t t = 0; t < 4; ++t) got[t] = first_diff16(ca[t], cb[t]);
-                            if (settle(got, 4u)) { stop = true; break; }
+                            for (uint32_t t = 0; t < 4; ++t) got[t] = first_diff16(xa[t], xb[t]);
+                            return settle(got, 4u);
+                        };
+                        load_round(ca, cb, qa);
+                        bool stop = false;
+                        uint32_t at = qa;                                        // ip-side position of the round about to be judged
+                        for (;;) {
+                            bool more = at + 8192u + 16u <= src_end;             // another whole round behind this one
+                            load_round(na, nb, more ? at + 4096u : at);          // (no other: the same round once more)
+                            if (judge_round(ca, cb)) { stop = true; break; }
                             if (!more) break;
                             at += 4096u;
-#pragma unroll
-                            for (uint32_t t = 0; t < 4; ++t) { ca[t] = na[t]; cb[t] = nb[t]; }
+                            more = at + 8192u + 16u <= src_end;
+                            load_round(ca, cb, more ? at + 4096u : at);
+                            if (judge_round(na, nb)) { stop = true; break; }
+                            if (!more) break;
+                            at += 4096u;
                         }
                         if (stop) break;
                         continue;
@@ -3354,10 +3412,11 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         return hipErrorInvalidValue;
     if (gap_chunk) {
         // frames in place: whole tiles only, chunks a power of two of at least one piece, `out` = body of chunk 0 (any alignment)
-        if (len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || gap_chunk < 1024u || (gap_chunk & (gap_chunk - 1u)))
+        // (and piece hashes: all-zero pieces are left unwritten, the hashes tell the readers which)
+        if (len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || gap_chunk < 1024u || (gap_chunk & (gap_chunk - 1u)) || !piece_hash)
             return hipErrorInvalidValue;
-        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 3) / 4, cap = (uint64_t)num_cus() * 16;
-        hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(256), 0, stream, in, out, n_tiles, len / 16,
+        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * 32;
+        hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(128), 0, stream, in, out, n_tiles, len / 16,
                            piece_hash, (uint32_t)__builtin_ctz(gap_chunk), side, side_w, X);
         return hipGetLastError();
     }
@@ -3396,7 +3455,7 @@ uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len
 }
 
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride)
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride, uint64_t* holes_map)
 {
     const uint64_t nchunks = (total + chunk - 1) / chunk, nfull = total / chunk;
     if (nchunks == 0) return hipSuccess;
@@ -3411,12 +3470,19 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(tab_val, 0xff, (size_t)tab * 4, stream);
     if (e != hipSuccess) return e;
-    if (nfull)
-        hipLaunchKernelGGL(lz4_dedupe_key_kernel, dim3((unsigned)nfull), dim3(64), 0, stream, piece_hash, chunk / 1024u, nfull, chunk_key, tab_key,
-                           tab_val, tab - 1u);
+    if (holes_map && total % 1024u != 0) return hipErrorInvalidValue;
+    const uint64_t nkey = holes_map ? nchunks : nfull;
+    if (nkey)
+        hipLaunchKernelGGL(lz4_dedupe_key_kernel, dim3((unsigned)nkey), dim3(64), 0, stream, piece_hash, chunk / 1024u, nfull, chunk_key, tab_key,
+                           tab_val, tab - 1u, holes_map, (uint32_t)((total - nfull * chunk) >> 10));
     hipLaunchKernelGGL(lz4_dedupe_verify_kernel, dim3((unsigned)nchunks), dim3(DEDUPE_THREADS), 0, stream, in, chunk, in_stride, nfull, nchunks, chunk_key,
-                       tab_key, tab_val, tab - 1u, dup_of);
+                       tab_key, tab_val, tab - 1u, dup_of, piece_hash, holes_map, total);
     return hipGetLastError();
+}
+
+uint64_t lz4_holes_map_bytes(uint64_t nchunks, uint32_t chunk)
+{
+    return nchunks * (1u + ((uint64_t)(chunk >> 10) + 63u) / 64u) * 8u;
 }
 
 uint64_t lz4_dedupe_work_bytes(uint64_t nchunks)
