@@ -155,7 +155,7 @@ __device__ __forceinline__ void transpose16x16_pairs(uint32_t r[16])
 // side != nullptr (diff3x3x1 right in front, see diff3x3x1_u16_rows_kernel): columns x < side_w of every row (X voxels, a multiple
 // of the 128 a lane owns) come from the compact buffer `side` (rows side_w voxels apart), everything else from `in`.
 template <bool GAP>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256)       // (launched in blocks of 128; bounds of 128 let the compiler take 173 registers instead of 127)
 void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words,
                        uint32_t* __restrict__ piece_hash, uint32_t gap_shift, const uint16_t* __restrict__ side, uint32_t side_w, uint32_t X)
 {
@@ -3415,7 +3415,7 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         // (and piece hashes: all-zero pieces are left unwritten, the hashes tell the readers which)
         if (len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || gap_chunk < 1024u || (gap_chunk & (gap_chunk - 1u)) || !piece_hash)
             return hipErrorInvalidValue;
-        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * 32;
+        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * 32;    // (blocks of two waves: see below)
         hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(128), 0, stream, in, out, n_tiles, len / 16,
                            piece_hash, (uint32_t)__builtin_ctz(gap_chunk), side, side_w, X);
         return hipGetLastError();
@@ -3427,13 +3427,15 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
     if (aligned) n_tiles = (seg_words * 16) / BSW_TILE_VOX;
     // piece hashes only when the tile kernel covers the whole buffer (see bitswap1_piece_hash_words)
     if (piece_hash && n_tiles * BSW_TILE_VOX != len) return hipErrorInvalidValue;
-    // the register-tile kernel, 16 blocks per CU.  It needs no LDS, so it runs next to the LZ4 chunk waves of other calls
-    // in flight (those hold nearly all of a CU's LDS)
+    // the register-tile kernel.  It needs no LDS, so it runs next to the LZ4 chunk waves of other calls in flight (those hold nearly
+    // all of a CU's LDS) -- in blocks of TWO waves: the waves of a block go to different SIMDs, and with chunk waves resident a block of
+    // four seldom finds room on all four at once (measured with three calls in flight: 0.78 ms per launch in blocks of four waves,
+    // 0.49 ms in blocks of two or one; alone 0.34 ms either way)
     if (n_tiles) {
-        const uint64_t want = (n_tiles + 3) / 4;
-        const uint64_t cap = (uint64_t)num_cus() * 16;
+        const uint64_t want = (n_tiles + 1) / 2;
+        const uint64_t cap = (uint64_t)num_cus() * 32;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
-        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(256), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u, side, side_w, X);
+        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(128), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u, side, side_w, X);
     }
     const uint64_t first_word = n_tiles * (BSW_TILE_VOX / 16);
     const uint64_t rest_words = seg_words - first_word;
@@ -3496,9 +3498,9 @@ hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hip
 {
     if (len == 0) return hipSuccess;
     const uint64_t seg = len / 8;
-    uint64_t blocks = (seg + 255) / 256;
+    uint64_t blocks = (seg + 127) / 128;                       // (blocks of two waves: they find room next to resident LZ4 chunk waves)
     if (blocks == 0) blocks = 1;
-    hipLaunchKernelGGL(bitswap1_u8_generic, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, len, seg);
+    hipLaunchKernelGGL(bitswap1_u8_generic, dim3((unsigned)blocks), dim3(128), 0, stream, in, out, len, seg);
     return hipGetLastError();
 }
 
