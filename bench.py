@@ -43,12 +43,19 @@ import time
 
 import numpy as np
 
+# HIP deals streams to hardware queues in creation order, FOUR queues by default: with the default stream in use that leaves three
+# caller streams a queue of their own, and a fourth caller shares one (its kernels never overlap the other's: measured 1250 GB/s
+# with four calls in flight against 1515 with three).  Eight queues, set before the HIP runtime starts: four calls in flight,
+# 1660 GB/s.  A deployment setting like the caller's thread count; the runtime reads it once, at its first call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PIPELINE = "bitswap1->lz4"
 SHAPE = (512, 1024, 1024)          # {z,y,x}: 1024x1024x512 voxels, uint16 -> 1 GiB
 HBM_PEAK_GBS = 8000.0              # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+SLABS_INFLIGHT = 3                 # slab calls in flight inside one Slabs call (--slabs-inflight)
 
 
 def lib_identity():
@@ -212,7 +219,7 @@ def secondary_configs(dev):
             for _ in range(3):                                 # (the first pass lets every context allocate its workspace)
                 torch.cuda.synchronize(); t0 = time.perf_counter()
                 rc, offs, sizes = sqeazy_amd.encode_slabs_device(pipeline, vol.data_ptr(), (nslabs * 256, 2048, 2048), np.uint16, nslabs,
-                                                                 buf.data_ptr(), cap, inflight=3)
+                                                                 buf.data_ptr(), cap, inflight=SLABS_INFLIGHT)
                 torch.cuda.synchronize(); dt = time.perf_counter() - t0
                 if rc:
                     raise RuntimeError("SQYAMD_PipelineEncode_Slabs_UI16_Device returned %d" % rc)
@@ -221,7 +228,7 @@ def secondary_configs(dev):
             algo = algo_per_voxel * nvox + sum(sizes)          # (payload + ~700 B of header per slab)
             out[key] = {"ms_total": round(best * 1e3, 2), "input_GBps": round(2 * nvox / best / 1e9, 1),
                         "roofline_frac": round(algo / best / 1e9 / HBM_PEAK_GBS, 5),
-                        "entry_point": "SQYAMD_PipelineEncode_Slabs_UI16_Device, one call, 3 slab calls in flight"}
+                        "entry_point": "SQYAMD_PipelineEncode_Slabs_UI16_Device, one call, %d slab calls in flight" % SLABS_INFLIGHT}
             del vol, buf
             torch.cuda.empty_cache()
         except Exception as e:   # reported, never required
@@ -247,6 +254,7 @@ def spawn_ranks(n, argv):
 
 
 def main():
+    global SLABS_INFLIGHT
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -256,12 +264,15 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="keep timing blocks of --steps steps until this much has been timed")
     ap.add_argument("--frames", type=int, default=SHAPE[0], help="z extent per GPU (default: the BASELINE config)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the second measurement with the RCCL gather to rank 0 inside the step")
-    ap.add_argument("--inflight", type=int, default=3,
+    ap.add_argument("--slabs-inflight", type=int, default=SLABS_INFLIGHT)
+    ap.add_argument("--inflight", type=int, default=4,
                     help="C-ABI calls in flight per GPU (host threads, one stream + workspace each; the C-ABI is re-entrant like "
-                         "the reference's).  1 = strictly one call after the other.  A call is three phases -- transpose (HBM), LZ4 "
-                         "parse (latency-bound, HBM idle), frame gather (HBM) -- so three calls keep every phase busy "
-                         "(measured: 1 -> 550, 2 -> 880, 3 -> 1035, 4 -> 850, 5 -> 950 GB/s)")
+                         "the reference's).  1 = strictly one call after the other.  A call is a chain of dependent kernels -- transpose "
+                         "(HBM), duplicate search, LZ4 parse (latency-bound, HBM mostly idle), frame gather -- so several calls keep "
+                         "every unit busy (measured in round 3, GPU_MAX_HW_QUEUES=8: 3 -> 1518, 4 -> 1665, 5 -> 1350, 6 -> 1550 GB/s; "
+                         "with the runtime's default of four hardware queues: 3 -> 1515, 4 -> 1250)")
     args = ap.parse_args()
+    SLABS_INFLIGHT = max(1, args.slabs_inflight)
 
     # (SQY_BENCH_FORCE_SPAWN=1: rehearsal of the self-launch on a one-GPU box)
     if (args.gpus > 1 or os.environ.get("SQY_BENCH_FORCE_SPAWN") == "1") and "WORLD_SIZE" not in os.environ:
@@ -444,6 +455,7 @@ def main():
                 shape[2], shape[1], shape[0], PIPELINE, mode,
                 ", slab blobs stay sharded on their GPUs, sizes all_gathered over RCCL" if world > 1 else ""),
                 "input_bytes_per_gpu": nbytes, "payload_bytes": payload_bytes, "blob_bytes": payload, "calls_in_flight_per_gpu": inflight,
+                "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
                 "single_call_latency_ms": round(single_ms, 4),
                 "one_call_at_a_time": {"value": round(nbytes / (single_ms / 1e3) / 1e9, 1), "unit": "GB/s",
                                        "roofline_frac_whole_call": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}},

@@ -1325,7 +1325,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // (Round 3 tried a tags-only fast path for batches that find nothing -- data that does not compress, the step schedule at 16
             // bytes and more: every probe enters itself with ds_max and the batch is PROVED empty from the tags in one LDS round trip.
             // Exact, an incompressible chunk 0.091 -> 0.064 ms, the 8-bit stack's LZ4 -14 %; but with it in the kernel the
-            // sequence-heavy chunks of the 16-bit stacks run 4..8 % slower (A/B on one box), which costs more than it saves.)
+            // sequence-heavy chunks of the 16-bit stacks run 4..8 % slower (A/B on one box), which costs more than it saves.
+            // Also tried: the sequences of the next eight batches kept in flight (DMA into the idle ring's slots, a batch reads its slot)
+            // -- exact as well, and no faster: a batch of these chunks is ~1 us of instructions and LDS round trips in this path, the
+            // HBM round trip of its strided reads is not what it waits for.)
             if (!batch_done) {
                 if (U != 0) SQY_REASON(6); else SQY_REASON(7);
                 const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
