@@ -1052,28 +1052,98 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     const uint64_t M = ballot(near && d >= 4u);
                     const uint64_t D = ballot(dup);
                     SQY_STAMP(21);
-                    // ---- the walk: uniform, registers only.  (Profiled in round 3: three quarters of a batch's time -- ~75 scalar
-                    // instructions per sequence at the 6..8 cycles a lone wave gets per instruction; now ~40: one folded exit test,
-                    // the record written with v_writelane, the inserted-probes mask derived after the walk from what it skipped.)
+                    // ---- the walk: uniform, registers only.  Sequence after sequence: first event lane at or behind the cursor -> literals,
+                    // catch-up, match length from that lane's `info` -> record (lane k of q_rec = sequence k) -> cursor behind the match.
+                    // Profiled in round 3: three quarters of a batch's time -- compiled from C++ a step was ~70 scalar instructions and
+                    // eight branches (~900 cycles at the rate a lone wave gets).  The common step -- an event lane that is a plain hit --
+                    // is now a hand-written scalar loop of ~30 instructions and one taken branch; it hands back to the C++ below for
+                    // the lanes that share a bucket with an earlier lane of the batch (reason 1) and ends the batch on a literal
+                    // limit (reason 2).  Which probes lie INSIDE matches (they do not enter the table) is no longer tracked step by
+                    // step: it is derived from the recorded sequences, in parallel, where somebody needs it.
                     uint32_t cur = 0, anc = 0, nseq = 0;                                // lane units; anchor == P on entry
-                    uint64_t nins = 0;                                                  // probes INSIDE matches: the ones that do not enter the table
                     uint32_t q_rec = 0;                                                 // lane k: sequence k, packed
+                    uint32_t q_fq = 0, q_ipn = 0;                                       // lane k: its probe lane and the lane behind its match
                     bool keep_dense = true;
                     uint64_t evm = M | D;                                               // lanes the walk has to look at
-                    while (cur < 64u && nseq < 16u) {
-                        const uint64_t ev = evm >> cur;
-                        if (!ev) break;                                                 // nothing more in this batch
-                        const uint32_t fq = cur + ctz64(ev);
+                    // probes inside the matches recorded so far: (fq, ipn) of every sequence but for ipn - 2 (LZ4_putPosition(ip - 2))
+                    auto inside_matches = [&]() -> uint64_t {
+                        const bool on = (uint32_t)lane < nseq;
+                        const uint32_t a1 = q_fq + 1u, e = q_ipn;                        // bits a1 .. e-1, minus bit e-2
+                        auto below = [](uint32_t x) -> uint64_t { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); };
+                        uint64_t m = on ? (below(e) & ~below(a1)) : 0ull;
+                        if (on && e - 2u < 64u) m &= ~(1ull << (e - 2u));
+                        uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
+                        // OR over the first row of 16 lanes (nseq <= 16), result in lane 15
+                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x111, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x111, 0xf, 0xf, false);
+                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x112, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x112, 0xf, 0xf, false);
+                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x114, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x114, 0xf, 0xf, false);
+                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x118, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x118, 0xf, 0xf, false);
+                        return ((uint64_t)lane_read(hi, 15) << 32) | lane_read(lo, 15);
+                    };
+                    for (;;) {
+                        uint32_t reason, fq, t0, t1, t2, t3, keep_m0;
+                        uint64_t ev;
+                        // reason 0: batch over (cursor past the batch, 16 sequences, or no event lane left); 1: event lane fq shares its
+                        // bucket with an earlier lane; 2: literal limit of lane fq (info bits 8..11) reached
+                        asm volatile(
+                            "s_mov_b32 %[km0], m0\n"
+                            "1:\n\t"
+                            "s_mov_b32 %[rsn], 0\n\t"
+                            "s_cmp_ge_u32 %[cur], 64\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_cmp_ge_u32 %[nseq], 16\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_lshr_b64 %[ev], %[evm], %[cur]\n\t"
+                            "s_cmp_eq_u64 %[ev], 0\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_ff1_i32_b64 %[t0], %[ev]\n\t"
+                            "s_add_u32 %[fq], %[cur], %[t0]\n\t"
+                            "s_mov_b32 %[rsn], 1\n\t"
+                            "s_bitcmp1_b64 %[dm], %[fq]\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "v_readlane_b32 %[t0], %[info], %[fq]\n\t"
+                            "s_sub_u32 %[t1], %[fq], %[anc]\n\t"                      // literals
+                            "s_bfe_u32 %[t2], %[t0], 0x40008\n\t"                     // literal limit
+                            "s_mov_b32 %[rsn], 2\n\t"
+                            "s_cmp_ge_u32 %[t1], %[t2]\n\t"
+                            "s_cbranch_scc1 3f\n\t"
+                            "s_bfe_u32 %[t2], %[t0], 0x30005\n\t"                     // equal bytes in front
+                            "s_min_u32 %[t2], %[t2], %[t1]\n\t"                       // back
+                            "s_and_b32 %[t3], %[t0], 31\n\t"                          // forward bytes
+                            "s_mov_b32 m0, %[nseq]\n\t"
+                            "v_writelane_b32 %[qfq], %[fq], m0\n\t"
+                            "s_add_u32 %[cur], %[fq], %[t3]\n\t"                      // behind the match
+                            "v_writelane_b32 %[qipn], %[cur], m0\n\t"
+                            "s_sub_u32 %[t1], %[t1], %[t2]\n\t"                       // literals - back
+                            "s_add_u32 %[t3], %[t3], %[t2]\n\t"
+                            "s_sub_u32 %[t3], %[t3], 4\n\t"                             // match code
+                            "s_lshl_b32 %[t3], %[t3], 4\n\t"
+                            "s_or_b32 %[t1], %[t1], %[t3]\n\t"
+                            "s_lshl_b32 %[t3], %[anc], 8\n\t"
+                            "s_or_b32 %[t1], %[t1], %[t3]\n\t"
+                            "s_and_b32 %[t0], %[t0], 0xffff0000\n\t"                  // offset
+                            "s_or_b32 %[t1], %[t1], %[t0]\n\t"
+                            "v_writelane_b32 %[qrec], %[t1], m0\n\t"
+                            "s_add_u32 %[nseq], %[nseq], 1\n\t"
+                            "s_mov_b32 %[anc], %[cur]\n\t"
+                            "s_branch 1b\n"
+                            "3:\n\t"
+                            "s_mov_b32 m0, %[km0]"
+                            : [rsn] "=&s"(reason), [fq] "=&s"(fq), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [km0] "=&s"(keep_m0),
+                              [ev] "=&s"(ev), [cur] "+s"(cur), [anc] "+s"(anc), [nseq] "+s"(nseq), [qrec] "+v"(q_rec), [qfq] "+v"(q_fq), [qipn] "+v"(q_ipn)
+                            : [evm] "s"(evm), [dm] "s"(D), [info] "v"(info)
+                            : "scc");
+                        if (reason == 0u) break;
+                        if (reason == 2u) { keep_dense = false; SQY_REASON(11); break; }
+                        // ---- lane fq shares its bucket with an earlier lane of this batch ----
+                        SQY_REASON(13); SQY_REASON(14);
                         bool is_hit = (M >> fq) & 1ull;
                         uint32_t inf = lane_read(info, fq);
-                        SQY_REASON(13);
-                        if ((D >> fq) & 1ull) {
-                            SQY_REASON(14);
-                            // an earlier lane of this batch hashes to the same bucket.  If one of them has entered the table by
-                            // now (a probe the parse passed over, or an ip - 2), the LATEST such lane is this probe's true
-                            // candidate -- both sequences sit in registers, compare them right here
+                        {
+                            // If one of the earlier lanes has entered the table by now (a probe the parse passed over, or an ip - 2), the
+                            // LATEST such lane is this probe's true candidate -- both sequences sit in registers, compare them right here
                             const uint32_t hf = lane_read(h, fq);
-                            const uint64_t passed = ~nins & ((1ull << fq) - 1ull);       // every probe in front of fq that is not inside a match
+                            const uint64_t passed = ~inside_matches() & ((1ull << fq) - 1ull);   // every probe in front of fq that is not inside a match
                             const uint64_t mates = ballot(h == hf) & passed;
                             if (mates) {
                                 const uint32_t qm = 63u - (uint32_t)__builtin_clzll(mates);
@@ -1096,21 +1166,19 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         if (lit >= ((inf >> 8) & 15u)) { keep_dense = false; SQY_REASON(11); break; }
                         const uint32_t df = inf & 31u, bkf = (inf >> 5) & 7u;
                         const uint32_t back = bkf < lit ? bkf : lit;
-                        // sequence k in lane k: literals | match code << 4 | anchor (lane units) << 8 | offset << 16
-                        {
-                            const uint32_t rec = (lit - back) | ((df - 4u + back) << 4) | (anc << 8) | (inf & 0xffff0000u);
-                            // (lane select through m0: two different SGPRs exceed the constant bus; "if (lane == nseq)" costs a compare
-                            // and a select plus their SGPR traffic)
-                            uint32_t keep_m0;
-                            asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
-                                : "+v"(q_rec), "=&s"(keep_m0) : "s"(rec), "s"(nseq));
-                        }
                         const uint32_t ipn = fq + df;                                   // behind the match (may lie beyond the batch)
-                        // the probes inside the match, fq + 1 .. ipn - 1, are skipped -- but for ipn - 2 (LZ4_putPosition(ip - 2))
-                        const uint64_t upto = ipn < 64u ? (1ull << ipn) : 0ull;         // (0 - x = every bit from x on)
-                        nins |= (upto - (2ull << fq)) & ~(ipn - 2u < 64u ? 1ull << (ipn - 2u) : 0ull);
+                        {
+                            // sequence k in lane k: literals | match code << 4 | anchor (lane units) << 8 | offset << 16
+                            const uint32_t rec = (lit - back) | ((df - 4u + back) << 4) | (anc << 8) | (inf & 0xffff0000u);
+                            // (lane select through m0: two different SGPRs exceed the constant bus)
+                            uint32_t km;
+                            asm("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
+                                "v_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
+                                : "+v"(q_rec), "+v"(q_fq), "+v"(q_ipn), "=&s"(km) : "s"(rec), "s"(fq), "s"(ipn), "s"(nseq));
+                        }
                         nseq += 1; anc = ipn; cur = ipn;
                     }
+                    const uint64_t nins = inside_matches();
                     // the probes the parse passed over enter the table: everything in front of the cursor that is not inside a match
                     const uint64_t ins = ~nins & (cur < 64u ? (1ull << cur) - 1ull : ~0ull);
                     SQY_REASON(8);
