@@ -28,6 +28,9 @@ static double now(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t);
 int main(int argc, char** argv)
 {
     if (argc < 5) { fprintf(stderr, "usage: slabs_c_test z y x nslabs [pipeline] [inflight]\n"); return 2; }
+    /* the HIP runtime deals streams to four hardware queues unless told otherwise, and kernels behind the same queue never overlap:
+     * eight queues for the slab calls in flight (read once, at the runtime's first call -- so first thing here) */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     const long Z = atol(argv[1]), Y = atol(argv[2]), X = atol(argv[3]);
     const int nslabs = atoi(argv[4]);
     const char* pipeline = argc > 5 ? argv[5] : "bitswap1->lz4";

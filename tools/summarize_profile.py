@@ -30,6 +30,15 @@ SHORT = {"lz4_chunks_kernel<false, false>": "lz4_chunks", "lz4_chunks_kernel<fal
          "lz4_dedupe_verify_kernel": "lz4_dedupe_verify"}
 
 
+def newest(pattern):
+    """the files of the most recent run only: gpurun merges a run's output into gpurun_out/ without removing what an earlier run left"""
+    files = glob.glob(pattern)
+    if not files:
+        return []
+    files.sort(key=os.path.getmtime)
+    return [files[-1]]
+
+
 def is_ours(name):
     return name.startswith("sqy::") or name.startswith("void sqy::")
 
@@ -44,12 +53,12 @@ def short(name):
 
 
 rows = []
-for f in glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
+for f in newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")):
     for r in csv.DictReader(open(f)):
         if is_ours(r["Name"]):
             rows.append(r)
 with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
-    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick  (defaults: 30 steps, 5 warm-up, 3 calls in flight)   (sqy:: kernels only)\n")
+    f.write("# rocprofv3 --kernel-trace --stats -- python3 bench.py --quick  (defaults: 30 steps, 5 warm-up, 4 calls in flight, GPU_MAX_HW_QUEUES=8)   (sqy:: kernels only)\n")
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "StdDev"])
     for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
@@ -57,7 +66,7 @@ with open(os.path.join(dst, "%s_kernel_stats.csv" % tag), "w") as f:
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("pmc_fetch", "pmc_write"):
-    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if is_ours(r["Kernel_Name"]):
                 pmc[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
@@ -82,7 +91,7 @@ json.dump({"library_sha256": sha, "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_S
 # wave-level counters (what the waves wait for), summed over the XCDs' instances of a launch, mean over launches
 sq = collections.defaultdict(lambda: collections.defaultdict(list))
 for name in ("pmc_sq1", "pmc_sq2", "pmc_sq3"):
-    for f in glob.glob(os.path.join(src, name, "*", "*_counter_collection.csv")):
+    for f in newest(os.path.join(src, name, "*", "*_counter_collection.csv")):
         per_launch = collections.defaultdict(float)
         for r in csv.DictReader(open(f)):
             if is_ours(r["Kernel_Name"]):
