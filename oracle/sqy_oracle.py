@@ -930,7 +930,9 @@ def pipeline_decode(blob):
                 v = v.reshape(h["shape"]) if v.size == n else v.reshape(1, 1, -1)
             else:
                 v = np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
-            out = np.empty_like(v)
+            # (frames with equal metrics: the map names one frame several times and others not at all -- those the reference leaves as
+            # its output buffer had them, frame_shuffle_utils.hpp:337-344; here, and in the product, they are zeros)
+            out = np.zeros_like(v)
             out[dmap.astype(np.int64)] = v
             cur = out
         else:

@@ -1205,14 +1205,23 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: no reorder_map in the header\n"); return 1; }
                 const std::vector<unsigned char> mapb = sqy::base64_decode(it->second.substr(10, it->second.size() - 21));
                 if (mapb.size() != Z * 8) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: malformed reorder_map\n"); return 1; }
+                std::vector<bool> targeted(Z, false);
+                bool permutation = true;
                 for (uint64_t i = 0; i < Z; ++i) {
                     uint64_t v; std::memcpy(&v, mapb.data() + 8 * i, 8);
                     if (v >= Z) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: reorder_map out of range\n"); return 1; }
+                    if (targeted[v]) permutation = false;
+                    targeted[v] = true;
                 }
                 if (ws->small.ensure(std::max<uint64_t>(Z * 8, 4096))) return 1;
                 SQY_HIP(hipMemcpyAsync(ws->small.p, mapb.data(), Z * 8, hipMemcpyHostToDevice, stream));
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
+                // Frames with equal metrics share ONE source frame in the encoder (std::find, frame_shuffle_utils.hpp:158-161): the map then
+                // names a frame twice and others not at all.  The reference's decode leaves the frames nobody names as the output
+                // buffer had them (frame_shuffle_utils.hpp:337-344); here they come out as zeros, not as whatever the
+                // workspace held.
+                if (!permutation) SQY_HIP(hipMemsetAsync(out, 0, stage_in_bytes, stream));
                 {
                     ProfScope ps("frame_scatter", stream, pend);
                     SQY_HIP(sqy::launch_frame_scatter(cur, out, Z, frame_bytes_dec, static_cast<const uint64_t*>(ws->small.p), stream));

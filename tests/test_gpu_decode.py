@@ -310,3 +310,20 @@ def test_diff_decode_one_launch_kernel_strip_geometries(sqy, oracle, shape):
     blob = oracle.pipeline_encode("diff3x3x1->lz4", vol)
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back, vol), shape
+
+
+def test_frame_shuffle_decode_with_equal_metrics(sqy, oracle):
+    """all-zero frames around the data: the encoder's map names frame 0 for every one of them (std::find), the frames nobody
+    names come out as zeros -- like the oracle's, not as workspace bytes"""
+    rng = np.random.default_rng(5)
+    vol = np.zeros((34, 95, 354), np.uint16)
+    vol[4:9:2] = rng.integers(0, 4000, (3, 95, 354))
+    vol[29:] = rng.integers(0, 60000, (5, 95, 354))
+    blob = oracle.pipeline_encode("frame_shuffle->lz4", vol)
+    # (dirty the decode workspace first: a volume of the same size full of ones)
+    rc, _ = sqy.decode(oracle.pipeline_encode("frame_shuffle->lz4", np.full(vol.shape, 0xFFFF, np.uint16)))
+    assert rc == 0
+    rc, back = sqy.decode(blob)
+    assert rc == 0
+    assert np.array_equal(back, oracle.pipeline_decode(blob))
+    assert np.array_equal(back, vol)

@@ -36,8 +36,16 @@ def data(shape, dtype, kind):
             p = int(rng.integers(1, 40)); run = int(rng.integers(4, 200))
             a[pos:pos + run] = np.tile(rng.integers(0, hi, p), run // p + 1)[:run]; pos += run
         a = a[:n]
-    else:                                                      # low-entropy bytes: many short matches
+    elif kind == 7:                                            # low-entropy bytes: many short matches
         a = rng.integers(0, 4, n) * (hi // 4)
+    elif kind == 8:                                            # noise with all-zero stretches (holes inside stored chunks)
+        a = rng.integers(0, hi, n); step = int(rng.integers(3, 400)) * 8192
+        for s0 in range(int(rng.integers(0, 8192)), n, step): a[s0:s0 + int(rng.integers(1, 3)) * 8192] = 0
+    else:                                                      # small values in a few blobs, zero elsewhere (zero pieces inside sparse chunks, empty top planes)
+        a = np.zeros(n, np.int64)
+        for _ in range(int(rng.integers(1, 6))):
+            s0 = int(rng.integers(0, n)); ln = int(rng.integers(1, max(2, n // 4)))
+            a[s0:s0 + ln] = rng.integers(0, 1 << int(rng.integers(1, 13)), min(ln, n - s0))
     return a.astype(dtype).reshape(shape)
 
 
@@ -57,7 +65,12 @@ while time.time() - t0 < budget:
     if "diff3x3x1" in pipe and rng.random() < 0.5:
         x = max(8, x - x % 8)                                   # the strip kernel's geometry
     nth = 1 if rng.random() < 0.3 else 0
-    vol = data((z, y, x), dtype, int(rng.integers(0, 8)))
+    if dtype == np.uint16 and rng.random() < 0.35:
+        # frames in place (and the holes in them): a 16-bit bitswap1 in front of a chunked lz4, whole tiles of 8192 voxels
+        pipe = str(rng.choice(["bitswap1->lz4", "diff3x3x1->bitswap1->lz4", "bitswap1->lz4(blocksize_kb=64,framestep_kb=64)"]))
+        y, x = max(64, y - y % 64), max(128, x - x % 128)
+        nth = 0
+    vol = data((z, y, x), dtype, int(rng.integers(0, 10)))
     try:
         want = o.pipeline_encode(pipe, vol, nthreads=nth)
     except (ValueError, NotImplementedError):
@@ -70,9 +83,8 @@ while time.time() - t0 < budget:
         sys.exit(1)
     rc, back = sqeazy_amd.decode(want)
     ref = o.pipeline_decode(want)
-    if rc == 0 and "frame_shuffle" in pipe and not np.array_equal(back, ref) and not np.array_equal(ref, vol):
-        skipped += 1          # frames with equal metrics share a source frame (std::find): the stage is not invertible, the reference's decode is not defined by the blob
-        continue
+    # (frames with equal metrics share a source frame (std::find): the stage is not invertible then; the frames the map does not name
+    # come out as zeros on both sides -- compared like everything else)
     if rc != 0 or not np.array_equal(back, ref):
         print("DECODE MISMATCH", pipe, (z, y, x), np.dtype(dtype).name, "nthreads", nth, "rc", rc, "seed", seed, "case", cases)
         sys.exit(1)
