@@ -237,6 +237,30 @@ def secondary_configs(dev):
     volume_in_flight(PIPELINE, 8, 2048, 2, "north_star 2048^3 u16 bitswap1->lz4, ONE Slabs call (8 slabs, three in flight)")
     volume_in_flight("diff3x3x1->bitswap1->lz4", 8, 2048, 2, "C3 2048^3 u16 diff3x3x1->bitswap1->lz4, ONE Slabs call (8 slabs, three in flight)")
     volume_in_flight("quantiser->bitswap1->lz4", 4, 1024, 4, "C5 2048x2048x1024 u16 quantiser->bitswap1->lz4, ONE Slabs call (4 slabs, three in flight)")
+    # the same north_star volume from a plain C program (tools/slabs_c_test.c, a child process: its own HIP runtime, no torch
+    # streams sharing the hardware queues with the library's) -- what a C caller of the entry point gets
+    try:
+        exe = os.path.join(ROOT, "sqeazy_amd", "bin", "slabs_c_test")
+        if os.path.exists(exe):
+            torch.cuda.synchronize()
+            r = subprocess.run([exe, "2048", "2048", "2048", "8", PIPELINE, str(SLABS_INFLIGHT)], capture_output=True, text=True, timeout=180)
+            ms = None
+            for ln in r.stdout.splitlines():
+                if ln.startswith("one call,"):
+                    ms = float(ln.split(":")[1].split("ms")[0])
+            if r.returncode == 0 and ms:
+                nvox = 2048 ** 3
+                payload = None
+                for ln in r.stdout.splitlines():
+                    if "blob bytes" in ln:
+                        payload = int(ln.split(";")[1].split("blob bytes")[0])
+                if payload:
+                    out["north_star 2048^3 u16 bitswap1->lz4, ONE Slabs call from a plain C program (tools/slabs_c_test.c, child process)"] = {
+                        "ms_total": round(ms, 2), "input_GBps": round(2 * nvox / (ms / 1e3) / 1e9, 1),
+                        "roofline_frac": round((2 * nvox + payload) / (ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
+                        "blobs_equal_single_calls": "blobs equal" in r.stdout}
+    except Exception as e:   # reported, never required
+        out["slabs_c_test"] = {"error": repr(e)}
     return out
 
 
