@@ -1052,23 +1052,22 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     const uint64_t M = ballot(near && d >= 4u);
                     const uint64_t D = ballot(dup);
                     SQY_STAMP(21);
-                    // ---- the walk: uniform, registers only.  Sequence after sequence: first event lane at or behind the cursor -> literals,
-                    // catch-up, match length from that lane's `info` -> record (lane k of q_rec = sequence k) -> cursor behind the match.
+                    // ---- the walk: uniform, registers only.  Sequence after sequence: first event lane at or behind the cursor -> its verdict
+                    // word (`info`) -> cursor behind the match; lane k of q_fq / q_inf records sequence k.
                     // Profiled in round 3: three quarters of a batch's time -- compiled from C++ a step was ~70 scalar instructions and
                     // eight branches (~900 cycles at the rate a lone wave gets).  The common step -- an event lane that is a plain hit --
-                    // is now a hand-written scalar loop of ~30 instructions and one taken branch; it hands back to the C++ below for
+                    // is a hand-written scalar loop of ~20 instructions and one taken branch; it hands back to the C++ below for
                     // the lanes that share a bucket with an earlier lane of the batch (reason 1) and ends the batch on a literal
-                    // limit (reason 2).  Which probes lie INSIDE matches (they do not enter the table) is no longer tracked step by
-                    // step: it is derived from the recorded sequences, in parallel, where somebody needs it.
-                    uint32_t cur = 0, anc = 0, nseq = 0;                                // lane units; anchor == P on entry
-                    uint32_t q_rec = 0;                                                 // lane k: sequence k, packed
-                    uint32_t q_fq = 0, q_ipn = 0;                                       // lane k: its probe lane and the lane behind its match
+                    // limit (reason 2).  Which probes lie INSIDE matches (they do not enter the table) is not tracked step by step:
+                    // it is derived from the recorded sequences, in parallel, where somebody needs it.
+                    uint32_t cur = 0, nseq = 0;                                         // lane units; the cursor is also the anchor of the next sequence
+                    uint32_t q_fq = 0, q_inf = 0;                                       // lane k: sequence k -- its probe lane and that lane's verdict word
                     bool keep_dense = true;
                     uint64_t evm = M | D;                                               // lanes the walk has to look at
                     // probes inside the matches recorded so far: (fq, ipn) of every sequence but for ipn - 2 (LZ4_putPosition(ip - 2))
                     auto inside_matches = [&]() -> uint64_t {
                         const bool on = (uint32_t)lane < nseq;
-                        const uint32_t a1 = q_fq + 1u, e = q_ipn;                        // bits a1 .. e-1, minus bit e-2
+                        const uint32_t a1 = q_fq + 1u, e = q_fq + (q_inf & 31u);        // bits a1 .. e-1, minus bit e-2
                         auto below = [](uint32_t x) -> uint64_t { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); };
                         uint64_t m = on ? (below(e) & ~below(a1)) : 0ull;
                         if (on && e - 2u < 64u) m &= ~(1ull << (e - 2u));
@@ -1081,8 +1080,14 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         return ((uint64_t)lane_read(hi, 15) << 32) | lane_read(lo, 15);
                     };
                     for (;;) {
-                        uint32_t reason, fq, t0, t1, t2, t3, keep_m0;
+                        uint32_t reason, fq, t0, t1, t2, keep_m0;
                         uint64_t ev;
+                        // (uniform by construction; said explicitly, the compiler otherwise hands the mask over in vector registers)
+                        const uint64_t evm_s = ((uint64_t)sgpr((uint32_t)(evm >> 32)) << 32) | sgpr((uint32_t)evm);
+                        SQY_STAMP(24);
+                        // The serial part of a step is only the chain cursor -> first event lane -> its forward bytes -> cursor: the loop
+                        // records the lane and its verdict word, what the sequence looks like (literals, catch-up, match code) is worked
+                        // out afterwards for all sequences at once, lane k = sequence k.
                         // reason 0: batch over (cursor past the batch, 16 sequences, or no event lane left); 1: event lane fq shares its
                         // bucket with an earlier lane; 2: literal limit of lane fq (info bits 8..11) reached
                         asm volatile(
@@ -1102,37 +1107,25 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                             "s_bitcmp1_b64 %[dm], %[fq]\n\t"
                             "s_cbranch_scc1 3f\n\t"
                             "v_readlane_b32 %[t0], %[info], %[fq]\n\t"
-                            "s_sub_u32 %[t1], %[fq], %[anc]\n\t"                      // literals
+                            "s_sub_u32 %[t1], %[fq], %[cur]\n\t"                      // literals
                             "s_bfe_u32 %[t2], %[t0], 0x40008\n\t"                     // literal limit
                             "s_mov_b32 %[rsn], 2\n\t"
                             "s_cmp_ge_u32 %[t1], %[t2]\n\t"
                             "s_cbranch_scc1 3f\n\t"
-                            "s_bfe_u32 %[t2], %[t0], 0x30005\n\t"                     // equal bytes in front
-                            "s_min_u32 %[t2], %[t2], %[t1]\n\t"                       // back
-                            "s_and_b32 %[t3], %[t0], 31\n\t"                          // forward bytes
                             "s_mov_b32 m0, %[nseq]\n\t"
+                            "s_and_b32 %[t1], %[t0], 31\n\t"                          // forward bytes
                             "v_writelane_b32 %[qfq], %[fq], m0\n\t"
-                            "s_add_u32 %[cur], %[fq], %[t3]\n\t"                      // behind the match
-                            "v_writelane_b32 %[qipn], %[cur], m0\n\t"
-                            "s_sub_u32 %[t1], %[t1], %[t2]\n\t"                       // literals - back
-                            "s_add_u32 %[t3], %[t3], %[t2]\n\t"
-                            "s_sub_u32 %[t3], %[t3], 4\n\t"                             // match code
-                            "s_lshl_b32 %[t3], %[t3], 4\n\t"
-                            "s_or_b32 %[t1], %[t1], %[t3]\n\t"
-                            "s_lshl_b32 %[t3], %[anc], 8\n\t"
-                            "s_or_b32 %[t1], %[t1], %[t3]\n\t"
-                            "s_and_b32 %[t0], %[t0], 0xffff0000\n\t"                  // offset
-                            "s_or_b32 %[t1], %[t1], %[t0]\n\t"
-                            "v_writelane_b32 %[qrec], %[t1], m0\n\t"
+                            "v_writelane_b32 %[qinf], %[t0], m0\n\t"
+                            "s_add_u32 %[cur], %[fq], %[t1]\n\t"                      // behind the match
                             "s_add_u32 %[nseq], %[nseq], 1\n\t"
-                            "s_mov_b32 %[anc], %[cur]\n\t"
                             "s_branch 1b\n"
                             "3:\n\t"
                             "s_mov_b32 m0, %[km0]"
-                            : [rsn] "=&s"(reason), [fq] "=&s"(fq), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [t3] "=&s"(t3), [km0] "=&s"(keep_m0),
-                              [ev] "=&s"(ev), [cur] "+s"(cur), [anc] "+s"(anc), [nseq] "+s"(nseq), [qrec] "+v"(q_rec), [qfq] "+v"(q_fq), [qipn] "+v"(q_ipn)
-                            : [evm] "s"(evm), [dm] "s"(D), [info] "v"(info)
+                            : [rsn] "=&s"(reason), [fq] "=&s"(fq), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [km0] "=&s"(keep_m0),
+                              [ev] "=&s"(ev), [cur] "+s"(cur), [nseq] "+s"(nseq), [qfq] "+v"(q_fq), [qinf] "+v"(q_inf)
+                            : [evm] "s"(evm_s), [dm] "s"(D), [info] "v"(info)
                             : "scc");
+                        SQY_STAMP(25);
                         if (reason == 0u) break;
                         if (reason == 2u) { keep_dense = false; SQY_REASON(11); break; }
                         // ---- lane fq shares its bucket with an earlier lane of this batch ----
@@ -1141,42 +1134,42 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         uint32_t inf = lane_read(info, fq);
                         {
                             // If one of the earlier lanes has entered the table by now (a probe the parse passed over, or an ip - 2), the
-                            // LATEST such lane is this probe's true candidate -- both sequences sit in registers, compare them right here
+                            // LATEST such lane is this probe's true candidate.  Earlier lanes of the bucket, latest first; a lane has entered
+                            // the table unless it lies strictly inside a recorded match (and is not that match's ip - 2) -- asked of the
+                            // sequence lanes directly, the whole mask of such probes is not needed for one lane.
                             const uint32_t hf = lane_read(h, fq);
-                            const uint64_t passed = ~inside_matches() & ((1ull << fq) - 1ull);   // every probe in front of fq that is not inside a match
-                            const uint64_t mates = ballot(h == hf) & passed;
-                            if (mates) {
-                                const uint32_t qm = 63u - (uint32_t)__builtin_clzll(mates);
-                                const uint32_t x0 = lane_read(s16.x, fq) ^ lane_read(s16.x, qm);
-                                const uint32_t x1 = lane_read(s16.y, fq) ^ lane_read(s16.y, qm);
-                                const uint32_t x2 = lane_read(s16.z, fq) ^ lane_read(s16.z, qm);
-                                const uint32_t x3 = lane_read(s16.w, fq) ^ lane_read(s16.w, qm);
+                            uint64_t mates = ballot(h == hf) & ((1ull << fq) - 1ull);
+                            const uint32_t s_ipn = q_fq + (q_inf & 31u);
+                            uint32_t qm = 64u;
+                            while (mates) {
+                                const uint32_t c = 63u - (uint32_t)__builtin_clzll(mates);
+                                mates &= ~(1ull << c);
+                                if (!ballot((uint32_t)lane < nseq && q_fq < c && c < s_ipn && c + 2u != s_ipn)) { qm = c; break; }
+                            }
+                            qm = sgpr(qm);
+                            if (qm < 64u) {
+                                // both sequences sit in registers: lane qm's 16 + 4 bytes go to every lane, each compares its own against
+                                // them (one vector pass instead of ten lane reads and a scalar compare chain), lane fq's result counts
+                                const uint4 cq = make_uint4(lane_read(s16.x, qm), lane_read(s16.y, qm), lane_read(s16.z, qm), lane_read(s16.w, qm));
+                                const uint32_t dq = lane_read(first_diff16(s16, cq), fq);
                                 const uint32_t xbq = lane_read(b4, fq) ^ lane_read(b4, qm);
-                                is_hit = x0 == 0;
-                                const uint32_t dq = x0 ? ((uint32_t)__builtin_ctz(x0) >> 3) : x1 ? 4u + ((uint32_t)__builtin_ctz(x1) >> 3)
-                                                  : x2 ? 8u + ((uint32_t)__builtin_ctz(x2) >> 3) : x3 ? 12u + ((uint32_t)__builtin_ctz(x3) >> 3) : 16u;
+                                is_hit = dq >= 4u;
                                 const uint32_t bq = xbq ? ((uint32_t)__builtin_clz(xbq) >> 3) : 4u;
                                 const uint32_t ml1 = (dq == 16u || P + qm < 16u) ? 0u : (bq == 4u ? 5u : 15u);
                                 inf = dq | (bq << 5) | (ml1 << 8) | ((fq - qm) << 16);
                                 SQY_REASON(10);
                             }
                         }
-                        if (!is_hit) { evm &= ~(1ull << fq); continue; }                 // (a same-bucket lane that is no match: one more probe passed)
-                        const uint32_t lit = fq - anc;
-                        if (lit >= ((inf >> 8) & 15u)) { keep_dense = false; SQY_REASON(11); break; }
-                        const uint32_t df = inf & 31u, bkf = (inf >> 5) & 7u;
-                        const uint32_t back = bkf < lit ? bkf : lit;
-                        const uint32_t ipn = fq + df;                                   // behind the match (may lie beyond the batch)
+                        if (!is_hit) { evm &= ~(1ull << fq); SQY_STAMP(26); continue; }  // (a same-bucket lane that is no match: one more probe passed)
+                        if (fq - cur >= ((inf >> 8) & 15u)) { keep_dense = false; SQY_REASON(11); break; }
                         {
-                            // sequence k in lane k: literals | match code << 4 | anchor (lane units) << 8 | offset << 16
-                            const uint32_t rec = (lit - back) | ((df - 4u + back) << 4) | (anc << 8) | (inf & 0xffff0000u);
                             // (lane select through m0: two different SGPRs exceed the constant bus)
                             uint32_t km;
-                            asm("s_mov_b32 %3, m0\n\ts_mov_b32 m0, %7\n\tv_writelane_b32 %0, %4, m0\n\tv_writelane_b32 %1, %5, m0\n\t"
-                                "v_writelane_b32 %2, %6, m0\n\ts_mov_b32 m0, %3"
-                                : "+v"(q_rec), "+v"(q_fq), "+v"(q_ipn), "=&s"(km) : "s"(rec), "s"(fq), "s"(ipn), "s"(nseq));
+                            asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
+                                : "+v"(q_fq), "+v"(q_inf), "=&s"(km) : "s"(fq), "s"(inf), "s"(nseq));
                         }
-                        nseq += 1; anc = ipn; cur = ipn;
+                        nseq += 1; cur = fq + (inf & 31u);                              // behind the match (may lie beyond the batch)
+                        SQY_STAMP(26);
                     }
                     const uint64_t nins = inside_matches();
                     // the probes the parse passed over enter the table: everything in front of the cursor that is not inside a match
@@ -1192,7 +1185,14 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     // ---- write the sequences: lane k = sequence k ----
                     {
                         const bool on = (uint32_t)lane < nseq;
-                        const uint32_t q_lit = q_rec & 15u, q_mc = (q_rec >> 4) & 15u, q_anc = (q_rec >> 8) & 0xffu, q_off = q_rec >> 16;
+                        // sequence k from its probe lane and verdict word: the anchor is where the sequence in front of it ended (lane k - 1,
+                        // one DPP step; 0 for the first), the catch-up takes what the literals and the bytes known equal in front allow
+                        const uint32_t q_df = q_inf & 31u, q_bk = (q_inf >> 5) & 7u, q_off = q_inf >> 16;
+                        const uint32_t q_ipn = q_fq + q_df;
+                        const uint32_t q_anc = __builtin_amdgcn_update_dpp(0u, q_ipn, 0x111, 0xf, 0xf, false);   // row_shr:1
+                        const uint32_t q_lit0 = q_fq - q_anc;
+                        const uint32_t q_back = q_bk < q_lit0 ? q_bk : q_lit0;
+                        const uint32_t q_lit = q_lit0 - q_back, q_mc = q_df - 4u + q_back;
                         const uint32_t ext = q_mc >= 15u ? 1u : 0u;                     // match code <= 15: at most one extension byte (0)
                         const uint32_t sb = on ? 1u + q_lit + 2u + ext : 0u;
                         uint32_t inc = sb;                                              // inclusive prefix sum over the first 16 lanes (one DPP row)
