@@ -342,6 +342,35 @@ def main():
 
     last_at = [(0, 0, 0)]            # (thread, buffer, offset) of the blob of the last step taken
 
+    # the caller threads live as long as the run (an application's encoder threads do); a block of steps is handed to them as a job
+    job_q = [queue.Queue() for _ in range(inflight)]
+
+    def caller(t):
+        torch.cuda.set_device(local_rank)
+        while True:
+            job = job_q[t].get()
+            if job is None:
+                return
+            k, free_qt, done_q, stop, errors = job
+            try:
+                for s_ in range(t, k, inflight):
+                    b = free_qt.get()
+                    if b is None or stop.is_set():
+                        break
+                    rc, off, n = sqeazy_amd.encode_device_at(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[t][b].data_ptr(), cap, nthreads=0,
+                                                             stream=streams[t].cuda_stream)
+                    if rc:
+                        raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
+                    done_q.put((s_, t, b, n, off))
+            except Exception as e:   # pragma: no cover
+                errors.append(e)
+                done_q.put((-1, t, 0, 0, 0))
+            done_q.put((-2, t, 0, 0, 0))          # this thread's share of the block is over
+
+    callers = [threading.Thread(target=caller, args=(t,), daemon=True) for t in range(inflight)]
+    for th in callers:
+        th.start()
+
     def run_steps(k, gather=False):
         """k steps: thread t encodes steps t, t+inflight, ...; the main thread takes them in step order and either exchanges the
         sizes (sharded container) or hands the blob to the gatherer (overlapped gather to rank 0), then recycles the buffer"""
@@ -352,31 +381,19 @@ def main():
             fq.put(1)
         errors = []
         stop = threading.Event()
-
-        def worker(t):
-            try:
-                torch.cuda.set_device(local_rank)
-                for s_ in range(t, k, inflight):
-                    b = free_q[t].get()
-                    if b is None or stop.is_set():
-                        return
-                    rc, off, n = sqeazy_amd.encode_device_at(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[t][b].data_ptr(), cap, nthreads=0,
-                                                             stream=streams[t].cuda_stream)
-                    if rc:
-                        raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
-                    done_q.put((s_, t, b, n, off))
-            except Exception as e:   # pragma: no cover
-                errors.append(e)
-                done_q.put((-1, t, 0, 0, 0))
-
-        threads = [threading.Thread(target=worker, args=(t,)) for t in range(min(inflight, max(k, 1)))]
-        for th in threads:
-            th.start()
-        pending, nxt, last_n = {}, 0, 0
-        while nxt < k:
+        for t in range(inflight):
+            job_q[t].put((k, free_q[t], done_q, stop, errors))
+        pending, nxt, last_n, finished = {}, 0, 0, 0
+        while finished < inflight:
             s_, t, b, n, off = done_q.get()
+            if s_ == -2:
+                finished += 1
+                continue
             if s_ < 0:
-                break
+                stop.set()
+                for fq in free_q:                    # wake every caller thread that waits for a buffer, then fail loudly
+                    fq.put(None)
+                continue
             pending[s_] = (t, b, n, off)
             while nxt in pending:
                 t2, b2, n2, off2 = pending.pop(nxt)
@@ -391,12 +408,6 @@ def main():
                     free_q[t2].put(b2)
                 last_n = n2
                 nxt += 1
-        if errors:
-            stop.set()
-            for fq in free_q:                    # wake every caller thread that waits for a buffer, then fail loudly
-                fq.put(None)
-        for th in threads:
-            th.join()
         if dist_on and gather:
             gatherer.drain()
         if errors:
@@ -454,6 +465,10 @@ def main():
     sqeazy_amd.profile_enable(False)
     prof_alone = sqeazy_amd.profile_get()
     fence()
+    for q in job_q:                      # the caller threads are done
+        q.put(None)
+    for th in callers:
+        th.join()
 
     if rank == 0:
         dt = statistics.median(times)
