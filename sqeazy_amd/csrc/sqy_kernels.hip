@@ -2114,13 +2114,13 @@ void frame_metric_i8_kernel(const int8_t* __restrict__ in, uint64_t Z, uint64_t 
 }
 
 // Block-parallel EXACT evaluation of the same sequential binary32 sum.
-// While the running sum S (an integer) stays inside one binade [2^e, 2^(e+1)) with ulp u = 2^(e-23) >= 2, adding an
-// integer v rounds S+v to a multiple of u (ties to the even multiple).  With r = v mod u, d = v div u and p = parity of
-// S/u:  r < u/2 rounds down (delta -r), r > u/2 rounds up (delta u-r), r == u/2 is a tie: down when p^(d&1) == 0, else up,
-// and the parity after a tie is always 0.  So apart from ties every element is "parity ^= c, delta += const": a wave
-// splits a 4 KiB block over its 64 lanes, each lane walks its 64 bytes once (tracking what happens before its first tie
-// symbolically), and the 64 lane results are chained in lane order.  Blocks that may cross into the next binade (at most
-// a dozen per frame) are added by the lanes one after the other with real v_add_f32.  Below 2^24 everything is exact.
+// While the running sum S (an integer) stays inside one binade [2^e, 2^(e+1)) with ulp u = 2^(e-23) >= 2, adding an integer v
+// rounds S + v to a multiple of u (ties to the even multiple): how it rounds depends on v, on the binade and on the PARITY of S / u,
+// on nothing else of S.  So what a run of elements does to the sum is a map  parity in -> (increment, parity out), maps compose, and a
+// map is obtained by letting the hardware's float add do the rounding on a stand-in for S with the right binade and parity
+// (FmBlock::lane_map).  A wave splits a 4 KiB block over its 64 lanes, each lane adds its 64 bytes to both stand-ins, the 64 lane maps
+// are composed in lane order by a tree (FmBlock::block_map).  Blocks that may cross into the next binade (at most a dozen per frame)
+// are added by the lanes one after the other, starting from the real sum.  Below 2^24 everything is exact.
 // Checked against numpy's sequential float32 cumsum (tests) and, end to end, against the oracle's C loop.
 // building blocks of the exact evaluation, one 4 KiB block of a frame per wavefront step
 template <typename T>
@@ -2154,60 +2154,32 @@ struct FmBlock {
         for (int o = 32; o >= 1; o >>= 1) tot += __shfl_xor(tot, o);
         return sgpr(tot);
     }
-    // what this lane's elements do to the running sum in regime k: flags = seen-a-tie | C0 << 1 | parity-after << 2
-    static __device__ __forceinline__ void lanes(const uint32_t x[EPL], uint32_t k, uint32_t& flags, int32_t& D0, int32_t& Df)
+    // What this lane's elements do to the running sum while it stays in the binade of regime k (ulp u = 2^k): a map
+    //   parity of S / u coming in  ->  (exact increment of S, parity going out).
+    // Only that parity and the binade decide how S + v rounds, so the lane simply ADDS ITS ELEMENTS WITH THE HARDWARE'S FLOAT ADD to
+    // two stand-ins for S -- 2^e (parity 0) and 2^e + u (parity 1), e = 23 + k -- : same binade, same parity, hence the same
+    // roundings as the real sum, 64 bytes cannot leave the binade from there, and the stand-in's last mantissa bit is the parity going
+    // out.  Two v_add_f32 and a convert per element.  (Round 2 tracked remainders, ties and parities symbolically: ~14 instructions per
+    // element, the block-record kernel was compute-bound at 0.48 ms per GiB.)
+    static __device__ __forceinline__ void lane_map(const uint32_t x[EPL], uint32_t k, uint32_t& q, int32_t& i0, int32_t& i1)
     {
-        const uint32_t u = 1u << k, half = u >> 1, um = u - 1u;
-        uint32_t seen = 0, C0 = 0, pcur = 0;
-        D0 = 0; Df = 0;
+        const uint32_t bits = (k + 23u + 127u) << 23;
+        const float b0 = __builtin_bit_cast(float, bits), b1 = __builtin_bit_cast(float, bits | 1u);
+        float s0 = b0, s1 = b1;
 #pragma unroll
         for (uint32_t i = 0; i < EPL; ++i) {
-            const uint32_t r = x[i] & um, dbit = (x[i] >> k) & 1u;
-            const bool tie = r == half, up = r > half;
-            const int32_t dl_nt = up ? (int32_t)(u - r) : -(int32_t)r;  // delta of a non-tie
-            if (!seen) {
-                if (tie) { seen = 1; C0 ^= dbit; pcur = 0; }             // its own delta is settled when the lanes are chained
-                else { C0 ^= dbit ^ (up ? 1u : 0u); D0 += dl_nt; }
-            } else {
-                const uint32_t base = pcur ^ dbit;
-                if (tie) { Df += base ? (int32_t)half : -(int32_t)half; pcur = 0; }
-                else { Df += dl_nt; pcur = base ^ (up ? 1u : 0u); }
-            }
+            const float f = (float)x[i];
+            s0 = s0 + f;
+            s1 = s1 + f;
         }
-        flags = seen | (C0 << 1) | (pcur << 2);
+        q = (__builtin_bit_cast(uint32_t, s0) & 1u) | ((__builtin_bit_cast(uint32_t, s1) & 1u) << 1);   // parity out for parity in 0 | parity in 1 << 1
+        i0 = (int32_t)(s0 - b0);                                       // exact: both multiples of u, less than 2^24 apart
+        i1 = (int32_t)(s1 - b1);
     }
-    // the 64 lane results in lane order, starting from parity par: returns the total delta, par becomes the parity after
-    static __device__ __forceinline__ int64_t chain(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, uint32_t& par)
+    // The 64 lane maps in lane order as an ordered tree reduction: maps compose associatively, six rounds of "lower lanes' map, then
+    // upper lanes' map" leave the whole block's map in lane 0 (~70 instructions): increment and parity out for both parities in.
+    static __device__ __forceinline__ void block_map(uint32_t q, int32_t d0, int32_t d1, int32_t& inc0, uint32_t& par0, int32_t& inc1, uint32_t& par1)
     {
-        const int32_t half = (int32_t)((1u << k) >> 1);
-        int64_t delta = 0;
-        for (int L = 0; L < 64; ++L) {
-            const uint32_t fl = lane_read(flags, L);
-            const int32_t d0 = (int32_t)lane_read((uint32_t)D0, L);
-            if (fl & 1u) {
-                const uint32_t base = par ^ ((fl >> 1) & 1u);
-                delta += d0 + (base ? half : -half) + (int32_t)lane_read((uint32_t)Df, L);
-                par = (fl >> 2) & 1u;
-            } else {
-                delta += d0;
-                par ^= (fl >> 1) & 1u;
-            }
-        }
-        return delta;
-    }
-    // The same for BOTH starting parities, as an ordered tree reduction instead of a walk over the 64 lanes: what a lane's elements
-    // do to the running sum is a map  parity in -> (parity out, delta)  -- without a tie  p -> (p ^ C0, D0), with one
-    // p -> (parity after its last tie, D0 +- half + Df), the sign from p ^ C0 -- and maps compose associatively: six rounds of
-    // "lower lane's map, then upper lane's map" leave the whole block's map in lane 0 (~70 instructions instead of ~1000).
-    static __device__ __forceinline__ void chain2_tree(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, int32_t& delta0, uint32_t& par0,
-                                                       int32_t& delta1, uint32_t& par1)
-    {
-        const int32_t half = (int32_t)((1u << k) >> 1);
-        const uint32_t seen = flags & 1u, C0 = (flags >> 1) & 1u, pc = (flags >> 2) & 1u;
-        // this lane's map: q = parity out for parity in 0 | parity in 1 << 1; d0 / d1 = delta for parity in 0 / 1
-        uint32_t q = seen ? (pc | (pc << 1)) : (C0 | ((C0 ^ 1u) << 1));
-        int32_t d0 = seen ? D0 + (C0 ? half : -half) + Df : D0;
-        int32_t d1 = seen ? D0 + (C0 ? -half : half) + Df : D0;
 #pragma unroll
         for (int s_ = 1; s_ < 64; s_ <<= 1) {
             // the map of the 2 s_ lanes that start here = (upper s_ lanes) after (lower s_ lanes); only lanes that are a multiple of
@@ -2220,28 +2192,7 @@ struct FmBlock {
             q = ((uq >> m0) & 1u) | (((uq >> m1) & 1u) << 1);
         }
         par0 = lane_read(q, 0) & 1u; par1 = (lane_read(q, 0) >> 1) & 1u;
-        delta0 = (int32_t)lane_read((uint32_t)d0, 0); delta1 = (int32_t)lane_read((uint32_t)d1, 0);
-    }
-    // both starting parities in one pass over the lanes (the serial form of chain2_tree)
-    static __device__ __forceinline__ void chain2(uint32_t flags, int32_t D0, int32_t Df, uint32_t k, int32_t& delta0, uint32_t& par0,
-                                                  int32_t& delta1, uint32_t& par1)
-    {
-        const int32_t half = (int32_t)((1u << k) >> 1);
-        par0 = 0; par1 = 1; delta0 = 0; delta1 = 0;
-        for (int L = 0; L < 64; ++L) {
-            const uint32_t fl = lane_read(flags, L);
-            const int32_t d0 = (int32_t)lane_read((uint32_t)D0, L);
-            if (fl & 1u) {
-                const int32_t df = (int32_t)lane_read((uint32_t)Df, L);
-                const uint32_t c = (fl >> 1) & 1u;
-                delta0 += d0 + ((par0 ^ c) ? half : -half) + df;
-                delta1 += d0 + ((par1 ^ c) ? half : -half) + df;
-                par0 = par1 = (fl >> 2) & 1u;
-            } else {
-                delta0 += d0; delta1 += d0;
-                par0 ^= (fl >> 1) & 1u; par1 ^= (fl >> 1) & 1u;
-            }
-        }
+        inc0 = (int32_t)lane_read((uint32_t)d0, 0); inc1 = (int32_t)lane_read((uint32_t)d1, 0);
     }
     // the block may change binade: lanes add their elements one after the other with the hardware's float add
     static __device__ __forceinline__ uint64_t sequential(const uint32_t x[EPL], uint64_t S, int lane)
@@ -2264,10 +2215,10 @@ struct FmBlock {
             const uint32_t e = 63u - (uint32_t)__builtin_clzll(S);
             const uint32_t k = e - 23u;
             if (S + tot + (uint64_t)BLK * ((1ull << k) >> 1) < (1ull << (e + 1))) {
-                uint32_t flags; int32_t D0, Df;
-                lanes(x, k, flags, D0, Df);
-                uint32_t par = (uint32_t)(S >> k) & 1u;
-                return (uint64_t)((int64_t)(S + tot) + chain(flags, D0, Df, k, par));
+                uint32_t q, p0, p1; int32_t i0, i1, inc0, inc1;
+                lane_map(x, k, q, i0, i1);
+                block_map(q, i0, i1, inc0, p0, inc1, p1);
+                return (uint64_t)((int64_t)S + (((uint32_t)(S >> k) & 1u) ? inc1 : inc0));
             }
         }
         return sequential(x, S, lane);
@@ -2340,10 +2291,10 @@ void frame_block_summaries_kernel(const T* __restrict__ in, uint64_t per_frame, 
         if (P + tot + (uint64_t)B::BLK * ((1ull << k) >> 1) < (1ull << (e + 1))) {
             uint32_t x[B::EPL];
             B::load(in + z * per_frame, per_frame, b, lane, x);
-            uint32_t flags; int32_t D0, Df;
-            B::lanes(x, k, flags, D0, Df);
-            uint32_t p0, p1;
-            B::chain2_tree(flags, D0, Df, k, r.d0, p0, r.d1, p1);
+            uint32_t q, p0, p1; int32_t i0, i1, inc0, inc1;
+            B::lane_map(x, k, q, i0, i1);
+            B::block_map(q, i0, i1, inc0, p0, inc1, p1);
+            r.d0 = inc0 - (int32_t)tot; r.d1 = inc1 - (int32_t)tot;   // (the chain adds the block's integer sum itself)
             r.info = 1u | (k << 8) | (p0 << 16) | (p1 << 17);
         }
     }
