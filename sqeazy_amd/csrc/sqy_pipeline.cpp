@@ -782,11 +782,17 @@ void frame_shuffle_order(const float* sums, size_t Z, size_t per_frame, uint64_t
 {
     std::vector<float> metric(Z);
     for (size_t z = 0; z < Z; ++z) metric[z] = sums[z] / per_frame;          // float / size_t
-    std::vector<float> sorted_metric = metric;
-    std::sort(sorted_metric.begin(), sorted_metric.end());
+    // The reference sorts the metrics and looks every sorted value up with std::find (frame_shuffle_utils.hpp:138-161): slot i gets
+    // the FIRST frame whose metric equals the i-th smallest.  The same map in Z log Z instead of Z^2 compares (0.3 ms of host time per
+    // call at 1024 frames): a stable argsort puts the frames of equal metric in index order, every slot of such a run takes the run's
+    // first frame.
+    std::vector<uint32_t> idx(Z);
+    for (size_t z = 0; z < Z; ++z) idx[z] = (uint32_t)z;
+    std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return metric[a] < metric[b]; });
+    uint32_t first = 0;
     for (size_t i = 0; i < Z; ++i) {
-        const auto it = std::find(metric.begin(), metric.end(), sorted_metric[i]);
-        decode_map[i] = (uint64_t)std::distance(metric.begin(), it);
+        if (i == 0 || !(metric[idx[i]] == metric[idx[i - 1]])) first = idx[i];
+        decode_map[i] = first;
     }
 }
 
