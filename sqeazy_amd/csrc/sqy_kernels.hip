@@ -1390,17 +1390,47 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // generic path: any step schedule, chunk borders, hazards -- exact but slower
             // ---------------------------------------------------------------------------------------
             if (pend) { emit_pending(); if (failed) break; }
-            // (Round 3 tried a tags-only fast path for batches that find nothing -- data that does not compress, the step schedule at 16
-            // bytes and more: every probe enters itself with ds_max and the batch is PROVED empty from the tags in one LDS round trip.
-            // Exact, an incompressible chunk 0.091 -> 0.064 ms, the 8-bit stack's LZ4 -14 %; but with it in the kernel the
-            // sequence-heavy chunks of the 16-bit stacks run 4..8 % slower (A/B on one box), which costs more than it saves.
-            // Also tried: the sequences of the next eight batches kept in flight (DMA into the idle ring's slots, a batch reads its slot)
-            // -- exact as well, and no faster: a batch of these chunks is ~1 us of instructions and LDS round trips in this path, the
+            // (Round 3, measured without gain and not kept:
+            // the sequences of the next eight batches of incompressible data kept in flight (DMA into the idle ring's slots, a batch reads its slot)
+            // -- exact, and no faster: a batch of these chunks is ~1 us of instructions and LDS round trips in this path, the
             // HBM round trip of its strided reads is not what it waits for.
             // And the lean loop's scalar bookkeeping (loop bounds cached, ONE arithmetic test for everything unusual about the pending
             // sequence, exit reasons as one word instead of flags): ~20 scalar instructions fewer per sequence, the sparse planes 1.5 %
             // faster, the dense kernel 2.7 % slower (A/B on one box) -- an extra scalar instruction costs ~1.6 cycles of an
             // iteration's ~730 (20 s_nop anywhere in the loop: +4.4 %), the loop is bound by its dependent LDS / VALU chain.)
+            // Batches that find nothing (data that does not compress; the step schedule is at 16 bytes and more): proved empty from the
+            // tags, one LDS round trip per batch.  Every probe reads its bucket and enters itself with ds_max (returning what was there):
+            // nothing can match unless some probe's entry -- the one from before the batch, or an earlier probe of the batch in the
+            // same bucket -- carries the probe's tag within reach.  A probe that finds a LATER probe of the batch in its bucket (the
+            // atomics of one instruction did not run in lane order) proves nothing; then, and on any tag hit, the buckets are put
+            // back and the batch goes through the generic code below.
+            // (first pass and linked frames only: the dense kernel sees chunks of short sequences, and is 3 % slower with this loop compiled in)
+            while (!DENSE && !batch_done && U >= LZ4_RINGLESS_U && put2 == 0xffffffffu) {
+                const uint32_t s_first = (62 + U) >> 6;
+                const uint32_t ustar = 64 * (s_first + 1) - 62;
+                const uint32_t u = U + lane;
+                const uint32_t pos = P + s_first * lane + (u > ustar ? u - ustar : 0u);
+                const uint32_t nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
+                if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
+                const uint64_t seq = glb_ld_u64(w.src + pos);              // (the ring was left behind at these strides)
+                const uint32_t h = lz4_hash5(seq);
+                const uint32_t mytag = tag_of((uint32_t)seq);
+                const uint32_t mine = (pos << tsh) | mytag;
+                const uint32_t oe = table[h];
+                const uint32_t seen = atomicMax(&table[h], mine);
+                wave_lds_sync();
+                const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
+                const uint32_t sp = seen >> tsh;
+                const bool in_batch = sp >= P && seen != oe;
+                const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
+                if (ballot(trouble)) {
+                    table[h] = oe;                                          // (same value from every probe of a bucket)
+                    wave_lds_sync();
+                    break;
+                }
+                P = lane_read(nxt, 63);
+                U += 64;
+            }
             if (!batch_done) {
                 if (U != 0) SQY_REASON(6); else SQY_REASON(7);
                 const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
