@@ -63,6 +63,35 @@ def test_lz4_structured_bytes(sqy, oracle):
         assert blob == want, "stream %d differs (len %d vs %d)" % (i, len(blob), len(want))
 
 
+@pytest.mark.parametrize("layout", [2, 1])
+def test_lz4_noise_with_planted_repeats(sqy, oracle, layout):
+    """Incompressible bytes -- the parse strides over them in batches that are proved empty from the table tags alone -- with repeats
+    planted where that proof must NOT hold: copies of 8..40 bytes at distances from 5 bytes to just inside and just outside the
+    64 KiB reach, runs of equal bytes (probes of one batch in one bucket), repeats that end at a chunk's last bytes."""
+    rng = np.random.default_rng(23)
+    n = 5 * (256 << 10) + 777
+    x = rng.integers(0, 256, n, dtype=np.uint8)
+    for _ in range(400):
+        ln = int(rng.integers(8, 41))
+        dist = int(rng.choice([5, 16, 17, 64, 200, 1000, 4095, 4096, 30000, 65535, 65536, 65540, 100000]))
+        dst_at = int(rng.integers(dist, n - ln))
+        x[dst_at:dst_at + ln] = x[dst_at - dist:dst_at - dist + ln]
+    for at in rng.integers(0, n - 300, 30):
+        x[at:at + int(rng.integers(20, 300))] = rng.integers(0, 256)
+    for k in range(1, 6):                                              # repeats across / right in front of chunk borders
+        e = k * (256 << 10)
+        x[e - 9:e + 9] = x[e - 3000:e - 3000 + 18]
+    vol = x.reshape(1, 1, -1)
+    rc, blob = sqy.encode("lz4", vol, nthreads=layout)
+    assert rc == 0
+    assert blob == oracle.pipeline_encode("lz4", vol, nthreads=layout)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+    v16 = x[:n - n % 2].view(np.uint16).reshape(1, 1, -1)
+    rc, blob = sqy.encode("bitswap1->lz4", v16, nthreads=layout)
+    assert rc == 0 and blob == oracle.pipeline_encode("bitswap1->lz4", v16, nthreads=layout)
+
+
 def test_diff_bitswap_lz4_u16(sqy, oracle):
     for shape in ((16, 32, 48), (8, 8, 8), (40, 12, 20), (6, 8, 16), (9, 10, 8), (10, 10, 8), (12, 33, 2100), (5, 3, 3), (2, 9, 17),
                   (1, 4, 4), (30, 7, 5)):
