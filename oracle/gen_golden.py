@@ -193,5 +193,47 @@ def main():
     print("wrote", os.path.join(GOLD, "golden.json"), "with", sum(len(v) for k, v in G.items() if k != "_meta"), "vectors")
 
 
+def headline():
+    """tests/golden/headline.json: payload digests of the BASELINE headline stacks (configs[0] 256^3 and configs[1] 1024x1024x512 uint16,
+    'bitswap1->lz4') produced by the REFERENCE pieces themselves -- the reference's SSE bit-plane gather (encoders/sse_utils.hpp:1365-1433,
+    compiled in place) followed by liblz4 1.9.3 frames through sqeazy's encode_parallel call sequence (encoders/lz4_utils.hpp:193-274) --
+    plus the slab 0 of the 2048^3 north_star volume.  The GPU tests and bench.py compare the HIP path's payload with these digests, so
+    the headline is pinned to the reference and not only to the restated oracle.  (The sqy header in front of the payload is the oracle's:
+    the reference's header code needs Boost.)"""
+    assert ref.available() and ref.lz4_version() == 10903
+    H = {"_meta": {"generator": "oracle/gen_golden.py --headline", "bitswap1": "reference simd_segment_broadcast (sse_utils.hpp:1365-1433), 16 threads",
+                   "lz4": "liblz4 1.9.3 (LZ4_versionNumber 10903) via encode_parallel (lz4_utils.hpp:193-274), 256 KiB chunks",
+                   "stack": "sqeazy_amd.synth.stack(shape, uint16[, frames z_offset.. of z_total])"}, "stacks": []}
+    cases = (("C1 256x256x256 u16", (256, 256, 256), 0, None), ("C2 1024x1024x512 u16", (512, 1024, 1024), 0, None),
+             ("north_star slab 0 of 2048^3 u16 (2048x2048x256)", (256, 2048, 2048), 0, 2048))
+    for name, shape, z0, ztot in cases:
+        vol = synth.stack(shape, np.uint16) if ztot is None else None
+        if vol is None:
+            # frames [z0, z0 + Z) of a (ztot, Y, X) volume without building the whole volume
+            Z, Y, X = shape
+            per = Y * X
+            noise = synth._noise(z0 * per, Z * per, synth.SEED).reshape(Z, Y, X)
+            sh = synth._shell(z0, Z, ztot, Y, X)
+            vol = (100 + (noise >> 2) + sh * 6000).astype(np.uint16)
+        planes = ref.bitswap1_encode_u16(vol, 16)
+        payload = ref.lz4_encode_parallel(planes.view(np.uint8), nthreads=8)
+        mine = o.pipeline_encode("bitswap1->lz4", vol)
+        h = o.header_unpack(mine)
+        assert mine[h["size"]:] == payload.tobytes(), ("oracle payload differs from the reference pieces", name)
+        H["stacks"].append({"name": name, "shape_zyx": list(shape), "z_offset": z0, "z_total": ztot or shape[0], "pipeline": "bitswap1->lz4",
+                            "voxels_sha256": sha(vol.tobytes()), "payload_bytes": int(payload.size), "payload_sha256": sha(payload.tobytes()),
+                            "blob_bytes": len(mine), "blob_sha256": sha(mine), "header_bytes": h["size"],
+                            "source": "payload: reference SSE bitswap + liblz4 1.9.3; header: oracle"})
+        print(name, payload.size, H["stacks"][-1]["payload_sha256"][:16], flush=True)
+        del vol, planes, payload, mine
+    with open(os.path.join(GOLD, "headline.json"), "w") as f:
+        json.dump(H, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(GOLD, "headline.json"))
+
+
 if __name__ == "__main__":
-    main()
+    if "--headline" in sys.argv:
+        headline()
+    else:
+        main()
+        headline()

@@ -11,6 +11,7 @@
 #include <climits>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <atomic>
 #include <condition_variable>
@@ -106,11 +107,12 @@ struct DevBuf {
 
 struct Workspace {
     DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan, dedupe;
+    DevBuf diff_side;         // diff3x3x1 in front of a 16-bit bitswap1: the columns the stage can touch (outside the ping/pong rotation)
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
     void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
-        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release();
+        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release();
     }
 };
 
@@ -190,6 +192,7 @@ struct Context {
     hipStream_t stream = nullptr;       // used when the caller brings no stream (host-pointer entry points)
     hipStream_t side = nullptr;         // decode: stored frames are copied here while the compressed ones are decoded
     hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t t_done = nullptr;        // recorded behind this call's bit-plane transpose (the transposes of calls in flight run one after the other)
     hipStream_t own_stream()
     {
         if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
@@ -210,6 +213,11 @@ struct Context {
 
 constexpr int kMaxDev = 16;
 constexpr size_t kMaxCtxPerDev = 8;
+// EXPERIMENT (SQY_EXP_TCHAIN): the bit-plane transposes of the calls in flight on one device are chained on the GPU (a stream waits
+// for the previous call's transpose before it starts its own): two HBM-bound kernels side by side each run at half speed, one after
+// the other the first call's parse starts a transpose earlier.
+std::mutex g_tchain_mu[kMaxDev];
+hipEvent_t g_tchain_last[kMaxDev] = {};
 std::mutex g_pool_mu;
 std::condition_variable g_pool_cv;
 std::vector<std::unique_ptr<Context>> g_pool[kMaxDev];
@@ -393,12 +401,29 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 uint8_t* out = gap_chunk ? static_cast<uint8_t*>(d_dst) + inplace_t0 + 11 : next_buf(cur_len * cur_elem);
                 if (!out) return 1;
                 if (!gap_chunk && ph && (reinterpret_cast<uintptr_t>(out) & 15)) { ph = nullptr; lz4_piece_hash = nullptr; }
+                static const bool tchain = std::getenv("SQY_EXP_TCHAIN") != nullptr;
+                int devid = 0;
+                const bool chain = tchain && gap_chunk && hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < kMaxDev;
+                std::unique_lock<std::mutex> tlock;
+                if (chain) {
+                    if (!cx.t_done && hipEventCreateWithFlags(&cx.t_done, hipEventDisableTiming) != hipSuccess) return 1;
+                    tlock = std::unique_lock<std::mutex>(g_tchain_mu[devid]);
+                    if (g_tchain_last[devid] && g_tchain_last[devid] != cx.t_done) SQY_HIP(hipStreamWaitEvent(stream, g_tchain_last[devid], 0));
+                }
+                {
                 ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
                 if (cur_elem == 2)
                     SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream, ph,
                                                      (uint32_t)gap_chunk, bsw_side, bsw_side_w, bsw_side_X));
                 else
                     SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
+                }
+                if (chain) {
+                    SQY_HIP(hipEventRecord(cx.t_done, stream));
+                    g_tchain_last[devid] = cx.t_done;
+                    tlock.unlock();
+                }
+                bsw_side = nullptr; bsw_side_w = 0; bsw_side_X = 0;       // (consumed: a later bitswap1 of the pipeline reads its plain input)
                 cur = out;
                 break;
             }
@@ -532,8 +557,10 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                          (reinterpret_cast<uintptr_t>(cur) & 15) == 0)
                                             ? sqy::diff3x3x1_side_width(Z, Y, X, cur_elem) : 0;
                     if (sw) {
-                        uint8_t* side = next_buf(Z * Y * (uint64_t)sw * 2);
-                        if (!side) return 1;
+                        // a buffer of its own: `cur` stays where it is, so the transpose's output (the next buffer of the
+                        // ping/pong rotation) can never be the buffer `cur` lives in
+                        if (ws->diff_side.ensure(Z * Y * (uint64_t)sw * 2)) return 1;
+                        uint8_t* side = static_cast<uint8_t*>(ws->diff_side.p);
                         ProfScope ps("diff3x3x1", stream, pend);
                         SQY_HIP(sqy::launch_diff3x3x1_side(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(side), Z, Y, X, sw, stream));
                         bsw_side = reinterpret_cast<const uint16_t*>(side);

@@ -56,17 +56,26 @@ __device__ __forceinline__ uint32_t lds_ld_u8(const lds_u8* p) { return *p; }
 __device__ __forceinline__ uint32_t lds_ld_u32(const lds_u8* p) { return reinterpret_cast<const SQY_LDS pk_u32*>(p)->v; }
 __device__ __forceinline__ uint64_t lds_ld_u64(const lds_u8* p) { return reinterpret_cast<const SQY_LDS pk_u64*>(p)->v; }
 typedef uint32_t v4u_any __attribute__((ext_vector_type(4), aligned(1)));
-// ONE 16-byte load: four field loads get split by the optimiser into a b64 now and a conditional b64 later when only
-// the low half decides a branch -- a second dependent LDS round trip on the parse's critical path
-// ... issued as TWO 8-byte reads: a ds_read_b128 whose address is not a multiple of 16 is replayed (measured 146 instead of
-// 90 cycles in a dependent chain, tools/lds_bench.hip; SQ_LDS_UNALIGNED_STALL 20 % of the wave-cycles of the round-2 kernel),
-// ds_read_b64 is not (82 cycles at any alignment).  volatile: keeps the two from being merged back into one b128 and from
-// being split into "now" and "later".
+// What a DS read off its natural alignment costs (round 4, tools/lds_bench2.hip, dependent chain of one wave): EVERY instruction
+// with a lane off the natural alignment of its width is replayed, +64 cycles each -- ds_read_b32 73 -> 137, ds_read_b64 75 -> 139,
+// ds_read_b128 87 -> 147, two ds_read_b64 back to back 87 -> 211, four ds_read_b32 95 -> 339; ds_read_u8 never (73); two
+// ds_read2_b32 at a multiple of 4 (four dwords) 95.  Round 3 issued a 16-byte ring read as two ds_read_b64, which is the better
+// shape only at multiples of 8: at byte granularity ONE ds_read_b128 is replayed once (147), the pair twice (211).
+// SQ_LDS_UNALIGNED_STALL was 28 % of the wave-cycles of round 3's lz4_chunks.
+// ONE 16-byte load at any alignment (volatile: four field loads get split by the optimiser into a b64 now and a conditional
+// b64 later when only the low half decides a branch -- a second dependent LDS round trip on the parse's critical path).
 __device__ __forceinline__ uint4 lds_ld_u128(const lds_u8* p)
 {
-    const uint64_t lo = reinterpret_cast<const volatile SQY_LDS pk_u64*>(p)->v;
-    const uint64_t hi = reinterpret_cast<const volatile SQY_LDS pk_u64*>(p + 8)->v;
-    return make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    const v4u_any t = *reinterpret_cast<const volatile SQY_LDS v4u_any*>(p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+// four dwords at a multiple of 4: two ds_read2_b32, never replayed (95 cycles against 147 for a ds_read_b128 off a multiple of 16)
+struct __attribute__((aligned(4))) al4_u64 { uint32_t x, y; };
+__device__ __forceinline__ uint4 lds_ld_4dw(const lds_u8* p)
+{
+    const volatile SQY_LDS al4_u64* q = reinterpret_cast<const volatile SQY_LDS al4_u64*>(p);
+    const al4_u64 a = { q[0].x, q[0].y }, b = { q[1].x, q[1].y };
+    return make_uint4(a.x, a.y, b.x, b.y);
 }
 __device__ __forceinline__ uint32_t glb_ld_u8(glb_u8* p) { return *p; }
 __device__ __forceinline__ uint32_t glb_ld_u32(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u32*>(p)->v; }
@@ -713,6 +722,17 @@ __device__ __forceinline__ uint32_t ffbl(uint32_t v)
     asm("v_ffbl_b32 %0, %1" : "=v"(r) : "v"(v));
     return r;
 }
+// the same from the four dwords of x ^ y
+__device__ __forceinline__ uint32_t first_nonzero16(uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3)
+{
+    const uint32_t t0 = ffbl(x0);
+    const uint32_t t1 = ffbl(x1) | 32u;
+    const uint32_t t2 = ffbl(x2) | 64u;
+    const uint32_t t3 = ffbl(x3) | 96u;
+    const uint32_t a = t0 < t1 ? t0 : t1, b = t2 < t3 ? t2 : t3;
+    const uint32_t m = a < b ? a : b;
+    return (m < 128u ? m : 128u) >> 3;
+}
 __device__ __forceinline__ uint32_t first_diff16(uint4 x, uint4 y)
 {
     // "| 32 k" adds the dword offset to a real index and leaves the "no difference in this dword" marker (~0) above every
@@ -1257,6 +1277,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 const bool putlane = lane == 15;
                 const uint32_t posoff = putlane ? 0xfffffffeu : (uint32_t)lane;
                 const uint32_t notprobe = (uint32_t)lane < 15u ? 0u : 1u;
+                const uint32_t lane0_off = lane == 0 ? 0u : 0xffffffffu;
                 for (;;) {
                     {
                         // (all scalar: a three-way vector minimum here costs the loop a round through VCC per iteration)
@@ -1266,15 +1287,15 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     }
                     SQY_STAMP(1);
                     const uint32_t pos = P + posoff;
-                    const uint32_t wlo4 = w.wlo + 4u;
-                    // ring offsets of both reads BEFORE the first is issued: computed behind it, the second one's address lands in
-                    // a register the first one is still writing to, and the loop waits for the ring right here (seen in the ISA)
-                    uint32_t o16 = pos & (LZ4_WIN - 1u), o4 = (pos - 4u) & (LZ4_WIN - 1u);
-                    asm volatile("" : "+v"(o16), "+v"(o4));
-                    const uint32_t b4 = lds_ld_u32(w.win + o4);
-                    // (the hash takes five bytes, the tag four: eight bytes per probe are all this batch reads of the sequence)
-                    const uint64_t s8 = lds_ld_u64(w.win + o16);
-                    const uint2 s16 = make_uint2((uint32_t)s8, (uint32_t)(s8 >> 32));
+                    const uint32_t wlo8 = w.wlo + 8u;
+                    // The twelve bytes [pos - 4, pos + 8) of every probe (the hash takes five bytes, the tag four, the four in front
+                    // serve the catch-up and the literals) out of the four dwords that hold them: reads at a multiple of 4 are not
+                    // replayed, the byte shift is three v_alignbyte.  (Round 3: a 4-byte and an 8-byte read at byte granularity,
+                    // two replays = +128 cycles per sequence.)
+                    const uint32_t sh1 = pos & 3u;
+                    const uint4 d1 = lds_ld_4dw(w.win + ((pos - 4u - sh1) & (LZ4_WIN - 1u)));
+                    const uint32_t b4 = __builtin_amdgcn_alignbyte(d1.y, d1.x, sh1);
+                    const uint2 s16 = make_uint2(__builtin_amdgcn_alignbyte(d1.z, d1.y, sh1), __builtin_amdgcn_alignbyte(d1.w, d1.z, sh1));
                     // (in the shadow of those reads: limit checks / stage room of the sequence found in the last iteration)
                     if (pend) { emit_pending_checks(); if (failed) break; }
                     SQY_STAMP(2);
@@ -1304,6 +1325,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     const uint32_t f0 = ctz64(nm);                                      // <= 14
                     const uint32_t mt0 = lane_read(old, f0);
                     const uint32_t ip0 = P + f0;
+                    // (the wide compare below starts up to 7 bytes in front of the match: a candidate at the stream's first bytes
+                    // -- the empty buckets of a fresh table say "first byte" -- goes to the generic path)
+                    if (mt0 < p_lo + 8u) { SQY_REASON(3); break; }
                     SQY_STAMP(5);
                     // Commit probes 0..f0 now and read the buckets back: a probe that does not find its own entry shares its
                     // bucket with another probe of the batch -- the later one's true candidate would be the earlier one --,
@@ -1313,29 +1337,41 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     if (commit) table[h] = mine;
                     wave_lds_sync();
                     const uint32_t rb = table[h];
-                    const uint32_t dd = (uint32_t)lane * 16u;
-                    uint32_t g, cb4;
+                    // One frame for both sides: it starts 4 + r bytes in front of (ip0, mt0), r = ip0 & 3, so that the ip side is read
+                    // at multiples of 4 (never replayed) and the 4 bytes in front of the match -- the catch-up -- are part of lane 0's
+                    // 16 bytes instead of a read of their own; the match side is ONE 16-byte read per lane (replayed once unless the
+                    // offset happens to be a multiple of 16).  Round 3 read 4 + 2 x 8 + 2 x 8 bytes at byte granularity: five replays,
+                    // +320 cycles per sequence.
+                    const uint32_t r3 = ip0 & 3u;
+                    const uint32_t hd = 4u + r3;                                        // bytes of lane 0 in front of ip0
+                    const uint32_t dd = (uint32_t)lane * 16u - hd;
+                    uint32_t x0, x1, x2, x3;                                            // ip side ^ match side
                     // (two complete branches: a merged load would make the common, ring-only side wait on vmcnt too)
-                    if (mt0 >= wlo4) {
-                        uint32_t ocb = (mt0 - 4u) & (LZ4_WIN - 1u), oi = (ip0 + dd) & (LZ4_WIN - 1u), om = (mt0 + dd) & (LZ4_WIN - 1u);
-                        asm volatile("" : "+v"(ocb), "+v"(oi), "+v"(om));               // (all three reads issued back to back, see the loop top)
-                        cb4 = lds_ld_u32(w.win + ocb);
-                        const uint4 ci = lds_ld_u128(w.win + oi), cm = lds_ld_u128(w.win + om);   // ip side resident and clear of matchlimit (loop condition)
-                        g = first_diff16(ci, cm);
+                    if (mt0 >= wlo8) {
+                        uint32_t oi = (ip0 + dd) & (LZ4_WIN - 1u), om = (mt0 + dd) & (LZ4_WIN - 1u);
+                        asm volatile("" : "+v"(oi), "+v"(om));                          // (both reads issued back to back, see the loop top)
+                        const uint4 ci = lds_ld_4dw(w.win + oi), cm = lds_ld_u128(w.win + om);   // ip side resident and clear of matchlimit (loop condition)
+                        x0 = ci.x ^ cm.x; x1 = ci.y ^ cm.y; x2 = ci.z ^ cm.z; x3 = ci.w ^ cm.w;
                     } else {
-                        const uint4 cg = glb_ld_u128(w.src + mt0 + dd);                 // mt0 + 1024 <= ip0 + 1023 < matchlimit
-                        cb4 = mt0 >= p_lo + 4u ? glb_ld_u32(w.src + mt0 - 4u) : (glb_ld_u32(w.src + p_lo) << (8u * (4u - (mt0 - p_lo))));
-                        g = first_diff16(w.lds128(ip0 + dd), cg);
-                        asm volatile("" : "+v"(g));                                     // (keeps the optimiser from re-merging the branches)
+                        const uint4 cg = glb_ld_u128(w.src + (uint32_t)(mt0 + dd));     // (32-bit sum: dd wraps for lane 0)  mt0 - 7 >= p_lo; mt0 + 1024 <= ip0 + 1023 < matchlimit
+                        const uint4 ci = lds_ld_4dw(w.win + ((ip0 + dd) & (LZ4_WIN - 1u)));
+                        x0 = ci.x ^ cg.x; x1 = ci.y ^ cg.y; x2 = ci.z ^ cg.z; x3 = ci.w ^ cg.w;
+                        asm volatile("" : "+v"(x0));                                    // (keeps the optimiser from re-merging the branches)
                         SQY_REASON(2);
                     }
+                    // the 4 bytes in front of (ip0, mt0): bytes r .. r+3 of lane 0
+                    const uint32_t xbv = __builtin_amdgcn_alignbyte(x1, x0, r3);
+                    // forward: lane 0 leaves out its first 4 + r bytes
+                    x0 &= lane0_off;
+                    x1 &= lane0_off | (0xffffffffu << (8u * r3));
+                    const uint32_t g = first_nonzero16(x0, x1, x2, x3);
                     SQY_STAMP(6);
                     const uint64_t nf = ballot(g != 16u);
-                    uint32_t eq = 1024u;                                                // equal bytes from (ip0, mt0) on
+                    uint32_t eq = 1024u - hd;                                           // equal bytes from (ip0, mt0) on
                     bool settled = false;
                     if (nf) {
                         const uint32_t l = ctz64(nf);
-                        eq = l * 16u + lane_read(g, l);
+                        eq = l * 16u + lane_read(g, l) - hd;
                         settled = true;
                     }
                     SQY_STAMP(7);
@@ -1348,7 +1384,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     }
                     const uint32_t ml = eq - 4u;                                        // exact when settled, else "at least"
                     // catch-up of the winner: ip - anchor = f0 literals, match > 0
-                    const uint32_t xb = lane_read(b4, f0) ^ sgpr(cb4);
+                    const uint32_t xb = lane_read(xbv, 0);
                     const uint32_t bk = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;   // equal bytes in front, 4 = maybe more
                     const uint32_t room0 = back_room(mt0);
                     const uint32_t lim = f0 < room0 ? f0 : room0;
