@@ -341,6 +341,7 @@ def main():
     torch.cuda.synchronize()
 
     last_at = [(0, 0, 0)]            # (thread, buffer, offset) of the blob of the last step taken
+    last_blob = [None] * inflight    # per caller thread: (buffer, offset, bytes) of the last blob it produced
 
     # the caller threads live as long as the run (an application's encoder threads do); a block of steps is handed to them as a job
     job_q = [queue.Queue() for _ in range(inflight)]
@@ -361,6 +362,7 @@ def main():
                                                              stream=streams[t].cuda_stream)
                     if rc:
                         raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
+                    last_blob[t] = (b, off, n)
                     done_q.put((s_, t, b, n, off))
             except Exception as e:   # pragma: no cover
                 errors.append(e)
@@ -445,6 +447,28 @@ def main():
     sqeazy_amd.profile_enable(False)
     prof = sqeazy_amd.profile_get()
     nblocks = len(times)
+    # What was timed is also checked (after the clock stopped): the LAST blob of every caller thread is hashed and compared with the
+    # digest the reference pieces themselves give for this stack (tests/golden/headline.json: reference SSE bit-plane gather + liblz4
+    # 1.9.3 frames, oracle/gen_golden.py --headline; a data file, nothing of oracle/ runs here)
+    digests = []
+    for t in range(inflight):
+        if last_blob[t] is not None:
+            b, off, n = last_blob[t]
+            digests.append(hashlib.sha256(outs[t][b][off:off + n].cpu().numpy().tobytes()).hexdigest())
+    verify = {"verified": False, "blobs_hashed": len(digests), "blob_sha256": digests[0] if digests else None,
+              "threads_agree": len(set(digests)) == 1}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "headline.json")) as f:
+            for g in json.load(f)["stacks"]:
+                if tuple(g["shape_zyx"]) == tuple(shape) and g["z_offset"] == rank * shape[0] and g["z_total"] == world * shape[0]:
+                    verify["reference_blob_sha256"] = g["blob_sha256"]
+                    verify["payload_sha256"] = g["payload_sha256"]
+                    verify["against"] = "tests/golden/headline.json (%s): %s" % (g["name"], g["source"])
+                    verify["verified"] = bool(digests) and all(d == g["blob_sha256"] for d in digests)
+    except Exception as e:   # reported, never fatal for the measurement
+        verify["error"] = repr(e)
+    if "against" not in verify:
+        verify["against"] = "no reference digest for this shape (only the BASELINE stack has one); threads compared with each other"
 
     gather_times = None
     if gatherer is not None:
@@ -512,6 +536,7 @@ def main():
             "single_call": {"ms": round(single_ms, 4), "value": round(nbytes / (single_ms / 1e3) / 1e9, 1), "unit": "GB/s",
                             "roofline_frac": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
                             "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof_alone.items()}},
+            "verified": verify["verified"], "payload_sha256": verify.get("payload_sha256"), "verification": verify,
             "entry_point": "SQYAMD_PipelineEncode_UI16_DeviceAt (device pointers; the blob may start anywhere in the destination: frames in place)",
             "build": ident,
         }

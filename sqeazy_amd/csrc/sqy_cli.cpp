@@ -15,6 +15,7 @@
 //   * TIFF input/output is the uncompressed 8/16-bit grayscale subset the reference itself writes (tiff_utils.hpp:
 //     286-310), read and written here without libtiff; .raw needs --shape and --dtype.
 // Uses nothing but the exported C symbols -- it doubles as the example of a third-party caller of the drop-in.
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -23,6 +24,7 @@
 #include <fstream>
 #include <iostream>
 #include <map>
+#include <set>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -66,6 +68,7 @@ struct TiffReader {
     uint64_t value(const Entry& e, uint64_t i)
     {
         const uint64_t o = e.value_off + i * type_size(e.type);
+        if (o < e.value_off) { err = "value offset wraps"; return 0; }
         switch (type_size(e.type)) { case 1: return rd<uint8_t>(o); case 2: return rd<uint16_t>(o); case 4: return rd<uint32_t>(o); case 8: return rd<uint64_t>(o); }
         return 0;
     }
@@ -91,8 +94,14 @@ struct TiffReader {
     {
         f.open(path, std::ios::binary);
         if (!f) { err = "unable to open"; return false; }
+        // the file is untrusted input: everything read from it is checked against the file's size (the strips are uncompressed, so
+        // a stack can never be larger than the file that holds it), IFD chains may not revisit an offset
+        f.seekg(0, std::ios::end);
+        const uint64_t file_size = (uint64_t)std::max<std::streamoff>(f.tellg(), 0);
+        f.seekg(0);
         char bo[2] = {0, 0};
         f.read(bo, 2);
+        if (!f) { err = "not a TIFF file"; return false; }
         const uint16_t probe = 1;
         const bool host_le = *reinterpret_cast<const uint8_t*>(&probe) == 1;
         if (bo[0] == 'I' && bo[1] == 'I') swap = !host_le; else if (bo[0] == 'M' && bo[1] == 'M') swap = host_le; else { err = "not a TIFF file"; return false; }
@@ -102,7 +111,9 @@ struct TiffReader {
         uint64_t w = 0, h = 0, bits = 0, frames = 0;
         std::vector<std::pair<uint64_t, uint64_t>> strips;     // (offset, bytes) in frame order
         uint64_t imagej_images = 0;
+        std::set<uint64_t> seen_ifds;
         while (ifd && err.empty()) {
+            if (ifd >= file_size || !seen_ifds.insert(ifd).second) { err = "IFD chain leaves the file or loops"; break; }
             std::map<uint16_t, Entry> t;
             const uint64_t next = read_ifd(ifd, t);
             if (!err.empty()) break;
@@ -115,15 +126,20 @@ struct TiffReader {
             if (spp != 1 || (fbits != 8 && fbits != 16)) { err = "only 8/16-bit single-sample stacks are supported"; break; }
             if (frames == 0) { w = fw; h = fh; bits = fbits; }
             else if (fw != w || fh != h || fbits != bits) { err = "frames of different shape/type"; break; }
+            if (fw == 0 || fh == 0 || fw > file_size || fh > file_size || fw * fh > file_size) { err = "frame larger than the file"; break; }
             const uint64_t nstrips = t[273].count;
+            if (nstrips == 0 || nstrips > fh || (t.count(279) && t[279].count < nstrips)) { err = "implausible strip table"; break; }
             uint64_t have = 0;
-            for (uint64_t s = 0; s < nstrips; ++s) {
+            for (uint64_t s = 0; s < nstrips && err.empty(); ++s) {
                 const uint64_t so = value(t[273], s);
                 uint64_t sb = t.count(279) ? value(t[279], s) : fw * fh * (fbits / 8);
+                if (so > file_size || sb > file_size - so) { err = "strip outside the file"; break; }
                 strips.emplace_back(so, sb);
                 have += sb;
             }
-            if (t.count(270) && frames == 0) {                   // ImageJ: "ImageJ=...\nimages=N\n..."
+            if (!err.empty()) break;
+            if (t.count(270) && frames == 0 && t[270].count <= (1u << 20) && t[270].value_off <= file_size &&
+                t[270].count <= file_size - t[270].value_off) {   // ImageJ: "ImageJ=...\nimages=N\n..."
                 std::string d((size_t)t[270].count, '\0');
                 f.seekg((std::streamoff)t[270].value_off); f.read(&d[0], (std::streamsize)d.size());
                 const size_t k = d.find("images=");
@@ -137,10 +153,12 @@ struct TiffReader {
         if (frames == 0) { err = "no image in file"; return false; }
         const uint64_t frame_bytes = w * h * (bits / 8);
         if (frames == 1 && imagej_images > 1) {                  // contiguous hyperstack behind the first strip
-            frames = imagej_images;
             const uint64_t first = strips.front().first;
+            if (frame_bytes == 0 || imagej_images > (file_size - first) / frame_bytes) { err = "ImageJ stack larger than the file"; return false; }
+            frames = imagej_images;
             strips.assign(1, std::make_pair(first, frames * frame_bytes));
         }
+        if (frame_bytes == 0 || frames > file_size / frame_bytes) { err = "stack larger than the file"; return false; }
         out.shape = {(long)frames, (long)h, (long)w};
         out.bytes_per_voxel = (int)(bits / 8);
         if (header_only) return true;
@@ -431,7 +449,15 @@ void usage(const char* me)
 
 }  // namespace
 
+static int run(int argc, char** argv);
 int main(int argc, char** argv)
+{
+    // (malformed input files must end in a message and an exit code, never in std::terminate)
+    try { return run(argc, argv); }
+    catch (const std::exception& e) { std::cerr << "[SQY]\t" << e.what() << "\n"; return 1; }
+    catch (...) { std::cerr << "[SQY]\tunexpected error\n"; return 1; }
+}
+static int run(int argc, char** argv)
 {
     Options o;
     std::vector<std::string> args(argv + 1, argv + argc);

@@ -127,3 +127,87 @@ def test_every_slab_of_the_sharded_volumes(sqy, oracle, pipeline):
             assert np.array_equal(back, host), slab
         else:
             assert np.array_equal(back, oracle.pipeline_decode(blob)), slab
+
+
+# ---- the headline pinned to the reference itself --------------------------------------------------
+# tests/golden/headline.json holds the payload digests the REFERENCE pieces produce for the BASELINE headline stacks (reference SSE
+# bit-plane gather + liblz4 1.9.3 frames, oracle/gen_golden.py --headline, build container only).  The HIP path's payload must
+# equal them through every device entry point -- including the one bench.py times, SQYAMD_PipelineEncode_UI16_DeviceAt with
+# four calls in flight.
+def _headline(name_prefix):
+    import json, os
+    with open(os.path.join(os.path.dirname(__file__), "golden", "headline.json")) as f:
+        H = json.load(f)
+    return next(s for s in H["stacks"] if s["name"].startswith(name_prefix))
+
+
+def _sha(b):
+    import hashlib
+    return hashlib.sha256(b).hexdigest()
+
+
+@pytest.mark.parametrize("prefix", ["C1", "C2", "north_star slab 0"])
+def test_headline_payload_equals_the_reference_digest(sqy, oracle, prefix):
+    import torch
+    g = _headline(prefix)
+    shape = tuple(g["shape_zyx"])
+    dev = torch.device("cuda", 0)
+    vol = synth.stack_torch(shape, np.uint16, dev, z_offset=g["z_offset"], z_total=g["z_total"])
+    if prefix == "C1":
+        assert _sha(vol.cpu().numpy().tobytes()) == g["voxels_sha256"]          # same voxels as the generator's
+    cap = sqy.max_compressed_length("bitswap1->lz4", shape, np.uint16)
+    out = torch.full((cap,), 0x5A, dtype=torch.uint8, device=dev)
+    # blob at the start of the destination
+    rc, n = sqy.encode_device("bitswap1->lz4", vol.data_ptr(), shape, np.uint16, out.data_ptr(), cap)
+    assert rc == 0 and n == g["blob_bytes"]
+    blob = out[:n].cpu().numpy().tobytes()
+    hs = sqy.header_size(blob[:65536])
+    assert hs == g["header_bytes"] and n - hs == g["payload_bytes"]
+    assert _sha(blob[hs:]) == g["payload_sha256"], "_Device payload differs from the reference pieces' payload"
+    assert _sha(blob) == g["blob_sha256"]
+    del blob
+    # frames in place (what bench.py calls)
+    out.fill_(0xA5)
+    rc, off, n = sqy.encode_device_at("bitswap1->lz4", vol.data_ptr(), shape, np.uint16, out.data_ptr(), cap)
+    assert rc == 0 and n == g["blob_bytes"] and off > 0
+    blob = out[off:off + n].cpu().numpy().tobytes()
+    assert _sha(blob[hs:]) == g["payload_sha256"], "_DeviceAt payload differs from the reference pieces' payload"
+    assert _sha(blob) == g["blob_sha256"]
+    del vol, out
+    torch.cuda.empty_cache()
+
+
+def test_headline_four_calls_in_flight_equal_the_reference_digest(sqy):
+    """exactly what bench.py times: four host threads, a stream and an output buffer each, SQYAMD_PipelineEncode_UI16_DeviceAt on the
+    1 GiB stack, several rounds back to back; every blob of every thread hashed"""
+    import threading
+    import torch
+    g = _headline("C2")
+    shape = tuple(g["shape_zyx"])
+    dev = torch.device("cuda", 0)
+    vol = synth.stack_torch(shape, np.uint16, dev)
+    cap = sqy.max_compressed_length("bitswap1->lz4", shape, np.uint16)
+    T, rounds = 4, 3
+    streams = [torch.cuda.Stream(device=dev) for _ in range(T)]
+    outs = [torch.full((cap,), 0xA5, dtype=torch.uint8, device=dev) for _ in range(T)]
+    torch.cuda.synchronize()
+    results, errors = [[] for _ in range(T)], []
+
+    def caller(t):
+        try:
+            torch.cuda.set_device(0)
+            for r in range(rounds):
+                rc, off, n = sqy.encode_device_at("bitswap1->lz4", vol.data_ptr(), shape, np.uint16, outs[t].data_ptr(), cap,
+                                                  stream=streams[t].cuda_stream)
+                assert rc == 0
+                if r == rounds - 1 or t == r:                                  # the last blob of every thread, and one from the middle
+                    results[t].append(_sha(outs[t][off:off + n].cpu().numpy().tobytes()))
+        except Exception as e:   # pragma: no cover
+            errors.append(e)
+
+    ths = [threading.Thread(target=caller, args=(t,)) for t in range(T)]
+    [th.start() for th in ths]
+    [th.join() for th in ths]
+    assert not errors, errors
+    for t in range(T):
+        assert results[t] and all(h == g["blob_sha256"] for h in results[t]), "thread %d produced a blob that differs from the reference digest" % t

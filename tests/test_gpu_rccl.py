@@ -89,3 +89,27 @@ def test_single_blob_from_slabs_without_a_host_walk(sqy):
     assert one.numel() == wn and torch.equal(one, whole[woff:woff + wn])
     # volumes of 2^31 voxels and more cannot be one blob (no single call could have produced or can decode it)
     assert not multi.single_blob_possible((2048, 2048, 2048), np.uint16, 8)
+
+
+def test_bench_self_spawn_and_distributed_path_on_one_gpu():
+    """bench.py's N > 1 plumbing rehearsed on the one-GPU box as a fresh child process: the script starts
+    its rank itself through torch.distributed.run (SQY_BENCH_FORCE_SPAWN), initialises RCCL with a group of one (SQY_BENCH_FORCE_DIST),
+    exchanges the blob sizes per step, runs the second measurement with the overlapped gather to rank 0, and prints ONE JSON line."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.update({"SQY_BENCH_FORCE_SPAWN": "1", "SQY_BENCH_FORCE_DIST": "1", "HSA_ENABLE_IPC_MODE_LEGACY": "0", "MASTER_ADDR": "127.0.0.1"})
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--quick", "--steps", "3", "--warmup", "1", "--min-seconds", "0.05"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 1 and line["steps"] == 3 and line["unit"] == "GB/s" and line["value"] > 0
+    assert "with_gather" in line and line["with_gather"]["value"] > 0          # the RCCL gather path ran
+    assert line["verified"] is True and line["verification"]["threads_agree"]  # and what was timed equals the reference digest
+    assert "sharded" in line["config"]["workload"] or line["n_gpus"] == 1
