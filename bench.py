@@ -346,6 +346,19 @@ def main():
     # the caller threads live as long as the run (an application's encoder threads do); a block of steps is handed to them as a job
     job_q = [queue.Queue() for _ in range(inflight)]
 
+    # the C call of every (thread, buffer), marshalled once: what a C caller's loop looks like (no Python object is built per step)
+    entry = sqeazy_amd.lib().SQYAMD_PipelineEncode_UI16_DeviceAt
+    pipe_b = PIPELINE.encode()
+    shape_c = (ctypes.c_long * 3)(*shape)
+
+    def prepared(t, b):
+        doff, dlen = ctypes.c_long(0), ctypes.c_long(0)
+        args = (pipe_b, ctypes.c_void_p(vol.data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][b].data_ptr()), ctypes.c_long(cap),
+                ctypes.byref(doff), ctypes.byref(dlen), ctypes.c_int(0), ctypes.c_void_p(streams[t].cuda_stream))
+        return args, doff, dlen
+
+    calls = [[prepared(t, b) for b in range(2)] for t in range(inflight)]
+
     def caller(t):
         torch.cuda.set_device(local_rank)
         while True:
@@ -354,16 +367,30 @@ def main():
                 return
             k, free_qt, done_q, stop, errors = job
             try:
-                for s_ in range(t, k, inflight):
-                    b = free_qt.get()
-                    if b is None or stop.is_set():
-                        break
-                    rc, off, n = sqeazy_amd.encode_device_at(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[t][b].data_ptr(), cap, nthreads=0,
-                                                             stream=streams[t].cuda_stream)
-                    if rc:
-                        raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
-                    last_blob[t] = (b, off, n)
-                    done_q.put((s_, t, b, n, off))
+                if free_qt is None:
+                    # one GPU, nothing consumes the blobs between the steps: the thread's steps back to back, its two buffers taking turns
+                    i = 0
+                    for s_ in range(t, k, inflight):
+                        args, doff, dlen = calls[t][i & 1]
+                        rc = entry(*args)
+                        if rc:
+                            raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
+                        last_blob[t] = (i & 1, doff.value, dlen.value)
+                        i += 1
+                    if i:
+                        done_q.put((-3, t, last_blob[t][0], last_blob[t][2], last_blob[t][1]))
+                else:
+                    for s_ in range(t, k, inflight):
+                        b = free_qt.get()
+                        if b is None or stop.is_set():
+                            break
+                        args, doff, dlen = calls[t][b]
+                        rc = entry(*args)
+                        if rc:
+                            raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
+                        off, n = doff.value, dlen.value
+                        last_blob[t] = (b, off, n)
+                        done_q.put((s_, t, b, n, off))
             except Exception as e:   # pragma: no cover
                 errors.append(e)
                 done_q.put((-1, t, 0, 0, 0))
@@ -377,6 +404,7 @@ def main():
         """k steps: thread t encodes steps t, t+inflight, ...; the main thread takes them in step order and either exchanges the
         sizes (sharded container) or hands the blob to the gatherer (overlapped gather to rank 0), then recycles the buffer"""
         done_q = queue.Queue()
+        handoff = dist_on                       # N > 1: the main thread takes every step's blob (size exchange / gather) before its buffer is reused
         free_q = [queue.Queue() for _ in range(inflight)]
         for fq in free_q:
             fq.put(0)
@@ -384,12 +412,16 @@ def main():
         errors = []
         stop = threading.Event()
         for t in range(inflight):
-            job_q[t].put((k, free_q[t], done_q, stop, errors))
+            job_q[t].put((k, free_q[t] if handoff else None, done_q, stop, errors))
         pending, nxt, last_n, finished = {}, 0, 0, 0
         while finished < inflight:
             s_, t, b, n, off = done_q.get()
             if s_ == -2:
                 finished += 1
+                continue
+            if s_ == -3:                        # (one GPU) a thread's block is done: remember where its last blob sits
+                last_at[0] = (t, b, off)
+                last_n = n
                 continue
             if s_ < 0:
                 stop.set()

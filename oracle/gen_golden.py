@@ -231,9 +231,40 @@ def headline():
     print("wrote", os.path.join(GOLD, "headline.json"))
 
 
+def accel():
+    """tests/golden/accel.json: liblz4 1.9.3 with an acceleration above 1 -- sqeazy's lz4(accel=-k), a negative LZ4F compression level
+    (encoders/lz4.hpp:103-113) -- block level, the chunked layout and the serial block-linked layout; asserts oracle == liblz4 on the way"""
+    assert ref.available() and ref.lz4_version() == 10903
+    A = {"_meta": {"generator": "oracle/gen_golden.py --accel", "liblz4": "1.9.3 (LZ4_versionNumber 10903)",
+                   "mapping": "sqeazy accel = LZ4F compressionLevel; level -k -> LZ4_compress_fast_continue acceleration k + 1 (lz4frame.c), capped at 65537"},
+         "cases": []}
+    for kind in ["zeros", "random", "2level", "8level", "ramp", "slowramp", "sparse", "words", "period7", "farrep", "rawmix", "periodic"]:
+        for n in (10000, 262144, 600000):
+            d = gen_bytes(kind, n, 4000 + n)
+            for level in (-1, -3, -64, -70000):
+                a = o.lz4_acceleration(level)
+                rb = ref.lz4_block(d, accel=a)
+                assert rb == o.lz4_block_compress(d, acceleration=a), ("block", kind, n, level)
+                cfg = o.Lz4Config("accel=%d" % level)
+                rc = ref.lz4_encode_parallel(d, accel=level, nthreads=2)
+                assert np.array_equal(rc, o.lz4_encode_chunked(d, cfg)), ("chunked", kind, n, level)
+                rs = ref.lz4_encode_serial(d, framestep=cfg.bytes_per_chunk(n), accel=level)
+                assert np.array_equal(rs, o.lz4_encode_serial(d, cfg)), ("serial", kind, n, level)
+                A["cases"].append({"kind": kind, "n": n, "seed": 4000 + n, "accel": level, "acceleration": a,
+                                   "block_csize": 0 if rb is None else len(rb), "block_sha256": None if rb is None else sha(rb),
+                                   "chunked_bytes": int(rc.size), "chunked_sha256": sha(rc.tobytes()),
+                                   "serial_bytes": int(rs.size), "serial_sha256": sha(rs.tobytes()), "source": "liblz4-1.9.3"})
+    with open(os.path.join(GOLD, "accel.json"), "w") as f:
+        json.dump(A, f, indent=1, sort_keys=True)
+    print("wrote", os.path.join(GOLD, "accel.json"), "with", len(A["cases"]), "cases")
+
+
 if __name__ == "__main__":
-    if "--headline" in sys.argv:
+    if "--accel" in sys.argv:
+        accel()
+    elif "--headline" in sys.argv:
         headline()
     else:
         main()
+        accel()
         headline()

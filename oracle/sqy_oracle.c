@@ -278,6 +278,13 @@ int sqo_diff3x3x1_decode_i8(const uint8_t* in, uint8_t* out, const size_t shape[
 #define LZ4_SKIPTRIGGER 6
 #define LZ4_HASHLOG 12
 
+/* liblz4's `acceleration` (LZ4_compress_fast_continue's last argument): 1 for sqeazy's accel = 0..2; LZ4F turns a negative
+ * compression level -k (sqeazy: lz4(accel=-k), encoders/lz4.hpp:103-113) into acceleration k + 1 (lz4frame.c 1.9.3,
+ * LZ4F_compressBlock / LZ4F_compressBlock_continue), lz4.c caps it at LZ4_ACCELERATION_MAX = 65537.  The search then starts with
+ * searchMatchNb = acceleration << 6 instead of 1 << 6.  Set by the test that drives the oracle (not thread safe: test infrastructure). */
+static int sqo_lz4_acceleration = 1;
+void sqo_lz4_set_acceleration(int a) { sqo_lz4_acceleration = a < 1 ? 1 : (a > 65537 ? 65537 : a); }
+
 static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
 
@@ -314,7 +321,7 @@ int sqo_lz4_block_compress(const uint8_t* src, int n, uint8_t* dst, int cap)
         {
             const uint8_t* forwardIp = ip;
             int step = 1;
-            int searchMatchNb = 1 << LZ4_SKIPTRIGGER;
+            int searchMatchNb = sqo_lz4_acceleration << LZ4_SKIPTRIGGER;
             do {
                 const uint32_t h = forwardH;
                 const uint32_t current = (uint32_t)(forwardIp - base);
@@ -612,7 +619,7 @@ static int lz4_block_continue(lz4_stream_model* st, const uint8_t* s0, uint64_t 
         {
             const uint8_t* forwardIp = ip;
             int step = 1;
-            int searchMatchNb = 1 << LZ4_SKIPTRIGGER;
+            int searchMatchNb = sqo_lz4_acceleration << LZ4_SKIPTRIGGER;
             do {
                 const uint32_t h = forwardH;
                 const uint32_t current = IDX(forwardIp);

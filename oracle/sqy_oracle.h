@@ -45,6 +45,8 @@ size_t sqo_diff3x3x1_offsets(const size_t shape[3], size_t* out, size_t cap, siz
 /* ---- LZ4 block, liblz4 1.9.3 LZ4_compress_fast_continue(fresh stream, .., cap, accel=1) ----
  * returns compressed size, 0 when the result does not fit `cap`. */
 int sqo_lz4_block_compress(const uint8_t* src, int n, uint8_t* dst, int cap);
+/* liblz4's acceleration for every later sqo_lz4_* compress call (1 = default; k + 1 for sqeazy's lz4(accel=-k)); not thread safe */
+void sqo_lz4_set_acceleration(int a);
 /* plain LZ4 block decoder (format spec); returns decoded size or -1 */
 int sqo_lz4_block_decompress(const uint8_t* src, int n, uint8_t* dst, int cap);
 

@@ -161,13 +161,33 @@ def diff3x3x1_offsets(shape):
     return out[:n], hx.value
 
 
-def lz4_block_compress(data, cap=None):
+def lz4_acceleration(accel):
+    """liblz4's acceleration for sqeazy's `accel` (= LZ4F compressionLevel, encoders/lz4.hpp:103-113): a negative level -k means
+    acceleration k + 1 (lz4frame.c 1.9.3, LZ4F_compressBlock), capped at 65537 (lz4.c); levels 0..2 mean 1"""
+    return min(1 - int(accel), 65537) if accel < 0 else 1
+
+
+class _Acceleration:
+    """sets the C restatement's acceleration for the calls inside the block (module state: not thread safe, test infrastructure)"""
+
+    def __init__(self, a):
+        self.a = int(a)
+
+    def __enter__(self):
+        lib().sqo_lz4_set_acceleration(ctypes.c_int(self.a))
+
+    def __exit__(self, *exc):
+        lib().sqo_lz4_set_acceleration(ctypes.c_int(1))
+
+
+def lz4_block_compress(data, cap=None, acceleration=1):
     src = np.frombuffer(bytes(data), dtype=np.uint8) if not isinstance(data, np.ndarray) else _c(data, np.uint8)
     n = src.size
     if cap is None:
         cap = n - 1
     dst = np.zeros(max(cap, 1) + 16, dtype=np.uint8)
-    r = lib().sqo_lz4_block_compress(_ptr(src, _u8p), ctypes.c_int(n), _ptr(dst, _u8p), ctypes.c_int(cap))
+    with _Acceleration(acceleration):
+        r = lib().sqo_lz4_block_compress(_ptr(src, _u8p), ctypes.c_int(n), _ptr(dst, _u8p), ctypes.c_int(cap))
     return dst[:r].tobytes() if r > 0 else None
 
 
@@ -251,8 +271,9 @@ def lz4_encode_chunked(data, cfg=None):
         raise NotImplementedError("accel >= 3 selects LZ4HC in liblz4 (not restated)")
     nchunks = (n + chunk - 1) // chunk if n else 1
     dst = _lz4_dst(n, cfg, nchunks)
-    r = lib().sqo_lz4_encode_chunked(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(chunk),
-                                     ctypes.c_int(cfg.block_id))
+    with _Acceleration(lz4_acceleration(cfg.accel)):
+        r = lib().sqo_lz4_encode_chunked(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(chunk),
+                                         ctypes.c_int(cfg.block_id))
     if r == 0:
         raise ValueError("lz4 configuration not encodable")
     return dst[:r]
@@ -270,8 +291,9 @@ def lz4_encode_serial(data, cfg=None, framestep=None):
     if framestep is None:
         framestep = cfg.bytes_per_chunk(n) if n else 1
     dst = _lz4_dst(n, cfg, 1)
-    r = lib().sqo_lz4_encode_serial(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(framestep),
-                                    ctypes.c_int(cfg.block_id))
+    with _Acceleration(lz4_acceleration(cfg.accel)):
+        r = lib().sqo_lz4_encode_serial(_ptr(src, _u8p), ctypes.c_size_t(n), _ptr(dst, _u8p), ctypes.c_size_t(framestep),
+                                        ctypes.c_int(cfg.block_id))
     if r == 0:
         raise ValueError("lz4 configuration not encodable")
     return dst[:r]

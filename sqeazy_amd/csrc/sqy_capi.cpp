@@ -47,6 +47,34 @@ std::atomic<bool> g_prof_on{false};
 std::mutex g_prof_mu;
 std::vector<ProfEntry> g_prof;
 
+// Timing events are pooled (created once, reused by every later call): creating and destroying two events per kernel cost the
+// calls of a profiled run tens of microseconds of host time each.
+std::mutex g_evpool_mu;
+std::vector<hipEvent_t> g_evpool[16];           // per device (an event belongs to the device it was created on)
+int ev_dev()
+{
+    int d = 0;
+    return (hipGetDevice(&d) == hipSuccess && d >= 0 && d < 16) ? d : -1;
+}
+hipEvent_t ev_take()
+{
+    const int d = ev_dev();
+    if (d >= 0) {
+        std::lock_guard<std::mutex> lock(g_evpool_mu);
+        if (!g_evpool[d].empty()) { hipEvent_t e = g_evpool[d].back(); g_evpool[d].pop_back(); return e; }
+    }
+    hipEvent_t e = nullptr;
+    return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
+void ev_give(hipEvent_t e)
+{
+    if (!e) return;
+    const int d = ev_dev();
+    if (d < 0) { hipEventDestroy(e); return; }
+    std::lock_guard<std::mutex> lock(g_evpool_mu);
+    g_evpool[d].push_back(e);
+}
+
 struct ProfScope {
     hipStream_t s;
     PendingEvent ev{};
@@ -56,7 +84,8 @@ struct ProfScope {
     {
         if (!on) return;
         ev.name = name;
-        if (hipEventCreate(&ev.a) != hipSuccess || hipEventCreate(&ev.b) != hipSuccess) { on = false; return; }
+        ev.a = ev_take(); ev.b = ev_take();
+        if (!ev.a || !ev.b) { ev_give(ev.a); ev_give(ev.b); on = false; return; }
         hipEventRecord(ev.a, s);
     }
     ~ProfScope()
@@ -79,8 +108,8 @@ void prof_collect(std::vector<PendingEvent>& pending)
             g_prof[i].ms += ms;
             g_prof[i].launches += 1;
         }
-        hipEventDestroy(p.a);
-        hipEventDestroy(p.b);
+        ev_give(p.a);
+        ev_give(p.b);
     }
     pending.clear();
 }
@@ -269,7 +298,7 @@ struct DrainOnExit {
         if (side) (void)hipStreamSynchronize(side);
         if (!pending->empty()) {
             if (g_prof_on.load()) prof_collect(*pending);
-            else { for (PendingEvent& p : *pending) { hipEventDestroy(p.a); hipEventDestroy(p.b); } pending->clear(); }
+            else { for (PendingEvent& p : *pending) { ev_give(p.a); ev_give(p.b); } pending->clear(); }
         }
     }
 };
@@ -671,6 +700,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
             }
             case StageKind::lz4: {
                 lz4p = &st.lz4;
+                // liblz4's acceleration: LZ4F turns a negative compression level -k into acceleration k + 1 (lz4frame.c, LZ4F_compressBlock),
+                // LZ4_compress_fast_continue caps it at 65537 (lz4.c, LZ4_ACCELERATION_MAX)
+                const uint32_t lz4_accel = st.lz4.accel < 0 ? (uint32_t)std::min<int64_t>(1 - (int64_t)st.lz4.accel, 65537) : 1u;
                 lz4_total = cur_len * (uint64_t)cur_elem;
                 lz4_chunk = lz4_total ? st.lz4.bytes_per_chunk(lz4_total) : 1;
                 lz4_nchunks = lz4_total ? (lz4_total + lz4_chunk - 1) / lz4_chunk : 0;
@@ -698,7 +730,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         ProfScope ps("lz4_chunks", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                        static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo, lz4_dup_of,
-                                                       lz4_in_stride));
+                                                       lz4_in_stride, lz4_accel));
                     }
                     SQY_HIP(hipMemcpyAsync(ws->pinned, d_redo, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                     SQY_HIP(hipStreamSynchronize(stream));
@@ -731,7 +763,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     {
                         ProfScope ps("lz4_linked", stream, pend);
                         SQY_HIP(sqy::launch_lz4_linked(cur, d_blocks, d_first, nframes, plan.max_block, static_cast<uint8_t*>(ws->lz4_scratch.p),
-                                                       lz4_stride, static_cast<uint32_t*>(ws->csize.p), stream));
+                                                       lz4_stride, static_cast<uint32_t*>(ws->csize.p), stream, lz4_accel));
                     }
                     SQY_HIP(hipStreamSynchronize(stream));                 // `plan` (host) is read by the async copies above
                     lz4_blocks = d_blocks;

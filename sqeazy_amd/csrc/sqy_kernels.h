@@ -48,7 +48,8 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 // there (redo[0] = count, redo[1..] = chunk numbers); launch_lz4_chunks_dense then parses exactly those
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
-                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr, uint64_t in_stride = 0);
+                             uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr, uint64_t in_stride = 0,
+                             uint32_t acceleration = 1);     // liblz4's acceleration (1, or k + 1 for sqeazy's lz4(accel=-k))
 hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                                    uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
                                    const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0, uint64_t in_stride = 0);
@@ -64,7 +65,7 @@ struct Lz4Block {
 // block-linked frames: wavefront f compresses blocks [frame_first[f], frame_first[f+1]) in order, hash table carried from
 // block to block; block k -> scratch + k*stride, csize[k] (0 = store raw).  max_block = largest blocks[k].n (<= 4 MiB)
 hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const uint32_t* frame_first, uint64_t nframes,
-                             uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream);
+                             uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream, uint32_t acceleration = 1);
 // frame_off[k] = byte offset of frame k in the concatenated stream, frame_off[nchunks] = total payload bytes
 // (blocks != nullptr: offset of what block k contributes -- frame header if it opens a frame, size field, body, end mark
 // if it closes one)

@@ -829,13 +829,19 @@ constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positio
 // and parsed again by the DENSE = true kernel, which resolves several sequences per batch; the host launches that one over
 // exactly the listed chunks, and only when there are any.  Two kernels instead of one keep the lean loop of the first pass
 // free of the dense batches' registers (and the dense batches free to use a larger window).
-template <bool LINKED, bool DENSE>
+// ACCEL = true (round 4): liblz4's acceleration above 1 (sqeazy's lz4(accel=-k): LZ4F turns a negative compression level into
+// acceleration k + 1, lz4frame.c LZ4F_compressBlock / _continue) -- the search then strides: searchMatchNb starts at
+// acceleration << 6, so the increments between probes are 1, 1, a, a, .. (a = acceleration) growing by one every 64 probes.
+// A separate instantiation that only takes the generic path with the general probe positions (the lean loop, the dense
+// batches and the no-hit batches are built on the stride-1 start and stay out): exact, not fast -- a rarely used setting --
+// and the acceleration-1 kernels keep their code.
+template <bool LINKED, bool DENSE, bool ACCEL = false>
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk, uint64_t in_stride,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
-                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of SQY_DIAG_ARG)
+                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
@@ -990,7 +996,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // batch of 64 probes spans a KiB, later several -- most probes lie behind the resident range and are read from global
             // memory anyway, and refilling the ring up to P + AHEAD would cost an HBM round trip per batch for bytes nobody reads.
             // The ring is left behind then; the first match restarts it (ensure's "jumped past everything" path).
-            if (U < LZ4_RINGLESS_U) w.ensure(P);
+            if (ACCEL || U < LZ4_RINGLESS_U) w.ensure(P);
 
             uint32_t f = 64, fcand = 0;      // first matching probe of the batch and its candidate
             uint32_t ipf = 0;                // its position
@@ -1267,7 +1273,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 }
                 if (failed) break;
             }
-            if (U == 0) {
+            if (!ACCEL && U == 0) {
                 // Enter the loop with no load of the compiler's own in flight (results the generic path left unused
                 // count): otherwise its waitcnt pass puts a vmcnt(0) in front of the loop's first ring read, and that
                 // one would wait for the ring block in flight on EVERY iteration.
@@ -1441,7 +1447,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // atomics of one instruction did not run in lane order) proves nothing; then, and on any tag hit, the buckets are put
             // back and the batch goes through the generic code below.
             // (first pass and linked frames only: the dense kernel sees chunks of short sequences, and is 3 % slower with this loop compiled in)
-            while (!DENSE && !batch_done && U >= LZ4_RINGLESS_U && put2 == 0xffffffffu) {
+            while (!DENSE && !ACCEL && !batch_done && U >= LZ4_RINGLESS_U && put2 == 0xffffffffu) {
                 const uint32_t s_first = (62 + U) >> 6;
                 const uint32_t ustar = 64 * (s_first + 1) - 62;
                 const uint32_t u = U + lane;
@@ -1469,13 +1475,28 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             }
             if (!batch_done) {
                 if (U != 0) SQY_REASON(6); else SQY_REASON(7);
-                const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
-                const uint32_t ustar = 64 * (s_first + 1) - 62;          // first unified index with step s_first+1
-                const uint32_t u = U + lane;
-                const uint32_t bump = u > ustar ? u - ustar : 0;          // #earlier lanes already at the larger step
-                const uint32_t pos = P + s_first * lane + bump;
-                const uint32_t adv = (u >= ustar) ? s_first + 1 : s_first;
-                const uint32_t nxt = pos + adv;
+                uint32_t pos, nxt;
+                if (!ACCEL) {
+                    const uint32_t s_first = (62 + U) >> 6 ? (62 + U) >> 6 : 1;
+                    const uint32_t ustar = 64 * (s_first + 1) - 62;      // first unified index with step s_first+1
+                    const uint32_t u = U + lane;
+                    const uint32_t bump = u > ustar ? u - ustar : 0;      // #earlier lanes already at the larger step
+                    pos = P + s_first * lane + bump;
+                    const uint32_t adv = (u >= ustar) ? s_first + 1 : s_first;
+                    nxt = pos + adv;
+                } else {
+                    // probe u (0 = the position right behind a match, 1 = the next byte / a block's first probe) sits S(u) bytes behind
+                    // probe 0: increments 1, 1, then (64 a + j) >> 6 for j = 0, 1, ..  (64-bit: a may be as large as 65537)
+                    auto S = [&](uint64_t u) -> uint64_t {
+                        if (u <= 2) return u;
+                        const uint64_t m = u - 2, q = m >> 6, r = m & 63;
+                        return 2 + 64 * ((uint64_t)accel * q + q * (q - 1) / 2) + r * ((uint64_t)accel + q);
+                    };
+                    const uint64_t s0 = S(U), s1 = S((uint64_t)U + lane) - s0, s2 = S((uint64_t)U + lane + 1) - s0;
+                    const uint64_t lim = (uint64_t)mflimitPlusOne + 1;    // (anything beyond is "not valid"; keeps the sums inside 32 bits)
+                    pos = (uint32_t)(P + s1 < lim ? P + s1 : lim);
+                    nxt = (uint32_t)(P + s2 < lim ? P + s2 : lim);
+                }
                 const bool valid = nxt <= mflimitPlusOne;
                 const uint64_t vmask = ballot(valid);                     // a prefix of the lanes
                 nvalid = (uint32_t)__builtin_popcountll(vmask);
@@ -3707,7 +3728,7 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride)
+                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride, uint32_t acceleration)
 {
     if (nchunks == 0) return hipSuccess;
     if (in_stride == 0) in_stride = chunk;
@@ -3716,8 +3737,12 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
         const hipError_t e = hipMemsetAsync(redo, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of SQY_DIAG_NULL);
+    if (acceleration > 1)    // (no dense second pass: the list stays empty)
+        hipLaunchKernelGGL((lz4_chunks_kernel<false, false, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
+                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, dup_of, acceleration SQY_DIAG_NULL);
+    else
+        hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
+                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of, 1u SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -3728,17 +3753,21 @@ hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t c
     if (redo_count == 0) return hipSuccess;
     if (in_stride == 0) in_stride = chunk;
     hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr SQY_DIAG_NULL);
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr, 1u SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
 hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const uint32_t* frame_first, uint64_t nframes,
-                             uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream)
+                             uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream, uint32_t acceleration)
 {
     if (nframes == 0) return hipSuccess;
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                       (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr SQY_DIAG_NULL);
+    if (acceleration > 1)
+        hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration SQY_DIAG_NULL);
+    else
+        hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u SQY_DIAG_NULL);
     return hipGetLastError();
 }
 

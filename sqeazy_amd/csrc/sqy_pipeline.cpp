@@ -452,7 +452,6 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
             case StageKind::lz4:
                 if (i + 1 != p.stages.size()) return fail("lz4 must be the last stage on MI355X");
                 if (st.lz4.accel >= 3) return fail("lz4 accel >= 3 selects LZ4HC in liblz4; not implemented on MI355X");
-                if (st.lz4.accel < 0) return fail("lz4 accel < 0 raises liblz4's acceleration above 1; not implemented on MI355X");
                 break;
             case StageKind::pass_through:
                 break;

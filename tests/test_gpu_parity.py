@@ -255,3 +255,32 @@ def test_lz4_large_blocks(sqy, oracle, kb):
     assert blob == oracle.pipeline_encode(pipeline, vol)
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back, vol)
+
+
+# ---- liblz4 acceleration above 1: lz4(accel=-k) (oracle pinned by tests/golden/accel.json) ----
+@pytest.mark.parametrize("accel", [-1, -3, -64, -70000])
+@pytest.mark.parametrize("nthreads", [2, 1])
+def test_lz4_negative_accel(sqy, oracle, accel, nthreads):
+    """a negative sqeazy `accel` is a negative LZ4F compression level: liblz4 strides its search (acceleration -accel + 1).  Byte streams
+    of every kind, both layouts (chunked frames / one block-linked frame), sizes with a ragged last chunk"""
+    from oracle.gen_golden import gen_bytes
+    assert sqy.pipeline_possible("lz4(accel=%d)" % accel, np.uint8)
+    for kind in ("zeros", "random", "8level", "sparse", "words", "farrep", "rawmix", "periodic"):
+        for n in (70000, 2 * 262144 + 12345):
+            vol = gen_bytes(kind, n, 4000 + n).reshape(1, 1, -1)
+            pipe = "lz4(accel=%d)" % accel
+            rc, blob = sqy.encode(pipe, vol, nthreads=nthreads)
+            assert rc == 0, (kind, n)
+            want = oracle.pipeline_encode(pipe, vol, nthreads=nthreads)
+            assert blob == want, "%s n=%d accel=%d nthreads=%d differs (len %d vs %d)" % (kind, n, accel, nthreads, len(blob), len(want))
+            rc, back = sqy.decode(blob)
+            assert rc == 0 and np.array_equal(back, vol)
+
+
+def test_bitswap1_lz4_negative_accel_u16(sqy, oracle):
+    vol = synth.stack((32, 128, 128))
+    for pipe in ("bitswap1->lz4(accel=-1)", "diff3x3x1->bitswap1->lz4(accel=-2)", "bitswap1->lz4(accel=-4,blocksize_kb=64,framestep_kb=256)"):
+        for nthreads in (2, 1):
+            rc, blob = sqy.encode(pipe, vol, nthreads=nthreads)
+            assert rc == 0, pipe
+            assert blob == oracle.pipeline_encode(pipe, vol, nthreads=nthreads), (pipe, nthreads)

@@ -142,3 +142,25 @@ def test_live_liblz4_linked_blocks(oracle):
             for step in (100000, 300001, 65536, 262145, 999999, 5_000_000, int(rng.integers(1000, 700000))):
                 want = ref.lz4_encode_serial(d, framestep=step, block_id=bid)
                 assert np.array_equal(oracle.lz4_encode_serial(d, cfg, framestep=step), want), (kb, step)
+
+
+# ---- liblz4 acceleration above 1: sqeazy's lz4(accel=-k) ----
+A = json.load(open(os.path.join(GOLD, "accel.json")))
+
+
+@pytest.mark.parametrize("case", A["cases"], ids=lambda c: "%s_%d_accel%d" % (c["kind"], c["n"], c["accel"]))
+def test_lz4_acceleration_vs_liblz4_golden(oracle, case):
+    d = gen_bytes(case["kind"], case["n"], case["seed"])
+    assert oracle.lz4_acceleration(case["accel"]) == case["acceleration"]
+    c = oracle.lz4_block_compress(d, acceleration=case["acceleration"])
+    if case["block_csize"] == 0:
+        assert c is None
+    else:
+        assert len(c) == case["block_csize"] and sha(c) == case["block_sha256"]
+    cfg = oracle.Lz4Config("accel=%d" % case["accel"])
+    f = oracle.lz4_encode_chunked(d, cfg)
+    assert f.size == case["chunked_bytes"] and sha(f.tobytes()) == case["chunked_sha256"]
+    assert np.array_equal(oracle.lz4_decode_frames(f, case["n"]), d)
+    f = oracle.lz4_encode_serial(d, cfg)
+    assert f.size == case["serial_bytes"] and sha(f.tobytes()) == case["serial_sha256"]
+    assert np.array_equal(oracle.lz4_decode_frames(f, case["n"]), d)
