@@ -538,11 +538,18 @@ def bitshuffle(a, block_size=0, decode=False):
     return out.view(a.dtype).reshape(a.shape)
 
 
-def frame_shuffle_encode(a, char=False):
-    """char=True: the tail filter form (frames of signed bytes: the metric sums values from -128 to 127)"""
+def frame_shuffle_encode(a, char=False, chunk=1):
+    """char=True: the tail filter form (frames of signed bytes: the metric sums values from -128 to 127).
+    chunk = frame_chunk_size: `chunk` consecutive frames are one sort unit (frame_shuffle_utils.hpp:105-133, encode_full) -- the
+    stage on Z / chunk frames of chunk * Y * X voxels; only whole multiples (the reference's remainder path is not restated)"""
     a = np.ascontiguousarray(a)
     if a.ndim != 3:
         raise ValueError("frame_shuffle needs a 3D shape")
+    if chunk != 1:
+        if chunk < 1 or a.shape[0] % chunk:
+            raise NotImplementedError("frame_shuffle: frames are no whole multiple of frame_chunk_size (encode_with_remainder is not restated)")
+        out, dmap = frame_shuffle_encode(a.reshape(a.shape[0] // chunk, a.shape[1] * chunk, a.shape[2]), char=char)
+        return out.reshape(a.shape), dmap
     out = np.empty_like(a)
     dmap = np.zeros(a.shape[0], dtype=np.uint64)
     if char:
@@ -851,7 +858,7 @@ def pipeline_encode(pipeline, vol, nthreads=2):
         elif s.name == "frame_shuffle":
             if seen_sink and cur.shape != vol.shape:
                 cur = cur.reshape(1, 1, -1)
-            cur, dmap = frame_shuffle_encode(cur, char=seen_sink)
+            cur, dmap = frame_shuffle_encode(cur, char=seen_sink, chunk=s.chunk)
             s.map = to_verbatim(dmap)
         elif s.name == "raster_reorder":
             if seen_sink:
@@ -954,9 +961,12 @@ def pipeline_decode(blob):
                 v = np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
             # (frames with equal metrics: the map names one frame several times and others not at all -- those the reference leaves as
             # its output buffer had them, frame_shuffle_utils.hpp:337-344; here, and in the product, they are zeros)
-            out = np.zeros_like(v)
-            out[dmap.astype(np.int64)] = v
-            cur = out
+            if v.shape[0] % s.chunk:
+                raise ValueError("frame_shuffle: frame_chunk_size does not divide the frames")
+            units = v.reshape(v.shape[0] // s.chunk, -1)                       # frame_chunk_size frames per sort unit
+            out = np.zeros_like(units)
+            out[dmap.astype(np.int64)] = units
+            cur = out.reshape(v.shape)
         else:
             raise NotImplementedError(s.name)
     return np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])

@@ -613,7 +613,21 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 // (tail filter: signed bytes; ONE frame {1, 1, bytes} when the sink did not write one byte per voxel)
                 const bool tail = pipe.sink_index >= 0 && (int)si > pipe.sink_index;
                 const bool flat = tail && cur_len * (uint64_t)cur_elem != len;
-                const uint64_t Z = flat ? 1 : dims[0], per_frame = flat ? cur_len : dims[1] * dims[2];
+                // frame_chunk_size = N: N consecutive frames are one sort unit (frame_shuffle_utils.hpp:105-133, encode_full) -- the stage
+                // on Z / N "frames" of N * Y * X voxels.  Z % N != 0 takes the reference's encode_with_remainder (Boost's P^2 median
+                // estimate as the metric, :193-260): not reproduced
+                uint64_t fcs = 1;
+                {
+                    auto c = st.cfg.find("frame_chunk_size");
+                    if (c != st.cfg.end()) fcs = (uint64_t)std::max(std::atoi(c->second.c_str()), 0);
+                }
+                const uint64_t Z0 = flat ? 1 : dims[0];
+                if (fcs == 0 || Z0 % fcs != 0) {
+                    std::fprintf(stderr, "[sqeazy]\t frame_shuffle: %llu frames are no whole multiple of frame_chunk_size=%llu; the reference's remainder path "
+                                         "(a P^2 median estimate as the metric) is not reproduced; refused\n", (unsigned long long)Z0, (unsigned long long)fcs);
+                    return 1;
+                }
+                const uint64_t Z = Z0 / fcs, per_frame = (flat ? cur_len : dims[1] * dims[2]) * fcs;
                 if (ws->small.ensure(std::max<uint64_t>(Z * 16, 4096))) return 1;
                 float* d_sums = static_cast<float*>(ws->small.p);
                 uint64_t* d_map = reinterpret_cast<uint64_t*>(static_cast<uint8_t*>(ws->small.p) + ((Z * 4 + 15) & ~(uint64_t)15));
@@ -653,7 +667,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     SQY_HIP(hipStreamSynchronize(stream));                 // `map` (host) is read by the async copy above
                     cur = out;
                 }
-                st.cfg["frame_chunk_size"] = "1";
+                st.cfg["frame_chunk_size"] = std::to_string(fcs);
                 st.cfg["reorder_map"] = sqy::to_verbatim(map.data(), Z * sizeof(uint64_t));   // frame_shuffle_scheme_impl.hpp:86-90
                 break;
             }
@@ -1259,8 +1273,15 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 auto it = st.cfg.find("reorder_map");
                 // (as a tail filter behind a sink that did not write one byte per voxel the stream is ONE frame: {1, 1, bytes})
                 const bool one_frame = sink_index >= 0 && (int)si > sink_index && n_in != n;
-                const uint64_t Z = one_frame ? 1 : h.shape[0];
-                const uint64_t frame_bytes_dec = one_frame ? stage_in_bytes : h.shape[1] * h.shape[2] * (uint64_t)e_in;
+                uint64_t fcs = 1;
+                {
+                    auto c = st.cfg.find("frame_chunk_size");
+                    if (c != st.cfg.end()) fcs = (uint64_t)std::max(std::atoi(c->second.c_str()), 0);
+                }
+                const uint64_t Z0 = one_frame ? 1 : h.shape[0];
+                if (fcs == 0 || Z0 % fcs != 0) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: frame_chunk_size does not divide the frames\n"); return 1; }
+                const uint64_t Z = Z0 / fcs;
+                const uint64_t frame_bytes_dec = (one_frame ? stage_in_bytes : h.shape[1] * h.shape[2] * (uint64_t)e_in) * fcs;
                 if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: no reorder_map in the header\n"); return 1; }
                 const std::vector<unsigned char> mapb = sqy::base64_decode(it->second.substr(10, it->second.size() - 21));
                 if (mapb.size() != Z * 8) { std::fprintf(stderr, "[sqeazy]\t frame_shuffle: malformed reorder_map\n"); return 1; }

@@ -102,6 +102,28 @@ def test_frame_shuffle_label_stacks(oracle):
     assert list(dmap) == [3, 1, 0, 0]
 
 
+def test_frame_shuffle_chunks_of_frames_label_stacks(oracle):
+    """test_frame_shuffle_scheme_impl.cpp:241-300,325-380 (reverse_2 / reverse_3, encode and round trip): frame_chunk_size = N sorts
+    UNITS of N frames.  The 8^3 cube labelled per pair of frames in descending order (label_stack_by_frame_reverse(.., 2), :70-92)
+    comes out labelled 0, 1, 2, 3 per pair; per unit of 4 frames it round-trips; 8 % 3 != 0 is the remainder path (not restated)"""
+    frame = 64
+    rev2 = np.repeat(np.arange(3, -1, -1, dtype=np.uint16), 2 * frame).reshape(8, 8, 8)
+    out, dmap = oracle.frame_shuffle_encode(rev2, chunk=2)
+    assert np.array_equal(out.reshape(-1), np.repeat(np.arange(4, dtype=np.uint16), 2 * frame))
+    assert list(dmap) == [3, 2, 1, 0]
+    assert out[0, 0, 0] != out.reshape(-1)[2 * frame]
+    rev4 = np.repeat(np.arange(1, -1, -1, dtype=np.uint16), 4 * frame).reshape(8, 8, 8)
+    out, dmap = oracle.frame_shuffle_encode(rev4, chunk=4)
+    assert list(dmap) == [1, 0] and np.array_equal(out.reshape(-1), np.repeat(np.arange(2, dtype=np.uint16), 4 * frame))
+    # the whole pipeline stage: config string and round trip
+    blob = oracle.pipeline_encode("frame_shuffle(frame_chunk_size=2)->lz4", rev2)
+    h = oracle.header_unpack(blob)
+    assert h["pipename"].startswith("frame_shuffle(frame_chunk_size=2,reorder_map=<verbatim>")
+    assert np.array_equal(oracle.pipeline_decode(blob), rev2)
+    with pytest.raises(NotImplementedError):
+        oracle.frame_shuffle_encode(rev2, chunk=3)
+
+
 def test_quantiser_ramp_histogram_and_exact_lut(oracle):
     """test_quantiser_impl.cpp:862-876 (ramp histogram is all ones); test_sqeazy_pipelines_impl.cpp:347-398
     (<= 256 levels quantise without loss)"""
