@@ -703,8 +703,11 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     // quantiser_scheme_impl.hpp:200-204: the decode LUT goes to the file the caller named, else into the header
                     auto lp = st.cfg.find("decode_lut_path");
                     if (lp != st.cfg.end()) {
-                        if (!sqy::quantiser_lut_to_file(lp->second, lut_decode, 256))
-                            std::fprintf(stderr, "[sqeazy]\t quantiser: unable to write the decode LUT to %s\n", lp->second.c_str());   // (the reference does not notice)
+                        if (!sqy::quantiser_lut_to_file(lp->second, lut_decode, 256)) {
+                            // (the reference does not notice and returns a blob nobody can decode; here the encode fails)
+                            std::fprintf(stderr, "[sqeazy]\t quantiser: unable to write the decode LUT to %s\n", lp->second.c_str());
+                            return 1;
+                        }
                     } else
                         st.cfg["decode_lut_string"] = sqy::to_verbatim(lut_decode, sizeof(lut_decode));
                 }
@@ -1618,7 +1621,8 @@ static int encode_slabs(const char* pipeline, const void* d_src, const long* sha
     if (inflight > nslabs) inflight = nslabs;
     if (inflight > (int)kMaxCtxPerDev) inflight = (int)kMaxCtxPerDev;
     std::atomic<int> first_error(0);
-    auto worker = [&](int t) {
+    for (int i = 0; i < nslabs; ++i) { offsets[i] = 0; lengths[i] = 0; }      // (defined whatever happens below)
+    auto work = [&](int t) {
         if (hipSetDevice(dev) != hipSuccess) { int z = 0; first_error.compare_exchange_strong(z, 1); return; }
         for (int i = t; i < nslabs && first_error.load() == 0; i += inflight) {
             const long z0 = (long)i * base + std::min<long>(i, rem), nz = base + (i < rem ? 1 : 0);
@@ -1642,8 +1646,21 @@ static int encode_slabs(const char* pipeline, const void* d_src, const long* sha
             lengths[i] = len;
         }
     };
+    // no exception leaves a worker (a thrown std::bad_alloc etc. becomes the call's error code), and the threads are joined on every
+    // way out of this function -- they hold references to its locals (round-3 advice)
+    auto worker = [&](int t) {
+        try { work(t); }
+        catch (const std::exception& e) { std::fprintf(stderr, "[sqeazy]\t slab worker: %s\n", e.what()); int z = 0; first_error.compare_exchange_strong(z, 1); }
+        catch (...) { int z = 0; first_error.compare_exchange_strong(z, 1); }
+    };
     std::vector<std::thread> th;
-    for (int t = 1; t < inflight; ++t) th.emplace_back([&, t]() { guarded([&]() -> int { worker(t); return 0; }); });
+    struct Joiner { std::vector<std::thread>& t; ~Joiner() { for (auto& x : t) if (x.joinable()) x.join(); } } joiner{th};
+    try {
+        th.reserve((size_t)inflight);
+        for (int t = 1; t < inflight; ++t) th.emplace_back(worker, t);
+    } catch (...) {                                                            // (no thread to be had: the call fails, the threads that did start are joined)
+        int z = 0; first_error.compare_exchange_strong(z, 1);
+    }
     worker(0);
     for (auto& x : th) x.join();
     return first_error.load();

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <sstream>
+#include <sys/stat.h>
 #include <thread>
 
 namespace sqy {
@@ -655,16 +656,26 @@ bool quantiser_lut_to_file(const std::string& path, const uint16_t* lut, size_t 
     return std::fclose(f) == 0;
 }
 
+// The path may come out of a blob's header, i.e. from untrusted input (decode): only a REGULAR file of at most 64 KiB is opened (a
+// FIFO or a device would block the call or feed it without end), and it has to hold exactly n values that fit 16 bits -- a short
+// or garbled file is an error here, where the reference decodes with whatever its stream extraction left in the table.
 bool quantiser_lut_from_file(const std::string& path, uint16_t* lut, size_t n)
 {
     for (size_t i = 0; i < n; ++i) lut[i] = 0;
+    struct stat sb;
+    if (::stat(path.c_str(), &sb) != 0 || !S_ISREG(sb.st_mode) || sb.st_size > (64 << 10)) return false;
     FILE* f = std::fopen(path.c_str(), "r");
     if (!f) return false;
-    unsigned v = 0;
+    unsigned long v = 0;
     size_t i = 0;
-    while (i < n && std::fscanf(f, "%u", &v) == 1) lut[i++] = (uint16_t)v;
+    bool ok = true;
+    while (i < n && std::fscanf(f, "%lu", &v) == 1) {
+        if (v > 65535ul) { ok = false; break; }
+        lut[i++] = (uint16_t)v;
+    }
+    if (ok && i == n && std::fscanf(f, "%lu", &v) == 1) ok = false;          // more than n values
     std::fclose(f);
-    return true;
+    return ok && i == n;
 }
 
 void quantiser_build_luts(const uint32_t* histo, size_t nbins, unsigned char* lut_encode, uint16_t* lut_decode,

@@ -134,37 +134,46 @@ int SQYAMD_Gather_Blobs(void* comm_v, int root, const void* d_blob, long nbytes,
 {
     return guarded([&]() -> int {
     Rccl& R = rccl();
-    if (!R.ok || !comm_v || nbytes < 0 || !sizes || (nbytes > 0 && !d_blob)) return 1;
+    // Without a communicator this rank cannot take part in anything; every OTHER local failure is carried through the protocol,
+    // so that all ranks return 1 together instead of one rank leaving and the others waiting for it until the RCCL time-out
+    // (round-3 advice): bad arguments and allocation failures travel as the size -1 in the first all-gather, anything that goes
+    // wrong after it as a 0 in the second one, and a group that has been started is always ended.
+    if (!R.ok || !comm_v) return 1;
     ncclComm_t comm = static_cast<ncclComm_t>(comm_v);
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     int world = 0, rank = -1;
     SQY_NCCL(R.CommCount(comm, &world));
     SQY_NCCL(R.CommUserRank(comm, &rank));
-    if (root < 0 || root >= world) return 1;
+    bool local_ok = nbytes >= 0 && sizes && !(nbytes > 0 && !d_blob) && root >= 0 && root < world;
     // 1. the sizes: one 8-byte all-gather (device buffers: a small allocation of this call)
     long long* d_sizes = nullptr;
-    SQY_HIPC(hipMalloc(reinterpret_cast<void**>(&d_sizes), sizeof(long long) * (size_t)(world + 1)));
+    if (hipMalloc(reinterpret_cast<void**>(&d_sizes), sizeof(long long) * (size_t)(world + 1)) != hipSuccess) {
+        std::fprintf(stderr, "[sqeazy]\t gather: no device memory for the size exchange\n");
+        return 1;                                                         // (nothing to send the news with)
+    }
     struct Free { long long* p; ~Free() { if (p) (void)hipFree(p); } } free_sizes{d_sizes};
-    const long long mine = nbytes;
+    const long long mine = local_ok ? nbytes : -1;
     SQY_HIPC(hipMemcpyAsync(d_sizes + world, &mine, sizeof(mine), hipMemcpyHostToDevice, stream));
     SQY_NCCL(R.AllGather(d_sizes + world, d_sizes, 1, ncclInt64, comm, stream));
     std::vector<long long> h(world);
     SQY_HIPC(hipMemcpyAsync(h.data(), d_sizes, sizeof(long long) * (size_t)world, hipMemcpyDeviceToHost, stream));
     SQY_HIPC(hipStreamSynchronize(stream));
     uint64_t total = 0;
+    bool all_ok = true;
     for (int r = 0; r < world; ++r) {
-        if (h[r] < 0) return 1;
-        sizes[r] = (long)h[r];
+        if (h[r] < 0) { all_ok = false; continue; }
+        if (sizes) sizes[r] = (long)h[r];
         total += (uint64_t)h[r];
     }
-    if (rank == root && (!d_recv || total > (uint64_t)(recv_capacity < 0 ? 0 : recv_capacity))) {
-        std::fprintf(stderr, "[sqeazy]\t gather: %llu bytes do not fit the root's buffer\n", (unsigned long long)total);
-        // (every rank still has to take part in the exchange below, or the others would wait for the root: fail after it)
+    if (!all_ok) {
+        if (local_ok) std::fprintf(stderr, "[sqeazy]\t gather: another rank reported a failure\n");
+        return 1;                                                         // every rank sees the same sizes: all return 1 here
     }
     const bool root_ok = rank != root || (d_recv && total <= (uint64_t)(recv_capacity < 0 ? 0 : recv_capacity));
+    if (!root_ok) std::fprintf(stderr, "[sqeazy]\t gather: %llu bytes do not fit the root's buffer\n", (unsigned long long)total);
     // 2. the blobs: grouped point-to-point transfers into the root's buffer, rank order; the root's own blob is a device copy.
-    //    A root without room receives into nothing -- it posts no receives, and tells the senders so through the second
-    //    all-gather below BEFORE anybody posts a send (no rank may be left waiting in a send that is never matched).
+    //    Whether everybody is still fit for it -- a root without room receives into nothing -- is settled by a second all-gather
+    //    BEFORE anybody posts a send (no rank may be left waiting in a send that is never matched).
     long long* d_flag = d_sizes;                                          // reuse: world + 1 words
     const long long okflag = root_ok ? 1 : 0;
     SQY_HIPC(hipMemcpyAsync(d_flag + world, &okflag, sizeof(okflag), hipMemcpyHostToDevice, stream));
@@ -172,18 +181,26 @@ int SQYAMD_Gather_Blobs(void* comm_v, int root, const void* d_blob, long nbytes,
     std::vector<long long> f(world);
     SQY_HIPC(hipMemcpyAsync(f.data(), d_flag, sizeof(long long) * (size_t)world, hipMemcpyDeviceToHost, stream));
     SQY_HIPC(hipStreamSynchronize(stream));
-    if (!f[root]) return 1;                                               // every rank returns 1 together
-    SQY_NCCL(R.GroupStart());
-    if (rank == root) {
-        uint64_t off = 0;
-        for (int r = 0; r < world; ++r) {
-            if (r != root && h[r] > 0) SQY_NCCL(R.Recv(static_cast<char*>(d_recv) + off, (size_t)h[r], ncclChar, r, comm, stream));
-            off += (uint64_t)h[r];
+    for (int r = 0; r < world; ++r)
+        if (!f[r]) return 1;                                              // every rank returns 1 together
+    int rc = 0;
+    auto nccl_ok = [&](ncclResult_t r_, const char* what) {
+        if (r_ != ncclSuccess) { std::fprintf(stderr, "[sqeazy]\t RCCL error %d in %s\n", (int)r_, what); rc = 1; }
+    };
+    nccl_ok(R.GroupStart(), "ncclGroupStart");
+    if (rc == 0) {
+        if (rank == root) {
+            uint64_t off = 0;
+            for (int r = 0; r < world && rc == 0; ++r) {
+                if (r != root && h[r] > 0) nccl_ok(R.Recv(static_cast<char*>(d_recv) + off, (size_t)h[r], ncclChar, r, comm, stream), "ncclRecv");
+                off += (uint64_t)h[r];
+            }
+        } else if (nbytes > 0) {
+            nccl_ok(R.Send(d_blob, (size_t)nbytes, ncclChar, root, comm, stream), "ncclSend");
         }
-    } else if (nbytes > 0) {
-        SQY_NCCL(R.Send(d_blob, (size_t)nbytes, ncclChar, root, comm, stream));
+        nccl_ok(R.GroupEnd(), "ncclGroupEnd");                            // (always: an open group would stay with the communicator)
     }
-    SQY_NCCL(R.GroupEnd());
+    if (rc) return 1;
     if (rank == root && nbytes > 0) {
         uint64_t off = 0;
         for (int r = 0; r < root; ++r) off += (uint64_t)h[r];

@@ -131,11 +131,11 @@ class SlabGatherer:
         """queue `blob[:nbytes]` (must stay untouched until on_done runs) for the gather; returns at once.
         Raises what an earlier gather hit (on every rank: see _run), after which nothing more is queued."""
         if self.error is not None:
-            # the peers post in step with this rank: its next gather still takes place, with the poison size, so that they
-            # raise there as well; nothing is queued after that
-            if not self._poisoned:
-                self._poisoned = True
-                self._q.put((blob, -1, on_done))
+            # the peers post in step with this rank, and some of them may have queued several gathers before they notice: EVERY
+            # later post of this rank still takes place, with the poison size, so that each of their queued gathers finds its
+            # partner and raises instead of waiting in an all_gather nobody joins (round-3 advice: one poison gather was not enough)
+            self._poisoned = True
+            self._q.put((blob, -1, on_done))
             raise self.error
         self._q.put((blob, int(nbytes), on_done))
 

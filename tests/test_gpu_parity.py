@@ -218,6 +218,24 @@ def test_quantiser_decode_lut_path(sqy, oracle, tmp_path):
     assert b"decode_lut_string" not in blob[:oracle.header_unpack(blob)["size"]]
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back, oracle.pipeline_decode(want))
+    # the path in a blob's header is untrusted input: a short or garbled table, a table with too many values, something that is no
+    # regular file (round-3 advice) make the decode fail instead of decoding with a wrong table or blocking on a FIFO
+    import os
+    good = lut.read_text()
+    for bad in ("1\n2\n3\n", "abc\n" * 256, good + "7\n", good.replace("\n", " 70000\n", 1)):
+        lut.write_text(bad)
+        rc, _ = sqy.decode(blob)
+        assert rc != 0
+    lut.unlink()
+    os.mkfifo(lut)
+    try:
+        rc, _ = sqy.decode(blob)                              # (would block for ever on open() if the FIFO were opened)
+        assert rc != 0
+    finally:
+        lut.unlink()
+    # an encode that cannot write its table fails (the reference returns a blob nobody can decode)
+    rc, _ = sqy.encode("quantiser(decode_lut_path=%s)->lz4" % (tmp_path / "no" / "such" / "dir" / "a.lut"), vol, nthreads=2)
+    assert rc == 1
 
 
 @pytest.mark.parametrize("pipeline", ["raster_reorder->lz4", "raster_reorder(tile_size=4)->bitswap1->lz4", "raster_reorder(tile_size=5)",
