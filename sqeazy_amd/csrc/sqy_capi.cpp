@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <climits>
 #include <cstdint>
 #include <cstdio>
@@ -222,6 +223,16 @@ struct Context {
     hipStream_t side = nullptr;         // decode: stored frames are copied here while the compressed ones are decoded
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t t_done = nullptr;        // recorded behind this call's bit-plane transpose (the transposes of calls in flight run one after the other)
+    hipStream_t hi = nullptr;           // EXPERIMENT (SQY_EXP_HIPRIO): a high-priority stream for everything behind the transpose
+    hipStream_t hi_stream()
+    {
+        if (!hi) {
+            int lo = 0, high = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &high) != hipSuccess) high = 0;
+            if (hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, high) != hipSuccess) hi = nullptr;
+        }
+        return hi;
+    }
     hipStream_t own_stream()
     {
         if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
@@ -242,11 +253,11 @@ struct Context {
 
 constexpr int kMaxDev = 16;
 constexpr size_t kMaxCtxPerDev = 8;
-// EXPERIMENT (SQY_EXP_TCHAIN): the bit-plane transposes of the calls in flight on one device are chained on the GPU (a stream waits
-// for the previous call's transpose before it starts its own): two HBM-bound kernels side by side each run at half speed, one after
-// the other the first call's parse starts a transpose earlier.
+// the chain of the bit-plane transposes of the calls in flight on one device (see the bitswap1 stage): the event behind the last
+// transpose launched, and when that was
 std::mutex g_tchain_mu[kMaxDev];
 hipEvent_t g_tchain_last[kMaxDev] = {};
+std::chrono::steady_clock::time_point g_tchain_when[kMaxDev];
 std::mutex g_pool_mu;
 std::condition_variable g_pool_cv;
 std::vector<std::unique_ptr<Context>> g_pool[kMaxDev];
@@ -292,10 +303,12 @@ struct DrainOnExit {
     hipStream_t s;
     std::vector<PendingEvent>* pending;
     hipStream_t side = nullptr;         // the context's side stream (decode)
+    hipStream_t hi = nullptr;
     ~DrainOnExit()
     {
         (void)hipStreamSynchronize(s);
         if (side) (void)hipStreamSynchronize(side);
+        if (hi) (void)hipStreamSynchronize(hi);
         if (!pending->empty()) {
             if (g_prof_on.load()) prof_collect(*pending);
             else { for (PendingEvent& p : *pending) { ev_give(p.a); ev_give(p.b); } pending->clear(); }
@@ -390,6 +403,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     const uint16_t* bsw_side = nullptr;
     uint32_t bsw_side_w = 0, bsw_side_X = 0;
     uint64_t* lz4_tail_info = nullptr;
+    bool dedupe_cleared = false;                 // the duplicate search's table and the dense list's counter were zeroed in front of the transpose
+    bool inplace_done = false;                   // frames in place, finished on the device: where the blob is
+    uint64_t inplace_blob_at = 0, inplace_blob_bytes = 0, inplace_hdr_bytes = 0;
     uint64_t* lz4_holes = nullptr;               // frames in place: which 1 KiB pieces of the plane stream the transpose left unwritten (all zero)
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
@@ -423,6 +439,10 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                 inplace_t0 = t0;
                                 lz4_in_stride = chunk + 15;
                                 lz4_inplace = true;
+                                // (one small kernel in front of the transpose instead of three fill dispatches between the kernels behind it)
+                                if (ws->plan.ensure((nch + 1) * sizeof(uint32_t))) return 1;
+                                SQY_HIP(sqy::launch_lz4_dedupe_clear(static_cast<uint8_t*>(ws->dedupe.p) + ph_bytes, nch, static_cast<uint32_t*>(ws->plan.p), stream));
+                                dedupe_cleared = true;
                             }
                         }
                     }
@@ -430,14 +450,23 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 uint8_t* out = gap_chunk ? static_cast<uint8_t*>(d_dst) + inplace_t0 + 11 : next_buf(cur_len * cur_elem);
                 if (!out) return 1;
                 if (!gap_chunk && ph && (reinterpret_cast<uintptr_t>(out) & 15)) { ph = nullptr; lz4_piece_hash = nullptr; }
-                static const bool tchain = std::getenv("SQY_EXP_TCHAIN") != nullptr;
+                // The bit-plane transposes of the calls in flight on one device run one after the other (round 4): a stream waits for the
+                // transpose of the call in front before it starts its own.  Two HBM-bound kernels side by side each run at half speed
+                // and end together; chained, the first call's parse starts a whole transpose earlier (bench, four calls in flight:
+                // +3 %; also chaining the duplicate search behind it: -12 %, measured and not kept).  Only a transpose launched within
+                // the last few milliseconds is waited for, so that a caller whose stream is stuck behind other work holds nobody up for
+                // long; SQY_NO_TRANSPOSE_CHAIN=1 in the environment switches the chain off.
+                static const bool tchain = std::getenv("SQY_NO_TRANSPOSE_CHAIN") == nullptr;
                 int devid = 0;
                 const bool chain = tchain && gap_chunk && hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < kMaxDev;
                 std::unique_lock<std::mutex> tlock;
                 if (chain) {
                     if (!cx.t_done && hipEventCreateWithFlags(&cx.t_done, hipEventDisableTiming) != hipSuccess) return 1;
                     tlock = std::unique_lock<std::mutex>(g_tchain_mu[devid]);
-                    if (g_tchain_last[devid] && g_tchain_last[devid] != cx.t_done) SQY_HIP(hipStreamWaitEvent(stream, g_tchain_last[devid], 0));
+                    const auto now = std::chrono::steady_clock::now();
+                    if (g_tchain_last[devid] && g_tchain_last[devid] != cx.t_done && now - g_tchain_when[devid] < std::chrono::milliseconds(5))
+                        SQY_HIP(hipStreamWaitEvent(stream, g_tchain_last[devid], 0));
+                    g_tchain_when[devid] = now;
                 }
                 {
                 ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
@@ -451,6 +480,14 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     SQY_HIP(hipEventRecord(cx.t_done, stream));
                     g_tchain_last[devid] = cx.t_done;
                     tlock.unlock();
+                    static const bool hiprio = std::getenv("SQY_EXP_HIPRIO") != nullptr;
+                    if (hiprio && cx.hi_stream()) {
+                        // everything behind the transpose on a high-priority stream: the later stages of a call in flight go in front of
+                        // the transposes of the calls behind it when workgroups are dispatched
+                        SQY_HIP(hipStreamWaitEvent(cx.hi, cx.t_done, 0));
+                        drain.hi = cx.hi;
+                        stream = cx.hi;
+                    }
                 }
                 bsw_side = nullptr; bsw_side_w = 0; bsw_side_X = 0;       // (consumed: a later bitswap1 of the pipeline reads its plain input)
                 cur = out;
@@ -738,7 +775,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         uint32_t* d_dup = reinterpret_cast<uint32_t*>(base + sqy::lz4_dedupe_work_bytes(lz4_nchunks));
                         if (lz4_inplace) lz4_holes = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(d_dup) + ((lz4_nchunks * 4 + 7) & ~(uint64_t)7));
                         ProfScope ps("lz4_dedupe", stream, pend);
-                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride, lz4_holes));
+                        SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride, lz4_holes,
+                                                       dedupe_cleared));
+
                         lz4_dup_of = d_dup;
                     }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
@@ -747,17 +786,65 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         ProfScope ps("lz4_chunks", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                        static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo, lz4_dup_of,
-                                                       lz4_in_stride, lz4_accel));
+                                                       lz4_in_stride, lz4_accel, dedupe_cleared));
                     }
-                    SQY_HIP(hipMemcpyAsync(ws->pinned, d_redo, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                    SQY_HIP(hipStreamSynchronize(stream));
-                    const uint32_t n_redo = *static_cast<uint32_t*>(ws->pinned);
-                    if (n_redo) {
+                    auto dense_pass = [&](uint32_t n_redo) -> int {
                         ProfScope ps("lz4_chunks_dense", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks_dense(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
                                                              static_cast<uint32_t*>(ws->csize.p), d_redo, n_redo, stream, lz4_frame_map, lz4_frame_bytes,
                                                              lz4_in_stride));
+                        return 0;
+                    };
+                    std::string hdr_prefix, hdr_suffix;
+                    if (lz4_inplace && !(fq && fq->every > 0)) sqy::header_pack_parts(elem_size, false, dims, pipe.name(), &hdr_prefix, &hdr_suffix);
+                    if (lz4_inplace && !hdr_prefix.empty() && hdr_prefix.size() + hdr_suffix.size() <= sqy::kLz4InplaceHeaderTextMax) {
+                        // Frames in place, ONE host round trip per call (round 4): frame scan + tail marks, the stored chunks in front of
+                        // the tail put aside, the gather and the sqy header are all queued behind the parse right away and take what
+                        // they need (where the stored tail begins, the payload size) from device memory; what the host has to know
+                        // comes back through pinned memory with the one synchronisation.  Only when the parse left chunks to the
+                        // dense pass (streams of short sequences: seldom on microscopy stacks) do these kernels return untouched --
+                        // they look at the list's counter -- and run again behind the dense pass.
+                        const unsigned char fd[2] = {0x40, (unsigned char)(st.lz4.block_id << 4)};
+                        const uint32_t hc = (sqy::xxh32(fd, 2, 0) >> 8) & 0xff;
+                        uint8_t* outb = static_cast<uint8_t*>(d_dst);
+                        volatile uint64_t* record = static_cast<volatile uint64_t*>(ws->pinned);
+                        auto tail = [&](const uint32_t* guard) -> int {
+                            record[0] = 0;
+                            {
+                                ProfScope ps("lz4_frame_scan", stream, pend);
+                                SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
+                                                                   static_cast<uint64_t*>(ws->frame_off.p), stream, nullptr, lz4_dup_of, lz4_tail_info, guard,
+                                                                   outb + inplace_t0 + 11, lz4_in_stride, fd[1], hc));
+                            }
+                            ProfScope ps("lz4_frame_gather", stream, pend);
+                            SQY_HIP(sqy::launch_lz4_inplace_tail(outb, inplace_t0, lz4_in_stride, lz4_total, (uint32_t)lz4_chunk, lz4_nchunks,
+                                                                 static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride, static_cast<uint32_t*>(ws->csize.p),
+                                                                 static_cast<uint64_t*>(ws->frame_off.p), lz4_dup_of, lz4_tail_info, fd[1], hc,
+                                                                 hdr_prefix.data(), (uint32_t)hdr_prefix.size(), hdr_suffix.data(), (uint32_t)hdr_suffix.size(),
+                                                                 (uint32_t)elem_size, guard, const_cast<uint64_t*>(record), stream));
+                            return 0;
+                        };
+                        if (tail(d_redo)) return 1;
+                        SQY_HIP(hipStreamSynchronize(stream));
+                        if (record[0] == 2) {
+                            if (dense_pass((uint32_t)record[6])) return 1;
+                            if (tail(nullptr)) return 1;
+                            SQY_HIP(hipStreamSynchronize(stream));
+                        }
+                        if (record[0] != 1) {
+                            std::fprintf(stderr, "[sqeazy]\t internal error: frames in place did not finish (status %llu)\n", (unsigned long long)record[0]);
+                            return 1;
+                        }
+                        inplace_done = true;
+                        inplace_blob_at = record[1]; inplace_blob_bytes = record[2]; payload_bytes = record[3];
+                        inplace_hdr_bytes = inplace_blob_bytes - payload_bytes;
+                        payload_is_lz4 = true;
+                        break;
                     }
+                    SQY_HIP(hipMemcpyAsync(ws->pinned, d_redo, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                    SQY_HIP(hipStreamSynchronize(stream));
+                    const uint32_t n_redo = *static_cast<uint32_t*>(ws->pinned);
+                    if (n_redo && dense_pass(n_redo)) return 1;
                 } else if (lz4_total) {
                     // block-linked frames: the serial layout (nthreads == 1) or chunks that span several LZ4 blocks.  The table
                     // of a frame is carried from block to block, so one wavefront walks each frame (lz4_utils.hpp:99-173)
@@ -801,6 +888,17 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
         }
     }
 
+    if (inplace_done) {
+        if (payload_bytes > (uint64_t)INT_MAX) {
+            std::fprintf(stderr, "[sqeazy]\t lz4: %llu payload bytes overflow the reference's int byte count\n", (unsigned long long)payload_bytes);
+            return 1;
+        }
+        if (g_prof_on.load()) prof_collect(cx.pending);
+        *dstoffset = (long)inplace_blob_at;
+        *dstlength = (long)inplace_blob_bytes;
+        (void)inplace_hdr_bytes;
+        return 0;
+    }
     // ---- payload size ----
     uint64_t tail_j = 0, tail_head_bytes = 0, tail_raw_head = 0;
     if (payload_is_lz4) {

@@ -25,7 +25,10 @@ uint64_t lz4_dedupe_work_bytes(uint64_t nchunks);
 // marker, 0); launch_lz4_dedupe(.., holes_map: scratch of lz4_holes_map_bytes) compares through the markers and then fills the pieces
 // in (writes into `in`) for every chunk anybody will read -- the bit planes above the data's range are neither written nor read
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0, uint64_t* holes_map = nullptr);
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0, uint64_t* holes_map = nullptr,
+                             bool table_is_clear = false);
+// the search's table emptied and *zero_word = 0 by one small kernel (a call launches it in front of its bit-plane transpose)
+hipError_t launch_lz4_dedupe_clear(void* work, uint64_t nchunks, uint32_t* zero_word, hipStream_t stream);
 uint64_t lz4_holes_map_bytes(uint64_t nchunks, uint32_t chunk);
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream);
 
@@ -49,7 +52,8 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
                              uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr, uint64_t in_stride = 0,
-                             uint32_t acceleration = 1);     // liblz4's acceleration (1, or k + 1 for sqeazy's lz4(accel=-k))
+                             uint32_t acceleration = 1,      // liblz4's acceleration (1, or k + 1 for sqeazy's lz4(accel=-k))
+                             bool redo_is_zero = false);     // redo[0] has been zeroed already (launch_lz4_dedupe_clear)
 hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                                    uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
                                    const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0, uint64_t in_stride = 0);
@@ -71,7 +75,22 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
 // if it closes one)
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
                                  uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks = nullptr,
-                                 const uint32_t* dup_of = nullptr, uint64_t* tail_info = nullptr);
+                                 const uint32_t* dup_of = nullptr, uint64_t* tail_info = nullptr,
+                                 // frames in place, one host round trip per call: guard[0] != 0 (chunks left to the dense pass) makes the
+                                 // kernel return at once; body0 != nullptr: the stored tail's frame marks are written here as well
+                                 const uint32_t* guard = nullptr, uint8_t* body0 = nullptr, uint64_t in_stride = 0, uint32_t bd_byte = 0,
+                                 uint32_t hc_byte = 0);
+// Frames in place: everything between the frame scan and the finished blob, driven from the device -- the stored chunks in front of
+// the tail put aside, the frames in front of the tail gathered up against it, the sqy header (hdr_prefix | payload bytes in decimal |
+// hdr_suffix, padded in front to a multiple of elem_size) written in front of them.  record (pinned host memory, 7 words) takes
+// [0] 1 done / 2 dense pass needed (guard[0] != 0: nothing was touched) / 3 no room for the header, [1] blob offset in `out`,
+// [2] blob bytes, [3] payload bytes, [4] chunks in front of the stored tail, [5] stored chunks among them, [6] guard[0].
+hipError_t launch_lz4_inplace_tail(uint8_t* out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
+                                   uint8_t* scratch, uint64_t stride, const uint32_t* csize, const uint64_t* frame_off, const uint32_t* dup_of,
+                                   const uint64_t* tail_info, uint32_t bd_byte, uint32_t hc_byte, const char* hdr_prefix, uint32_t prefix_len,
+                                   const char* hdr_suffix, uint32_t suffix_len, uint32_t elem_size, const uint32_t* guard, uint64_t* record,
+                                   hipStream_t stream);
+constexpr uint32_t kLz4InplaceHeaderTextMax = 3000;   // prefix + suffix bytes the finish kernel takes as an argument
 // Frames in place (chunked layout; the stage in front wrote chunk k of the stream at body0 + k * in_stride, in_stride = chunk + 15):
 // tail_info (4 words, from the scan) = {j, bytes of frames 0..j-1, stored chunks among them, payload bytes}, j = first chunk of
 // the run of stored chunks that ends the stream.  Those are final where they stand: tail_marks writes header / size field / end

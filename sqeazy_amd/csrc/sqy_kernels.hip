@@ -16,6 +16,7 @@
 #include <mutex>
 #include <stdint.h>
 #include <cstdlib>
+#include <cstring>
 
 #include "sqy_kernels.h"
 
@@ -1824,15 +1825,21 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 // field and body, plus the 7-byte frame header when it opens a frame and the 4-byte end mark when it closes one.
 // tail_info != nullptr (frames in place): [0] = j, the first chunk of the run of stored chunks that ends the stream (nchunks when
 // the last chunk compressed), [1] = bytes of the frames in front of it, [2] = stored chunks among those, [3] = payload bytes
+// Round 4 (one host round trip per call): `guard` != nullptr and guard[0] != 0 -- the parse left chunks to the dense second pass,
+// the sizes are not final -- makes this kernel and the ones behind it (stash, gather, finish) return at once; the host runs the
+// second pass and launches them again without a guard.  body0 != nullptr: the tail marks (frame header, size field, end mark of
+// the stored chunks that end the stream, lz4_tail_marks_kernel) are written here as well.
 __global__ __launch_bounds__(1024)
 void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
                            uint64_t* __restrict__ frame_off /* nchunks + 1 */, const Lz4Block* __restrict__ blocks,
-                           const uint32_t* __restrict__ dup_of, uint64_t* __restrict__ tail_info)
+                           const uint32_t* __restrict__ dup_of, uint64_t* __restrict__ tail_info, const uint32_t* __restrict__ guard,
+                           uint8_t* __restrict__ body0, uint64_t in_stride, uint32_t bd_byte, uint32_t hc_byte)
 {
     __shared__ uint64_t wsum[16];
     __shared__ uint64_t carry_s;
     __shared__ uint32_t last_comp_s, raw_head_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (guard && guard[0] != 0u) return;
     if (tid == 0) { carry_s = 0; last_comp_s = 0; raw_head_s = 0; }
     __syncthreads();
     for (uint64_t base = 0; base < nchunks; base += 1024) {
@@ -1881,6 +1888,17 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
             tail_info[2] = raw_head_s;
             tail_info[3] = carry_s;
         }
+        if (body0) {
+            for (uint64_t k = (uint64_t)j + tid; k < nchunks; k += 1024) {
+                const uint64_t left = total - k * chunk;
+                const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
+                uint8_t* b = body0 + k * in_stride;
+                const uint32_t field = nk | 0x80000000u;
+                b[-11] = 0x04; b[-10] = 0x22; b[-9] = 0x4D; b[-8] = 0x18; b[-7] = 0x40; b[-6] = (uint8_t)bd_byte; b[-5] = (uint8_t)hc_byte;
+                b[-4] = (uint8_t)field; b[-3] = (uint8_t)(field >> 8); b[-2] = (uint8_t)(field >> 16); b[-1] = (uint8_t)(field >> 24);
+                b[nk] = 0; b[nk + 1] = 0; b[nk + 2] = 0; b[nk + 3] = 0;
+            }
+        }
     }
 }
 
@@ -1904,25 +1922,36 @@ void lz4_tail_marks_kernel(uint8_t* __restrict__ body0, uint64_t in_stride, uint
 
 // Stored chunks IN FRONT of that run move (towards higher addresses, over their own and their neighbours' old places): they are
 // first put aside in their -- unused -- compressed-output slots; the gather then reads every frame body from the scratch.
+// tail_info != nullptr (round 4): how many chunks sit in front of the stored tail, and whether any of them is stored at all, is read
+// on the device (tail_info[0], [2]); the grid is a fixed number of blocks that share the (chunk, slice) items among them.
 __global__ __launch_bounds__(256)
 void lz4_stash_raw_kernel(const uint8_t* __restrict__ body0, uint64_t in_stride, uint64_t total, uint32_t chunk,
                           uint8_t* __restrict__ scratch, uint64_t stride, const uint32_t* __restrict__ csize,
-                          const uint32_t* __restrict__ dup_of, uint32_t slices_per_chunk)
+                          const uint32_t* __restrict__ dup_of, uint32_t slices_per_chunk, const uint64_t* __restrict__ tail_info,
+                          const uint32_t* __restrict__ guard)
 {
-    const uint64_t k = blockIdx.x / slices_per_chunk;
-    const uint32_t slice = blockIdx.x % slices_per_chunk;
-    if (csize[dup_of ? dup_of[k] : k] != 0u) return;
-    const uint64_t left = total - k * chunk;
-    const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
-    const uint32_t begin = slice * 32768u;
-    if (begin >= nk) return;
-    const uint32_t end = begin + 32768u < nk ? begin + 32768u : nk;
-    const uint8_t* __restrict__ sp = body0 + k * in_stride + begin;
-    uint8_t* __restrict__ dp = scratch + k * stride + begin;            // 16-byte aligned (stride and slices are)
-    const uint32_t len = end - begin, nvec = len >> 4;
-    for (uint32_t i = threadIdx.x; i < nvec; i += 256) *reinterpret_cast<uint4*>(dp + (size_t)i * 16) = ld_u128(sp + (size_t)i * 16);
-    const uint32_t done = nvec << 4;
-    if (threadIdx.x < len - done) dp[done + threadIdx.x] = sp[done + threadIdx.x];
+    uint64_t nitems = gridDim.x;
+    if (tail_info) {
+        if (guard && guard[0] != 0u) return;
+        if (tail_info[2] == 0) return;
+        nitems = tail_info[0] * slices_per_chunk;
+    }
+    for (uint64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+        const uint64_t k = item / slices_per_chunk;
+        const uint32_t slice = (uint32_t)(item % slices_per_chunk);
+        if (csize[dup_of ? dup_of[k] : k] != 0u) continue;
+        const uint64_t left = total - k * chunk;
+        const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
+        const uint32_t begin = slice * 32768u;
+        if (begin >= nk) continue;
+        const uint32_t end = begin + 32768u < nk ? begin + 32768u : nk;
+        const uint8_t* __restrict__ sp = body0 + k * in_stride + begin;
+        uint8_t* __restrict__ dp = scratch + k * stride + begin;            // 16-byte aligned (stride and slices are)
+        const uint32_t len = end - begin, nvec = len >> 4;
+        for (uint32_t i = threadIdx.x; i < nvec; i += 256) *reinterpret_cast<uint4*>(dp + (size_t)i * 16) = ld_u128(sp + (size_t)i * 16);
+        const uint32_t done = nvec << 4;
+        if (threadIdx.x < len - done) dp[done + threadIdx.x] = sp[done + threadIdx.x];
+    }
 }
 
 // one workgroup per (chunk, slice): copies its slice of the frame body, slice 0 also writes header/trailer
@@ -1934,10 +1963,22 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
                              const uint32_t* __restrict__ csize, const uint64_t* __restrict__ frame_off,
                              uint8_t* __restrict__ out, uint32_t bd_byte, uint32_t hc_byte, uint32_t slices_per_chunk,
                              const uint64_t* __restrict__ fmap, uint64_t fbytes, const Lz4Block* __restrict__ blocks,
-                             const uint32_t* __restrict__ dup_of, uint64_t in_stride, int raw_from_scratch)
+                             const uint32_t* __restrict__ dup_of, uint64_t in_stride, int raw_from_scratch,
+                             const uint64_t* __restrict__ tail_info, uint64_t t0, const uint32_t* __restrict__ guard)
 {
-    const uint64_t k = blockIdx.x / slices_per_chunk;
-    const uint32_t slice = blockIdx.x % slices_per_chunk;
+    // tail_info != nullptr (round 4, frames in place): how many frames there are to gather (tail_info[0]), where they go (they end
+    // where the stored tail begins: out + t0 + [0] * in_stride - [1]) and whether stored chunks among them were put aside in the
+    // scratch ([2]) is read on the device; the grid is a fixed number of blocks that share the (chunk, slice) items among them
+    uint64_t nitems = gridDim.x;
+    if (tail_info) {
+        if (guard && guard[0] != 0u) return;
+        nitems = tail_info[0] * slices_per_chunk;
+        out += t0 + tail_info[0] * in_stride - tail_info[1];
+        raw_from_scratch = tail_info[2] != 0;
+    }
+  for (uint64_t item = blockIdx.x; item < nitems; item += gridDim.x) {
+    const uint64_t k = item / slices_per_chunk;
+    const uint32_t slice = (uint32_t)(item % slices_per_chunk);
     uint32_t nk, flags = 3u;
     uint64_t lin;
     if (blocks) { const Lz4Block bd = blocks[k]; nk = bd.n; lin = bd.start; flags = bd.flags; }
@@ -1975,7 +2016,7 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
         if (on) d[o - (7u - hdr)] = v;
     }
     const uint32_t begin = slice * GATHER_SLICE;
-    if (begin >= body) return;
+    if (begin >= body) continue;
     const uint32_t end = (begin + GATHER_SLICE < body) ? begin + GATHER_SLICE : body;
     uint8_t* __restrict__ dd = d + hdr + 4 + begin;
     const uint8_t* __restrict__ ss = s + begin;
@@ -1996,6 +2037,59 @@ void lz4_frame_gather_kernel(const uint8_t* __restrict__ in, uint64_t total, uin
     }
     const uint32_t done = nvec << 4;
     if ((uint32_t)tid < len - done) dd[done + tid] = ss[done + tid];
+  }
+}
+
+// Frames in place, last kernel of a call (round 4): the sqy header is written on the device -- the text in front of and behind the
+// payload's byte count comes as a kernel argument, the count itself (tail_info[3]) is formatted here, the header ends where the
+// payload begins -- and what the host has to know goes to `record` (pinned host memory): [0] status (1 done, 2 the dense second
+// pass is needed, 3 the header does not fit in front of the payload), [1] blob offset, [2] blob bytes, [3] payload bytes,
+// [4] chunks in front of the stored tail, [5] stored chunks among them, [6] chunks left to the dense pass.
+// One host round trip per call instead of three (dense list, tail, header).
+struct Lz4HeaderParts { uint32_t prefix_len, suffix_len; char text[3000]; };
+
+__global__ __launch_bounds__(256)
+void lz4_inplace_finish_kernel(uint8_t* __restrict__ out, uint64_t t0, uint64_t in_stride, const uint64_t* __restrict__ tail_info,
+                               Lz4HeaderParts hp, uint32_t elem_size, const uint32_t* __restrict__ guard, uint64_t* __restrict__ record)
+{
+    const uint32_t tid = threadIdx.x;
+    if (guard && guard[0] != 0u) {
+        if (tid == 0) { record[6] = guard[0]; record[0] = 2; }
+        return;
+    }
+    const uint64_t tail_j = tail_info[0], head_bytes = tail_info[1], payload = tail_info[3];
+    const uint64_t payload_at = t0 + tail_j * in_stride - head_bytes;
+    char digits[20];
+    uint32_t nd = 0;
+    {
+        uint64_t v = payload;
+        do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);       // (least significant first)
+    }
+    const uint64_t text = (uint64_t)hp.prefix_len + nd + hp.suffix_len;
+    const uint64_t pad = (elem_size - text % elem_size) % elem_size;           // sqeazy_header.hpp:172-178: the header's size is a multiple of the voxel's
+    const uint64_t hdr_len = text + pad;
+    if (hdr_len > payload_at) {
+        if (tid == 0) record[0] = 3;
+        return;
+    }
+    uint8_t* h = out + payload_at - hdr_len;
+    for (uint64_t i = tid; i < hdr_len; i += 256) {
+        uint8_t c;
+        if (i < pad) c = ' ';
+        else if (i < pad + hp.prefix_len) c = (uint8_t)hp.text[i - pad];
+        else if (i < pad + hp.prefix_len + nd) c = (uint8_t)digits[nd - 1 - (i - pad - hp.prefix_len)];
+        else c = (uint8_t)hp.text[hp.prefix_len + (i - pad - hp.prefix_len - nd)];
+        h[i] = c;
+    }
+    if (tid == 0) {
+        record[1] = payload_at - hdr_len;
+        record[2] = hdr_len + payload;
+        record[3] = payload;
+        record[4] = tail_j;
+        record[5] = tail_info[2];
+        record[6] = 0;
+        record[0] = 1;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3614,8 +3708,30 @@ uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len
     return (len / BSW_TILE_VOX) * 16 * 4;
 }
 
+// the duplicate search's table emptied (keys 0, values ~0) and one more word zeroed (the dense pass's list counter) by ONE small kernel
+// that a call can launch in front of its bit-plane transpose: three fill dispatches less between the kernels of a call (round 4)
+__global__ __launch_bounds__(256)
+void lz4_dedupe_clear_kernel(uint64_t* __restrict__ tab_key, uint32_t* __restrict__ tab_val, uint32_t tab, uint32_t* __restrict__ zero_word)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < tab) { tab_key[i] = 0ull; tab_val[i] = 0xffffffffu; }
+    if (i == 0 && zero_word) *zero_word = 0u;
+}
+
+hipError_t launch_lz4_dedupe_clear(void* work, uint64_t nchunks, uint32_t* zero_word, hipStream_t stream)
+{
+    if (nchunks == 0) return hipSuccess;
+    uint32_t tab = 64;
+    while (tab < 2 * nchunks) tab <<= 1;
+    uint64_t* chunk_key = static_cast<uint64_t*>(work);
+    uint64_t* tab_key = chunk_key + nchunks;
+    uint32_t* tab_val = reinterpret_cast<uint32_t*>(tab_key + tab);
+    hipLaunchKernelGGL(lz4_dedupe_clear_kernel, dim3((tab + 255u) / 256u), dim3(256), 0, stream, tab_key, tab_val, tab, zero_word);
+    return hipGetLastError();
+}
+
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride, uint64_t* holes_map)
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride, uint64_t* holes_map, bool table_is_clear)
 {
     const uint64_t nchunks = (total + chunk - 1) / chunk, nfull = total / chunk;
     if (nchunks == 0) return hipSuccess;
@@ -3626,10 +3742,13 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
     uint64_t* chunk_key = static_cast<uint64_t*>(work);
     uint64_t* tab_key = chunk_key + nchunks;
     uint32_t* tab_val = reinterpret_cast<uint32_t*>(tab_key + tab);
-    hipError_t e = hipMemsetAsync(tab_key, 0, (size_t)tab * 8, stream);
-    if (e != hipSuccess) return e;
-    e = hipMemsetAsync(tab_val, 0xff, (size_t)tab * 4, stream);
-    if (e != hipSuccess) return e;
+    hipError_t e = hipSuccess;
+    if (!table_is_clear) {
+        e = hipMemsetAsync(tab_key, 0, (size_t)tab * 8, stream);
+        if (e != hipSuccess) return e;
+        e = hipMemsetAsync(tab_val, 0xff, (size_t)tab * 4, stream);
+        if (e != hipSuccess) return e;
+    }
     if (holes_map && total % 1024u != 0) return hipErrorInvalidValue;
     const uint64_t nkey = holes_map ? nchunks : nfull;
     if (nkey)
@@ -3728,12 +3847,12 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride, uint32_t acceleration)
+                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride, uint32_t acceleration, bool redo_is_zero)
 {
     if (nchunks == 0) return hipSuccess;
     if (in_stride == 0) in_stride = chunk;
     if (frame_map && (frame_bytes == 0 || frame_bytes % chunk != 0)) return hipErrorInvalidValue;
-    if (redo) {
+    if (redo && !redo_is_zero) {
         const hipError_t e = hipMemsetAsync(redo, 0, sizeof(uint32_t), stream);
         if (e != hipSuccess) return e;
     }
@@ -3772,9 +3891,35 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
 }
 
 hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64_t total, uint32_t chunk,
-                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks, const uint32_t* dup_of, uint64_t* tail_info)
+                                 uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks, const uint32_t* dup_of, uint64_t* tail_info,
+                                 const uint32_t* guard, uint8_t* body0, uint64_t in_stride, uint32_t bd_byte, uint32_t hc_byte)
 {
-    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of, tail_info);
+    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of, tail_info,
+                       guard, body0, in_stride, bd_byte, hc_byte);
+    return hipGetLastError();
+}
+
+// ---- frames in place, the tail of a call driven from the device (round 4): no host round trip between the parse and the blob ----
+hipError_t launch_lz4_inplace_tail(uint8_t* out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
+                                   uint8_t* scratch, uint64_t stride, const uint32_t* csize, const uint64_t* frame_off, const uint32_t* dup_of,
+                                   const uint64_t* tail_info, uint32_t bd_byte, uint32_t hc_byte, const char* hdr_prefix, uint32_t prefix_len,
+                                   const char* hdr_suffix, uint32_t suffix_len, uint32_t elem_size, const uint32_t* guard, uint64_t* record,
+                                   hipStream_t stream)
+{
+    Lz4HeaderParts hp;
+    if ((uint64_t)prefix_len + suffix_len > sizeof(hp.text) || nchunks == 0) return hipErrorInvalidValue;
+    hp.prefix_len = prefix_len; hp.suffix_len = suffix_len;
+    std::memcpy(hp.text, hdr_prefix, prefix_len);
+    std::memcpy(hp.text + prefix_len, hdr_suffix, suffix_len);
+    uint8_t* body0 = out + t0 + 11;
+    const uint32_t slices_stash = (chunk + 32767u) / 32768u, slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;
+    const uint64_t stash_items = nchunks * slices_stash, gather_items = nchunks * slices;
+    hipLaunchKernelGGL(lz4_stash_raw_kernel, dim3((unsigned)(stash_items < 1024 ? stash_items : 1024)), dim3(256), 0, stream, body0, in_stride, total, chunk,
+                       scratch, stride, csize, dup_of, slices_stash, tail_info, guard);
+    hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(gather_items < 2048 ? gather_items : 2048)), dim3(256), 0, stream, body0, total, chunk,
+                       scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, (const uint64_t*)nullptr, (uint64_t)0, (const Lz4Block*)nullptr,
+                       dup_of, in_stride, 0, tail_info, t0, guard);
+    hipLaunchKernelGGL(lz4_inplace_finish_kernel, dim3(1), dim3(256), 0, stream, out, t0, in_stride, tail_info, hp, elem_size, guard, record);
     return hipGetLastError();
 }
 
@@ -3793,7 +3938,7 @@ hipError_t launch_lz4_stash_raw(const uint8_t* body0, uint64_t in_stride, uint64
     if (nhead == 0) return hipSuccess;
     const uint32_t slices = (chunk + 32767u) / 32768u;
     hipLaunchKernelGGL(lz4_stash_raw_kernel, dim3((unsigned)(nhead * slices)), dim3(256), 0, stream, body0, in_stride, total, chunk, scratch,
-                       stride, csize, dup_of, slices);
+                       stride, csize, dup_of, slices, (const uint64_t*)nullptr, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 
@@ -3807,7 +3952,7 @@ hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t c
     const uint32_t slices = (chunk + GATHER_SLICE - 1) / GATHER_SLICE;      // (chunk = largest block of the list when `blocks`)
     hipLaunchKernelGGL(lz4_frame_gather_kernel, dim3((unsigned)(nchunks * slices)), dim3(256), 0, stream, in, total, chunk,
                        scratch, stride, csize, frame_off, out, bd_byte, hc_byte, slices, frame_map, frame_bytes, blocks, dup_of, in_stride,
-                       raw_from_scratch ? 1 : 0);
+                       raw_from_scratch ? 1 : 0, (const uint64_t*)nullptr, (uint64_t)0, (const uint32_t*)nullptr);
     return hipGetLastError();
 }
 

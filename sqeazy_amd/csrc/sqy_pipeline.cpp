@@ -529,6 +529,25 @@ static void json_escape(const std::string& s, std::string& out)
     }
 }
 
+// the header as  [pad] prefix | payload bytes in decimal | suffix  (pad: spaces in front up to a multiple of elem_size, which
+// depends on the number of digits): what a kernel needs to write the header once the payload size is known on the device
+void header_pack_parts(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
+                       std::string* prefix, std::string* suffix)
+{
+    // (the byte count is the only number behind `"bytes": "`; the text is searched from the back, where nothing a caller supplies sits)
+    const std::string probe = header_pack(1, is_signed8 && elem_size == 1, shape, pipename, 0);
+    const std::string key = "\"bytes\": \"";
+    const size_t at = probe.rfind(key);
+    *prefix = probe.substr(0, at + key.size());
+    *suffix = probe.substr(at + key.size() + 1);                                    // (behind the single digit "0")
+    if (elem_size == 2) {
+        // header_pack(1, ..) wrote the 8-bit type name; the 16-bit header differs in that word only
+        const std::string t8 = "\"type\": \"uint8\"", t16 = "\"type\": \"uint16\"";
+        const size_t tp = prefix->rfind(t8);
+        if (tp != std::string::npos) prefix->replace(tp, t8.size(), t16);
+    }
+}
+
 std::string header_pack(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
                         uint64_t payload_bytes)
 {

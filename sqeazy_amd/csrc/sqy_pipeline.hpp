@@ -112,6 +112,8 @@ uint64_t bitshuffle_block_elems(int elem_size, uint64_t block_size);
 // ---- header ----
 std::string header_pack(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
                         uint64_t payload_bytes);
+void header_pack_parts(int elem_size, bool is_signed8, const std::vector<uint64_t>& shape, const std::string& pipename,
+                       std::string* prefix, std::string* suffix);
 struct HeaderInfo {
     bool valid = false;
     std::string pipename, type;
