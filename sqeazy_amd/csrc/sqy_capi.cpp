@@ -223,16 +223,6 @@ struct Context {
     hipStream_t side = nullptr;         // decode: stored frames are copied here while the compressed ones are decoded
     hipEvent_t fork = nullptr, join = nullptr;
     hipEvent_t t_done = nullptr;        // recorded behind this call's bit-plane transpose (the transposes of calls in flight run one after the other)
-    hipStream_t hi = nullptr;           // EXPERIMENT (SQY_EXP_HIPRIO): a high-priority stream for everything behind the transpose
-    hipStream_t hi_stream()
-    {
-        if (!hi) {
-            int lo = 0, high = 0;
-            if (hipDeviceGetStreamPriorityRange(&lo, &high) != hipSuccess) high = 0;
-            if (hipStreamCreateWithPriority(&hi, hipStreamNonBlocking, high) != hipSuccess) hi = nullptr;
-        }
-        return hi;
-    }
     hipStream_t own_stream()
     {
         if (!stream && hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) != hipSuccess) stream = nullptr;
@@ -303,12 +293,10 @@ struct DrainOnExit {
     hipStream_t s;
     std::vector<PendingEvent>* pending;
     hipStream_t side = nullptr;         // the context's side stream (decode)
-    hipStream_t hi = nullptr;
     ~DrainOnExit()
     {
         (void)hipStreamSynchronize(s);
         if (side) (void)hipStreamSynchronize(side);
-        if (hi) (void)hipStreamSynchronize(hi);
         if (!pending->empty()) {
             if (g_prof_on.load()) prof_collect(*pending);
             else { for (PendingEvent& p : *pending) { ev_give(p.a); ev_give(p.b); } pending->clear(); }
@@ -403,6 +391,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     const uint16_t* bsw_side = nullptr;
     uint32_t bsw_side_w = 0, bsw_side_X = 0;
     uint64_t* lz4_tail_info = nullptr;
+    sqy::Lz4DedupeArgs lz4_dedupe_args;          // frames in place: the duplicate decision per chunk is made inside the parse kernel
+    bool fused_dedupe = false;
     bool dedupe_cleared = false;                 // the duplicate search's table and the dense list's counter were zeroed in front of the transpose
     bool inplace_done = false;                   // frames in place, finished on the device: where the blob is
     uint64_t inplace_blob_at = 0, inplace_blob_bytes = 0, inplace_hdr_bytes = 0;
@@ -480,14 +470,6 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     SQY_HIP(hipEventRecord(cx.t_done, stream));
                     g_tchain_last[devid] = cx.t_done;
                     tlock.unlock();
-                    static const bool hiprio = std::getenv("SQY_EXP_HIPRIO") != nullptr;
-                    if (hiprio && cx.hi_stream()) {
-                        // everything behind the transpose on a high-priority stream: the later stages of a call in flight go in front of
-                        // the transposes of the calls behind it when workgroups are dispatched
-                        SQY_HIP(hipStreamWaitEvent(cx.hi, cx.t_done, 0));
-                        drain.hi = cx.hi;
-                        stream = cx.hi;
-                    }
                 }
                 bsw_side = nullptr; bsw_side_w = 0; bsw_side_X = 0;       // (consumed: a later bitswap1 of the pipeline reads its plain input)
                 cur = out;
@@ -775,9 +757,11 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         uint32_t* d_dup = reinterpret_cast<uint32_t*>(base + sqy::lz4_dedupe_work_bytes(lz4_nchunks));
                         if (lz4_inplace) lz4_holes = reinterpret_cast<uint64_t*>(reinterpret_cast<uint8_t*>(d_dup) + ((lz4_nchunks * 4 + 7) & ~(uint64_t)7));
                         ProfScope ps("lz4_dedupe", stream, pend);
+                        // frames in place (acceleration 1): only the key table is built here, the decision per chunk (byte compare, hole fill)
+                        // is the first thing the chunk's parse wavefront does (lz4_chunk_dedupe)
+                        fused_dedupe = lz4_inplace && lz4_accel == 1;
                         SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride, lz4_holes,
-                                                       dedupe_cleared));
-
+                                                       dedupe_cleared, fused_dedupe ? &lz4_dedupe_args : nullptr));
                         lz4_dup_of = d_dup;
                     }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
@@ -785,8 +769,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     {
                         ProfScope ps("lz4_chunks", stream, pend);
                         SQY_HIP(sqy::launch_lz4_chunks(cur, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo, lz4_dup_of,
-                                                       lz4_in_stride, lz4_accel, dedupe_cleared));
+                                                       static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo,
+                                                       fused_dedupe ? nullptr : lz4_dup_of, lz4_in_stride, lz4_accel, dedupe_cleared,
+                                                       fused_dedupe ? &lz4_dedupe_args : nullptr));
                     }
                     auto dense_pass = [&](uint32_t n_redo) -> int {
                         ProfScope ps("lz4_chunks_dense", stream, pend);

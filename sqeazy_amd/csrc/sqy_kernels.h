@@ -7,6 +7,18 @@
 
 namespace sqy {
 
+// the duplicate search's tables, handed to launch_lz4_chunks when the decision per chunk is made by the chunk's own parse wavefront
+// (launch_lz4_dedupe(.., fused) fills it in); chunk_key == nullptr: not in use
+struct Lz4DedupeArgs {
+    const uint64_t* chunk_key = nullptr;
+    const uint64_t* tab_key = nullptr;
+    const uint32_t* tab_val = nullptr;
+    uint32_t tab_mask = 0;
+    uint32_t* dup_of = nullptr;          // out: dup_of[k] = k, or the earlier chunk that chunk k equals byte for byte
+    const uint32_t* piece_hash = nullptr;
+    const uint64_t* holes_map = nullptr;
+    uint64_t nchunks_full = 0;
+};
 // bitswap1: bit-plane transpose of `len` elements (encoders/bitswap_scheme_impl.hpp:97-145)
 // piece_hash != nullptr (bitswap1_piece_hash_words(..) words, only offered when that is non-zero): a hash of every 1 KiB piece of
 // plane data is left there for launch_lz4_dedupe
@@ -26,7 +38,7 @@ uint64_t lz4_dedupe_work_bytes(uint64_t nchunks);
 // in (writes into `in`) for every chunk anybody will read -- the bit planes above the data's range are neither written nor read
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
                              uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0, uint64_t* holes_map = nullptr,
-                             bool table_is_clear = false);
+                             bool table_is_clear = false, Lz4DedupeArgs* fused = nullptr);
 // the search's table emptied and *zero_word = 0 by one small kernel (a call launches it in front of its bit-plane transpose)
 hipError_t launch_lz4_dedupe_clear(void* work, uint64_t nchunks, uint32_t* zero_word, hipStream_t stream);
 uint64_t lz4_holes_map_bytes(uint64_t nchunks, uint32_t chunk);
@@ -53,7 +65,8 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map = nullptr,
                              uint64_t frame_bytes = 0, uint32_t* redo = nullptr, const uint32_t* dup_of = nullptr, uint64_t in_stride = 0,
                              uint32_t acceleration = 1,      // liblz4's acceleration (1, or k + 1 for sqeazy's lz4(accel=-k))
-                             bool redo_is_zero = false);     // redo[0] has been zeroed already (launch_lz4_dedupe_clear)
+                             bool redo_is_zero = false,      // redo[0] has been zeroed already (launch_lz4_dedupe_clear)
+                             const Lz4DedupeArgs* dedupe = nullptr);
 hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                                    uint32_t* csize, uint32_t* redo, uint32_t redo_count, hipStream_t stream,
                                    const uint64_t* frame_map = nullptr, uint64_t frame_bytes = 0, uint64_t in_stride = 0);

@@ -550,6 +550,121 @@ void diff3x3x1_u16_rows_kernel(const uint16_t* __restrict__ in, uint16_t* __rest
     }
 }
 
+// diff3x3x1 decode, SEVERAL frames per launch (round 4).  Frame z needs the DECODED frame z-1, so round 3 ran one launch per frame
+// (255 launch-bound kernels of 1 MiB each on a 2048 x 2048 x 256 slab: 1.6 ms).  Here a block owns a strip of R rows and decodes K
+// frames in a row without waiting for anybody: what it needs of its neighbours' strips it computes itself -- frame z+j of rows
+// [y0 - (K-1-j), y1 + (K-1-j)), a halo that shrinks by one row per frame -- starting from the decoded frame z-1, which the launch
+// before has finished.  Two images of the (R + 2K) x w touched columns take turns in LDS; only the block's own rows go to `out`.
+// (K - 1) / R of the work is redundant (K = 8, R = 32: 22 %), the chain is Z / K launches instead of Z.
+// w columns (a multiple of 8, the touched ones and their right-hand neighbour) are decoded; rewritten: 1 <= z < zlim, 1 <= y <= Y - 2,
+// 1 <= x < 1 + hx.  `out` rows are X voxels apart and hold the decoded frames.
+constexpr uint32_t DDK_K = 8, DDK_R = 32, DDK_ROWS = DDK_R + 2 * DDK_K;
+
+constexpr uint32_t DDK_THREADS = 1024, DDK_ITEMS = 2;          // an image is at most DDK_ITEMS * DDK_THREADS (row, vector) items (launcher)
+
+__global__ __launch_bounds__(DDK_THREADS)
+void diff3x3x1_u16_decode_frames_kernel(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint32_t Y, uint32_t X, uint32_t hx,
+                                        uint32_t zlim, uint32_t w, uint32_t z0, uint32_t nframes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint16_t ddk_lds[];   // 2 images of DDK_ROWS rows
+    const uint32_t pitch = w + 16u;                            // voxels per LDS row: [8 .. 8 + w) = columns 0 .. w-1, [8 + w] = column w (16-byte aligned rows)
+    uint16_t* img[2] = {ddk_lds, ddk_lds + (size_t)DDK_ROWS * pitch};
+    const int32_t y0 = (int32_t)(blockIdx.x * DDK_R);
+    const uint64_t frame = (uint64_t)Y * X;
+    const uint32_t vpr = w / 8u;                               // 8-voxel vectors per row; item vpr of a row is the single column w
+    // A thread owns the same (image row, vector) items in every frame: image row i <-> volume row y0 - K + i.  The encoded voxels of
+    // the NEXT frame are fetched while the frame in hand is computed (a block is 16 waves on one CU: nothing else hides the latency).
+    uint32_t it_i[DDK_ITEMS], it_v[DDK_ITEMS];
+    int32_t it_y[DDK_ITEMS];
+    bool it_on[DDK_ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < DDK_ITEMS; ++k) {
+        const uint32_t t = threadIdx.x + k * DDK_THREADS;
+        it_i[k] = t / (vpr + 1u); it_v[k] = t % (vpr + 1u);
+        it_y[k] = y0 - (int32_t)DDK_K + (int32_t)it_i[k];
+        it_on[k] = it_i[k] < DDK_ROWS && it_y[k] >= 0 && it_y[k] < (int32_t)Y;
+    }
+    auto active = [&](uint32_t k, uint32_t j) -> bool {        // frame j of this launch needs rows [y0 - halo, y0 + R + halo), halo = nframes - 1 - j
+        const int32_t halo = (int32_t)(nframes - 1u - j);
+        return it_on[k] && it_y[k] >= y0 - halo && it_y[k] < y0 + (int32_t)DDK_R + halo;
+    };
+    auto fetch = [&](uint32_t k, uint32_t j) -> uint4 {
+        const uint16_t* src = in + (uint64_t)(z0 + j) * frame + (uint64_t)it_y[k] * X;
+        if (it_v[k] < vpr) return *reinterpret_cast<const uint4*>(src + it_v[k] * 8u);
+        return make_uint4(w < X ? (uint32_t)src[w] : 0u, 0u, 0u, 0u);
+    };
+    // 1. the decoded frame z0 - 1 (z0 >= 1), all image rows
+    {
+        const uint16_t* prev = out + (uint64_t)(z0 - 1u) * frame;
+#pragma unroll
+        for (uint32_t k = 0; k < DDK_ITEMS; ++k) {
+            if (!it_on[k]) continue;
+            uint16_t* d = img[0] + (size_t)it_i[k] * pitch + 8u;
+            if (it_v[k] < vpr) *reinterpret_cast<uint4*>(d + it_v[k] * 8u) = *reinterpret_cast<const uint4*>(prev + (uint64_t)it_y[k] * X + it_v[k] * 8u);
+            else d[w] = w < X ? prev[(uint64_t)it_y[k] * X + w] : (uint16_t)0;
+        }
+    }
+    // (measured: ONE frame ahead, 34 us per launch of 8 frames; all 8 frames' voxels fetched up front, 16 loads in flight per thread:
+    // 41 us -- the column copy next to this chain keeps the HBM busy, 0.75 ms of the stage's 1.1 ms are that copy's)
+    uint4 cin[DDK_ITEMS];
+#pragma unroll
+    for (uint32_t k = 0; k < DDK_ITEMS; ++k) cin[k] = active(k, 0) ? fetch(k, 0) : make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    int cur = 0;
+    for (uint32_t j = 0; j < nframes; ++j) {
+        const uint32_t z = z0 + j;
+        uint4 nin[DDK_ITEMS];
+#pragma unroll
+        for (uint32_t k = 0; k < DDK_ITEMS; ++k) nin[k] = (j + 1u < nframes && active(k, j + 1u)) ? fetch(k, j + 1u) : make_uint4(0, 0, 0, 0);
+        uint16_t* dst = out + (uint64_t)z * frame;
+        const uint16_t* A = img[cur];
+        uint16_t* B = img[cur ^ 1];
+        const bool frame_touched = z >= 1u && z < zlim && hx > 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < DDK_ITEMS; ++k) {
+            if (!active(k, j)) continue;
+            const uint32_t i = it_i[k], v = it_v[k];
+            const int32_t y = it_y[k];
+            if (v == vpr) {                                    // column w is never rewritten (w >= 2 + hx, or w == X and nobody reads it)
+                B[(size_t)i * pitch + 8u + w] = (uint16_t)cin[k].x;
+                continue;
+            }
+            const uint32_t x0 = v * 8u;
+            const uint4 c = cin[k];
+            uint32_t val[8] = {c.x & 0xffffu, c.x >> 16, c.y & 0xffffu, c.y >> 16, c.z & 0xffffu, c.z >> 16, c.w & 0xffffu, c.w >> 16};
+            if (frame_touched && y >= 1 && y + 2 <= (int32_t)Y && x0 < 1u + hx) {
+                uint32_t colsum[10];
+#pragma unroll
+                for (int q = 0; q < 10; ++q) colsum[q] = 0;
+#pragma unroll
+                for (int dy = -1; dy <= 1; ++dy) {
+                    const uint16_t* r = A + (size_t)((int32_t)i + dy) * pitch + 8u + x0;    // columns x0 - 1 .. x0 + 8 of the decoded frame z - 1
+                    const uint4 e = *reinterpret_cast<const uint4*>(r);
+                    colsum[0] += r[-1];
+                    colsum[1] += e.x & 0xffffu; colsum[2] += e.x >> 16; colsum[3] += e.y & 0xffffu; colsum[4] += e.y >> 16;
+                    colsum[5] += e.z & 0xffffu; colsum[6] += e.z >> 16; colsum[7] += e.w & 0xffffu; colsum[8] += e.w >> 16;
+                    colsum[9] += r[8];
+                }
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const uint32_t x = x0 + (uint32_t)q;
+                    if (x >= 1u && x < 1u + hx) {
+                        const uint32_t sum = (colsum[q] + colsum[q + 1] + colsum[q + 2]) & 0xffffu;     // the reference's sum wraps in 16 bits
+                        val[q] = (val[q] + ((sum * 58255u) >> 19)) & 0xffffu;                          // + sum / 9
+                    }
+                }
+            }
+            const uint4 o = make_uint4(val[0] | (val[1] << 16), val[2] | (val[3] << 16), val[4] | (val[5] << 16), val[6] | (val[7] << 16));
+            *reinterpret_cast<uint4*>(B + (size_t)i * pitch + 8u + x0) = o;
+            if (y >= y0 && y < y0 + (int32_t)DDK_R) *reinterpret_cast<uint4*>(dst + (uint64_t)y * X + x0) = o;
+        }
+        __syncthreads();
+        cur ^= 1;
+#pragma unroll
+        for (uint32_t k = 0; k < DDK_ITEMS; ++k) cin[k] = nin[k];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // LZ4 block compressor: one wavefront per chunk, hash table (4096 x u32) in LDS.
 //
@@ -821,6 +936,83 @@ struct Lz4Out {
 // (struct Lz4Block: sqy_kernels.h)
 constexpr uint32_t LZ4_HIST = 65536;     // LINKED: a block is parsed at positions [HIST, HIST + n), its history sits below
 
+// Round 4: the duplicate decision of a chunk (lz4_dedupe_verify_kernel's work: look the chunk's key up, compare the bytes with the
+// first chunk of that key, fill the chunk's holes) done by the chunk's own parse wavefront in front of its parse.  The verify kernel
+// was 0.1 ms of HBM traffic on its own and 0.28 ms of every call's chain with other calls' transposes next to it; a wavefront does
+// the same for its one chunk in a few microseconds, and the parse of the other chunks no longer waits for the slowest compare.
+// (struct Lz4DedupeArgs: sqy_kernels.h.)  Returns true when the chunk is a duplicate (dup_of[k] = the chunk it equals): nothing to parse.
+// noinline: the registers of this cold code stay out of the parse loop's allocation.
+__device__ __attribute__((noinline)) bool lz4_chunk_dedupe(const uint8_t* __restrict__ in, uint32_t chunk, uint64_t in_stride, uint64_t total,
+                                                           uint64_t k, const Lz4DedupeArgs& dd, uint32_t lane)
+{
+    uint32_t r = (uint32_t)k;
+    if (k < dd.nchunks_full) {
+        if (lane == 0) {
+            const uint64_t key = dd.chunk_key[k];
+            uint32_t slot = (uint32_t)((key * 0x9E3779B97F4A7C15ull) >> 40) & dd.tab_mask;
+            for (uint32_t tries = 0; tries <= dd.tab_mask; ++tries, slot = (slot + 1u) & dd.tab_mask) {
+                const uint64_t tk = dd.tab_key[slot];
+                if (tk == key) { r = dd.tab_val[slot]; break; }
+                if (tk == 0) break;
+            }
+        }
+        r = sgpr(r);
+    }
+    // the all-zero 1 KiB pieces the transpose left unwritten (see lz4_dedupe_verify_kernel): one 1 KiB store per hole
+    auto fill_holes = [&]() {
+        if (!dd.holes_map) return;
+        const uint64_t left = total - k * chunk;
+        const uint32_t np = (uint32_t)((left < chunk ? left : chunk) >> 10);
+        const uint64_t* hm = dd.holes_map + k * (1u + ((chunk >> 10) + 63u) / 64u);
+        if ((uint32_t)hm[0] == 0u) return;
+        uint8_t* body = const_cast<uint8_t*>(in) + k * in_stride;
+        for (uint32_t w0 = 0; w0 < np; w0 += 64) {
+            uint64_t m = hm[1u + w0 / 64u];
+            while (m) {
+                const uint32_t pc = w0 + ctz64(m);
+                m &= m - 1;
+                const v4u zero = {0, 0, 0, 0};
+                *reinterpret_cast<v4u_any*>(body + (uint64_t)pc * 1024u + lane * 16u) = zero;
+            }
+        }
+    };
+    if (r >= k) { if (lane == 0) dd.dup_of[k] = (uint32_t)k; fill_holes(); return false; }     // first of its kind
+    if (dd.chunk_key[k] == 1ull) { if (lane == 0) dd.dup_of[k] = r; return true; }           // all zero, exactly: the first all-zero chunk's twin
+    fill_holes();
+    // byte compare with chunk r; pieces whose hash is the zero marker count as zeros, written or not (64 lanes x 16 bytes = one piece)
+    const v4u_any* a = reinterpret_cast<const v4u_any*>(in + k * in_stride);
+    const v4u_any* b = reinterpret_cast<const v4u_any*>(in + (uint64_t)r * in_stride);
+    const uint4* hk = reinterpret_cast<const uint4*>(dd.piece_hash) + k * (chunk >> 10);
+    const uint4* hr = reinterpret_cast<const uint4*>(dd.piece_hash) + (uint64_t)r * (chunk >> 10);
+    const uint32_t npieces = chunk >> 10;
+    uint32_t diff = 0;
+    for (uint32_t p0 = 0; p0 < npieces && !diff; p0 += 4) {             // four pieces (4 KiB per side) in flight
+        v4u x[4], y[4];
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) {
+            const uint32_t pc = p0 + u;
+            const v4u zero = {0, 0, 0, 0};
+            bool za = true, zb = true;
+            if (pc < npieces) {
+                za = zb = false;
+                if (dd.holes_map) {
+                    const uint4 qa = hk[pc], qb = hr[pc];
+                    za = (qa.x | qa.y | qa.z | qa.w) == 0u;
+                    zb = (qb.x | qb.y | qb.z | qb.w) == 0u;
+                }
+            }
+            x[u] = za ? zero : (v4u)a[pc * 64u + lane];
+            y[u] = zb ? zero : (v4u)b[pc * 64u + lane];
+        }
+        uint32_t d = 0;
+#pragma unroll
+        for (uint32_t u = 0; u < 4; ++u) d |= (x[u].x ^ y[u].x) | (x[u].y ^ y[u].y) | (x[u].z ^ y[u].z) | (x[u].w ^ y[u].w);
+        diff = ballot(d != 0u) != 0ull ? 1u : 0u;
+    }
+    if (lane == 0) dd.dup_of[k] = diff ? (uint32_t)k : r;
+    return diff == 0u;
+}
+
 // LINKED = false: one independent chunk per wavefront (the chunked layout's single-block frames).
 // LINKED = true: wavefront f walks the blocks [frame_first[f], frame_first[f+1]) of one frame in order; the table lives on
 // across blocks (positions are re-based by the previous block's size, entries that fall more than 64 KiB behind the new
@@ -842,7 +1034,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
-                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel SQY_DIAG_ARG)
+                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel, Lz4DedupeArgs dd SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
@@ -855,6 +1047,14 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
     if (!LINKED && !DENSE && dup_of && dup_of[blockIdx.x] != blockIdx.x) return;     // byte-identical to an earlier chunk (lz4_dedupe_*): its frame is that chunk's
+    if (!LINKED && !DENSE && !ACCEL && dd.chunk_key) {                                 // the same decision, made here (round 4)
+        if (lz4_chunk_dedupe(in, chunk, in_stride, total, blockIdx.x, dd, threadIdx.x)) return;
+        // The holes filled above are read back below by this same wavefront (loads and LDS-DMA): its stores have to have left the
+        // wave (vmcnt) -- nothing more: nobody has read those addresses since the kernel began, so no cache holds an older copy.
+        // (An agent-scope release here writes back the whole XCD's L2 once per chunk, next to other calls' transposes filling it:
+        // measured, the bench lost a quarter.)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : (DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x);
     const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
     uint32_t n_prev = 0;
@@ -3731,7 +3931,8 @@ hipError_t launch_lz4_dedupe_clear(void* work, uint64_t nchunks, uint32_t* zero_
 }
 
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
-                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride, uint64_t* holes_map, bool table_is_clear)
+                             uint32_t* dup_of, hipStream_t stream, uint64_t in_stride, uint64_t* holes_map, bool table_is_clear,
+                             Lz4DedupeArgs* fused)
 {
     const uint64_t nchunks = (total + chunk - 1) / chunk, nfull = total / chunk;
     if (nchunks == 0) return hipSuccess;
@@ -3754,6 +3955,12 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
     if (nkey)
         hipLaunchKernelGGL(lz4_dedupe_key_kernel, dim3((unsigned)nkey), dim3(64), 0, stream, piece_hash, chunk / 1024u, nfull, chunk_key, tab_key,
                            tab_val, tab - 1u, holes_map, (uint32_t)((total - nfull * chunk) >> 10));
+    if (fused) {
+        // the decision per chunk is left to the chunk's parse wavefront (lz4_chunk_dedupe): only the key table is built here
+        fused->chunk_key = chunk_key; fused->tab_key = tab_key; fused->tab_val = tab_val; fused->tab_mask = tab - 1u; fused->dup_of = dup_of;
+        fused->piece_hash = piece_hash; fused->holes_map = holes_map; fused->nchunks_full = nfull;
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(lz4_dedupe_verify_kernel, dim3((unsigned)nchunks), dim3(DEDUPE_THREADS), 0, stream, in, chunk, in_stride, nfull, nchunks, chunk_key,
                        tab_key, tab_val, tab - 1u, dup_of, piece_hash, holes_map, total);
     return hipGetLastError();
@@ -3847,7 +4054,8 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
-                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride, uint32_t acceleration, bool redo_is_zero)
+                             uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride, uint32_t acceleration, bool redo_is_zero,
+                             const Lz4DedupeArgs* dedupe)
 {
     if (nchunks == 0) return hipSuccess;
     if (in_stride == 0) in_stride = chunk;
@@ -3858,10 +4066,10 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
     }
     if (acceleration > 1)    // (no dense second pass: the list stays empty)
         hipLaunchKernelGGL((lz4_chunks_kernel<false, false, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, dup_of, acceleration SQY_DIAG_NULL);
+                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, dup_of, acceleration, Lz4DedupeArgs{} SQY_DIAG_NULL);
     else
         hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of, 1u SQY_DIAG_NULL);
+                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of, 1u, dedupe ? *dedupe : Lz4DedupeArgs{} SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -3872,7 +4080,7 @@ hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t c
     if (redo_count == 0) return hipSuccess;
     if (in_stride == 0) in_stride = chunk;
     hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr, 1u SQY_DIAG_NULL);
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr, 1u, Lz4DedupeArgs{} SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -3883,10 +4091,10 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
     if (acceleration > 1)
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, Lz4DedupeArgs{} SQY_DIAG_NULL);
     else
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, Lz4DedupeArgs{} SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -4266,6 +4474,16 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
         // frames that cannot change (z = 0, z >= zlim) in one launch each run, the others one by one
         hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X,
                            (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)w, rpb, 0u, 0u);
+        // frames 1 .. zlim-1: K frames per launch, strips of R rows that recompute the halo rows they need of their neighbours
+        // (diff3x3x1_u16_decode_frames_kernel); narrow stripes of columns only -- the two LDS images must fit
+        const size_t ddk_lds = 2 * (size_t)DDK_ROWS * (w + 16) * sizeof(uint16_t);
+        if (ddk_lds <= (64u << 10) && (uint64_t)DDK_ROWS * (w / 8 + 1) <= (uint64_t)DDK_ITEMS * DDK_THREADS) {
+            for (uint64_t z = 1; z < zlim; z += DDK_K) {
+                const uint32_t nf = (uint32_t)(zlim - z < DDK_K ? zlim - z : DDK_K);
+                hipLaunchKernelGGL(diff3x3x1_u16_decode_frames_kernel, dim3((unsigned)((Y + DDK_R - 1) / DDK_R)), dim3(DDK_THREADS), ddk_lds, stream, (const uint16_t*)in,
+                                   (uint16_t*)out, (uint32_t)Y, (uint32_t)X, (uint32_t)hx, (uint32_t)zlim, (uint32_t)w, (uint32_t)z, nf);
+            }
+        } else
         for (uint64_t z = 1; z < zlim; ++z)
             hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X,
                                (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)w, rpb, (uint32_t)z, 0u);
