@@ -49,6 +49,15 @@ def short(name):
         base = base[5:]
     if base.startswith("sqy::"):
         base = base[5:]
+    # round 4: the parse kernel has a third template parameter (liblz4 acceleration above 1)
+    if base.startswith("lz4_chunks_kernel<"):
+        args = [a.strip() for a in base[len("lz4_chunks_kernel<"):-1].split(",")]
+        if args[0] == "true":
+            return "lz4_linked"
+        return "lz4_chunks_dense" if args[1] == "true" else ("lz4_chunks_accel" if len(args) > 2 and args[2] == "true" else "lz4_chunks")
+    for k, v in (("lz4_dedupe_clear_kernel", "lz4_dedupe_clear"), ("lz4_inplace_finish_kernel", "lz4_inplace_finish")):
+        if base.startswith(k):
+            return v
     return SHORT.get(base, base)
 
 
