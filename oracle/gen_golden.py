@@ -231,6 +231,41 @@ def headline():
     print("wrote", os.path.join(GOLD, "headline.json"))
 
 
+def headline_serial():
+    """adds to tests/golden/headline.json the digests of the same stacks in the layout every default caller of the reference gets
+    (nthreads = 1: ONE block-linked frame, lz4_utils.hpp:99-173): reference SSE bit-plane gather + liblz4 1.9.3 LZ4F_compressUpdate
+    sequence; asserts the oracle's serial payload equals it on the way"""
+    assert ref.available() and ref.lz4_version() == 10903
+    path = os.path.join(GOLD, "headline.json")
+    with open(path) as f:
+        H = json.load(f)
+    H["_meta"]["lz4_serial"] = "liblz4 1.9.3 via encode_serial (lz4_utils.hpp:99-173): one block-linked frame, one LZ4F_compressUpdate per framestep"
+    for st in H["stacks"]:
+        shape, z0, ztot = tuple(st["shape_zyx"]), st["z_offset"], st["z_total"]
+        if ztot == shape[0]:
+            vol = synth.stack(shape, np.uint16)
+        else:
+            Z, Y, X = shape
+            per = Y * X
+            noise = synth._noise(z0 * per, Z * per, synth.SEED).reshape(Z, Y, X)
+            sh = synth._shell(z0, Z, ztot, Y, X)
+            vol = (100 + (noise >> 2) + sh * 6000).astype(np.uint16)
+        assert sha(vol.tobytes()) == st["voxels_sha256"]
+        planes = ref.bitswap1_encode_u16(vol, 16).view(np.uint8)
+        cfg = o.Lz4Config("")
+        payload = ref.lz4_encode_serial(planes, framestep=cfg.bytes_per_chunk(planes.size))
+        mine = o.pipeline_encode("bitswap1->lz4", vol, nthreads=1)
+        h = o.header_unpack(mine)
+        assert mine[h["size"]:] == payload.tobytes(), ("oracle serial payload differs from the reference pieces", st["name"])
+        st["serial"] = {"payload_bytes": int(payload.size), "payload_sha256": sha(payload.tobytes()), "blob_bytes": len(mine), "blob_sha256": sha(mine),
+                        "header_bytes": h["size"]}
+        print(st["name"], "serial", payload.size, st["serial"]["payload_sha256"][:16], flush=True)
+        del vol, planes, payload, mine
+    with open(path, "w") as f:
+        json.dump(H, f, indent=1, sort_keys=True)
+    print("wrote", path)
+
+
 def accel():
     """tests/golden/accel.json: liblz4 1.9.3 with an acceleration above 1 -- sqeazy's lz4(accel=-k), a negative LZ4F compression level
     (encoders/lz4.hpp:103-113) -- block level, the chunked layout and the serial block-linked layout; asserts oracle == liblz4 on the way"""
@@ -262,9 +297,13 @@ def accel():
 if __name__ == "__main__":
     if "--accel" in sys.argv:
         accel()
+    elif "--headline-serial" in sys.argv:
+        headline_serial()
     elif "--headline" in sys.argv:
         headline()
+        headline_serial()
     else:
         main()
         accel()
         headline()
+        headline_serial()

@@ -137,12 +137,13 @@ struct DevBuf {
 
 struct Workspace {
     DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan, dedupe;
+    DevBuf spec;              // block-linked frames parsed block-parallel: per block the table it started from and the one it left, the walk lists
     DevBuf diff_side;         // diff3x3x1 in front of a 16-bit bitswap1: the columns the stage can touch (outside the ping/pong rotation)
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
     void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
-        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release();
+        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release(); spec.release();
     }
 };
 
@@ -849,7 +850,78 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     if (ws->lz4_scratch.ensure(std::max<uint64_t>(nblocks * lz4_stride, 16))) return 1;
                     if (ws->csize.ensure(nblocks * sizeof(uint32_t))) return 1;
                     if (ws->frame_off.ensure((nblocks + 1) * sizeof(uint64_t))) return 1;
-                    {
+                    // Few long frames (the serial layout above all): block-parallel.  Every block is parsed by its own wavefront from
+                    // a table rebuilt by parsing the >= 64 KiB in front of it, the tables are checked against what the block in
+                    // front really left, and what fails the check is parsed again in order (sqy_kernels.h: Lz4SpecArgs).  Twice the
+                    // parse work on thousands of wavefronts instead of one: worth it when the frame walks would leave the chip empty.
+                    uint64_t longest = 0;
+                    for (uint64_t f = 0; f < nframes; ++f) longest = std::max<uint64_t>(longest, plan.frame_first[f + 1] - plan.frame_first[f]);
+                    // measurement / test knobs: SQY_NO_BLOCK_PARALLEL (the frame walk of rounds 2-3), SQY_BLOCK_PARALLEL_WARMUP = bytes
+                    // of warm-up in front of a block (default and liblz4's reach: 64 KiB; less makes the guess fail more often --
+                    // the result stays exact, the blocks that fail are parsed again)
+                    const bool spec_off = std::getenv("SQY_NO_BLOCK_PARALLEL") != nullptr;
+                    uint64_t warmup = 65536;
+                    if (const char* wv = std::getenv("SQY_BLOCK_PARALLEL_WARMUP")) warmup = std::strtoull(wv, nullptr, 10);
+                    if (!spec_off && longest >= 3 && nframes < 1024) {
+                        std::vector<uint32_t> wfirst(nblocks), wlast(nblocks), ok(nblocks);
+                        for (uint64_t f = 0; f < nframes; ++f)
+                            for (uint32_t k = plan.frame_first[f]; k < plan.frame_first[f + 1]; ++k) {
+                                uint32_t j = k;
+                                uint64_t have = 0;
+                                while (j > plan.frame_first[f] && have < warmup) { --j; have += plan.blocks[j].n; }
+                                wfirst[k] = j; wlast[k] = (uint32_t)k;
+                            }
+                        const uint64_t list_bytes = nblocks * sizeof(uint32_t);
+                        if (ws->spec.ensure(nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t) + 3 * list_bytes)) return 1;
+                        sqy::Lz4SpecArgs sa;
+                        sa.tables = static_cast<uint32_t*>(ws->spec.p);
+                        uint32_t* d_wfirst = sa.tables + nblocks * sqy::kLz4SpecTableWords;
+                        uint32_t* d_wlast = d_wfirst + nblocks;
+                        uint32_t* d_ok = d_wlast + nblocks;
+                        sa.wave_first = d_wfirst; sa.wave_last = d_wlast; sa.mode = 1;
+                        SQY_HIP(hipMemcpyAsync(d_wfirst, wfirst.data(), list_bytes, hipMemcpyHostToDevice, stream));
+                        SQY_HIP(hipMemcpyAsync(d_wlast, wlast.data(), list_bytes, hipMemcpyHostToDevice, stream));
+                        {
+                            ProfScope ps("lz4_linked_blocks", stream, pend);
+                            SQY_HIP(sqy::launch_lz4_linked_spec(cur, d_blocks, sa, nblocks, plan.max_block, static_cast<uint8_t*>(ws->lz4_scratch.p),
+                                                                lz4_stride, static_cast<uint32_t*>(ws->csize.p), stream, lz4_accel));
+                        }
+                        for (uint64_t round = 0;; ++round) {
+                            {
+                                ProfScope ps("lz4_linked_verify", stream, pend);
+                                SQY_HIP(sqy::launch_lz4_linked_verify(d_blocks, nblocks, sa.tables, plan.max_block, d_ok, stream));
+                            }
+                            SQY_HIP(hipMemcpyAsync(ok.data(), d_ok, list_bytes, hipMemcpyDeviceToHost, stream));
+                            SQY_HIP(hipStreamSynchronize(stream));
+                            // runs of blocks that did not start from the true table: one wavefront each, in order, from the table in front
+                            uint64_t nruns = 0;
+                            for (uint64_t k = 0; k < nblocks; ++k) {
+                                if (ok[k]) continue;
+                                uint64_t e = k;
+                                while (e + 1 < nblocks && !ok[e + 1] && !(plan.blocks[e + 1].flags & 1u)) ++e;
+                                wfirst[nruns] = (uint32_t)k; wlast[nruns] = (uint32_t)e; ++nruns;
+                                k = e;
+                            }
+                            if (std::getenv("SQY_BLOCK_PARALLEL_STATS")) {
+                                uint64_t nbad = 0;
+                                for (uint64_t r = 0; r < nruns; ++r) nbad += wlast[r] - wfirst[r] + 1;
+                                std::fprintf(stderr, "[sqeazy]\t lz4 block-parallel: round %llu, %llu of %llu blocks to parse again in %llu runs\n",
+                                             (unsigned long long)round, (unsigned long long)nbad, (unsigned long long)nblocks, (unsigned long long)nruns);
+                            }
+                            if (nruns == 0) break;
+                            if (round > nblocks) {
+                                std::fprintf(stderr, "[sqeazy]\t lz4: the block-parallel parse did not settle\n");
+                                return 1;
+                            }
+                            SQY_HIP(hipMemcpyAsync(d_wfirst, wfirst.data(), nruns * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                            SQY_HIP(hipMemcpyAsync(d_wlast, wlast.data(), nruns * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+                            sa.mode = 2;
+                            ProfScope ps("lz4_linked_redo", stream, pend);
+                            SQY_HIP(sqy::launch_lz4_linked_spec(cur, d_blocks, sa, nruns, plan.max_block, static_cast<uint8_t*>(ws->lz4_scratch.p),
+                                                                lz4_stride, static_cast<uint32_t*>(ws->csize.p), stream, lz4_accel));
+                            SQY_HIP(hipStreamSynchronize(stream));         // (wfirst / wlast are reused by the next round)
+                        }
+                    } else {
                         ProfScope ps("lz4_linked", stream, pend);
                         SQY_HIP(sqy::launch_lz4_linked(cur, d_blocks, d_first, nframes, plan.max_block, static_cast<uint8_t*>(ws->lz4_scratch.p),
                                                        lz4_stride, static_cast<uint32_t*>(ws->csize.p), stream, lz4_accel));

@@ -83,6 +83,29 @@ struct Lz4Block {
 // block to block; block k -> scratch + k*stride, csize[k] (0 = store raw).  max_block = largest blocks[k].n (<= 4 MiB)
 hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const uint32_t* frame_first, uint64_t nframes,
                              uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream, uint32_t acceleration = 1);
+// Block-linked frames, block-parallel (round 4).  liblz4's table only matters as far as it holds positions of the last 64 KiB, so a
+// wavefront can rebuild the table a block starts from by parsing the blocks in front of it (>= 64 KiB of them, output thrown away)
+// from an empty table -- a guess that is almost always right and is CHECKED: every parse leaves the table it started from and the
+// table it ended with in `tables`, launch_lz4_linked_verify compares block k's start with what block k - 1 really left (after the
+// same re-basing; entries more than 64 KiB behind are parked at one value by it, so equality is equivalence), and the blocks that
+// fail are parsed again from the true table (mode 2, runs of blocks in order).  When every block verifies, induction from the frame's
+// first block (a fresh table, no guess) makes every block's output liblz4's.
+//   mode 1: wavefront w walks blocks [wave_first[w], wave_last[w]]; the first starts from an empty table; only the last one's output,
+//           size and tables count (the others are the warm-up)
+//   mode 2: wavefront w walks blocks [wave_first[w], wave_last[w]], all of them for real; the first starts from the table block
+//           wave_first[w] - 1 left (tables) unless it opens a frame
+// tables: nblocks x 2 x 4096 words ([k][0] = the table block k was parsed from, [k][1] = the table it left)
+struct Lz4SpecArgs {
+    const uint32_t* wave_first = nullptr;
+    const uint32_t* wave_last = nullptr;
+    uint32_t* tables = nullptr;
+    uint32_t mode = 0;
+};
+constexpr uint64_t kLz4SpecTableWords = 2 * 4096;
+hipError_t launch_lz4_linked_spec(const uint8_t* in, const Lz4Block* blocks, const Lz4SpecArgs& spec, uint64_t nwaves,
+                                  uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream, uint32_t acceleration = 1);
+// ok[k] = 1 when block k opens a frame or started from the table block k - 1 left, else 0
+hipError_t launch_lz4_linked_verify(const Lz4Block* blocks, uint64_t nblocks, const uint32_t* tables, uint32_t max_block, uint32_t* ok, hipStream_t stream);
 // frame_off[k] = byte offset of frame k in the concatenated stream, frame_off[nchunks] = total payload bytes
 // (blocks != nullptr: offset of what block k contributes -- frame header if it opens a frame, size field, body, end mark
 // if it closes one)

@@ -1028,13 +1028,22 @@ __device__ __attribute__((noinline)) bool lz4_chunk_dedupe(const uint8_t* __rest
 // A separate instantiation that only takes the generic path with the general probe positions (the lean loop, the dense
 // batches and the no-hit batches are built on the stride-1 start and stay out): exact, not fast -- a rarely used setting --
 // and the acceleration-1 kernels keep their code.
+// (the last argument: the duplicate search's tables for the chunked layout, the block-parallel walk's for block-linked frames)
+template <bool LINKED> struct Lz4ExtraArgs { typedef Lz4DedupeArgs type; };
+template <> struct Lz4ExtraArgs<true> { typedef Lz4SpecArgs type; };
+__device__ __forceinline__ uint32_t lz4_linked_tag_shift(uint32_t max_block)
+{
+    const uint32_t pmax = LZ4_HIST + max_block;
+    return 31u - (32u - (uint32_t)__builtin_clz(pmax - 1));
+}
+
 template <bool LINKED, bool DENSE, bool ACCEL = false>
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk, uint64_t in_stride,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
-                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel, Lz4DedupeArgs dd SQY_DIAG_ARG)
+                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel, typename Lz4ExtraArgs<LINKED>::type dd SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
@@ -1047,7 +1056,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
     if (!LINKED && !DENSE && dup_of && dup_of[blockIdx.x] != blockIdx.x) return;     // byte-identical to an earlier chunk (lz4_dedupe_*): its frame is that chunk's
-    if (!LINKED && !DENSE && !ACCEL && dd.chunk_key) {                                 // the same decision, made here (round 4)
+    if constexpr (!LINKED && !DENSE && !ACCEL) if (dd.chunk_key) {                     // the same decision, made here (round 4)
         if (lz4_chunk_dedupe(in, chunk, in_stride, total, blockIdx.x, dd, threadIdx.x)) return;
         // The holes filled above are read back below by this same wavefront (loads and LDS-DMA): its stores have to have left the
         // wave (vmcnt) -- nothing more: nobody has read those addresses since the kernel began, so no cache holds an older copy.
@@ -1055,11 +1064,28 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         // measured, the bench lost a quarter.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    const uint32_t b_first = LINKED ? frame_first[blockIdx.x] : (DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x);
-    const uint32_t b_last = LINKED ? frame_first[blockIdx.x + 1] : b_first + 1;
+    uint32_t b_first, b_last;
+    uint32_t b_out = 0;                                        // LINKED: the first block of the walk whose output counts
+    uint32_t spec_mode = 0;
+    if constexpr (LINKED) {
+        spec_mode = dd.mode;
+        if (spec_mode) {
+            b_first = dd.wave_first[blockIdx.x];
+            b_last = dd.wave_last[blockIdx.x] + 1u;
+            b_out = spec_mode == 1u ? b_last - 1u : b_first;
+        } else {
+            b_first = frame_first[blockIdx.x];
+            b_last = frame_first[blockIdx.x + 1];
+            b_out = b_first;
+        }
+    } else {
+        b_first = DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x;
+        b_last = b_first + 1;
+    }
     uint32_t n_prev = 0;
   for (uint32_t bi = b_first; bi < b_last; ++bi) {
-    const uint64_t blk = bi;
+    // (a warm-up block's output lands where the counted block's will, and is overwritten by it)
+    const uint64_t blk = LINKED && bi < b_out ? b_last - 1u : bi;
     // position of the block's first byte (p0) and of the stream's first byte (p_lo) in the block's own coordinates
     const uint32_t p0 = LINKED ? LZ4_HIST : 0u;
     uint32_t n, p_lo = 0;
@@ -1074,6 +1100,15 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         low_in = bd.low_in - (int64_t)bd.start + LZ4_HIST;
         low_dict = bd.low_dict - (int64_t)bd.start + LZ4_HIST;
         fresh = (bd.flags & 1u) != 0;
+        if constexpr (LINKED) {
+            if (spec_mode == 1u && bi == b_first) fresh = true;                  // the guess: nothing older than this walk matters
+            if (spec_mode == 2u && bi == b_first && !fresh) {                   // the table the block in front really left
+                const uint32_t* __restrict__ tf = dd.tables + (uint64_t)(bi - 1u) * kLz4SpecTableWords + 4096u;
+#pragma unroll 4
+                for (int i = 0; i < 64; ++i) table[i * 64 + lane] = tf[i * 64 + lane];
+                n_prev = blocks[bi - 1u].n;
+            }
+        }
     } else {
         // frame_shuffle in front of the sink: the stream is the frames of `in` in the order fmap gives (a chunk never straddles
         // two frames, the host checks fbytes % chunk == 0), read in place instead of gathered into a copy first
@@ -1113,6 +1148,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         uint4* t4 = reinterpret_cast<uint4*>(table);
 #pragma unroll
         for (int i = 0; i < 16; ++i) t4[i * 64 + lane] = make_uint4(e0, e0, e0, e0);
+        if constexpr (LINKED) if (spec_mode && bi >= b_out && !(blocks[bi].flags & 1u)) {
+            // a guess without any warm-up (the host's knob): the table on record is the empty one, which no block leaves behind
+            uint4* g4 = reinterpret_cast<uint4*>(dd.tables + (uint64_t)bi * kLz4SpecTableWords);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g4[i * 64 + lane] = make_uint4(e0, e0, e0, e0);
+        }
     } else {
         // the stream moved on by n_prev bytes: positions shift down, whatever falls below 0 is more than 64 KiB behind
         // every position of this block ("too far" for good) and parks at position 0
@@ -1120,7 +1161,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         for (int i = 0; i < 64; ++i) {
             const uint32_t e = table[i * 64 + lane];
             const uint32_t pp = e >> tsh;
-            table[i * 64 + lane] = pp >= n_prev ? (((pp - n_prev) << tsh) | (e & tmask)) : 0u;
+            const uint32_t e2 = pp >= n_prev ? (((pp - n_prev) << tsh) | (e & tmask)) : 0u;
+            table[i * 64 + lane] = e2;
+            if constexpr (LINKED) if (spec_mode && bi >= b_out) dd.tables[(uint64_t)bi * kLz4SpecTableWords + i * 64 + lane] = e2;
         }
     }
     __syncthreads();
@@ -2009,9 +2052,14 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
     if (lane == 0) {
         if (!DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
-        else csize[blk] = failed ? 0u : op;
+        else if (!LINKED || bi >= b_out) csize[blk] = failed ? 0u : op;
     }
     if (LINKED) __syncthreads();
+    if constexpr (LINKED) if (spec_mode && bi >= b_out) {
+        uint32_t* __restrict__ tf = dd.tables + (uint64_t)bi * kLz4SpecTableWords + 4096u;
+#pragma unroll 4
+        for (int i = 0; i < 64; ++i) tf[i * 64 + lane] = table[i * 64 + lane];
+    }
   }
 #ifdef SQY_LZ4_DIAG
     if (lane == 0) { diag[blockIdx.x * 32] = dacc; diag[blockIdx.x * 32 + 1] = dcnt; for (int i = 0; i < 16; ++i) diag[blockIdx.x * 32 + 8 + i] = dreason[i]; }
@@ -4091,10 +4139,60 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
     if (acceleration > 1)
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, Lz4DedupeArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, Lz4SpecArgs{} SQY_DIAG_NULL);
     else
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, Lz4DedupeArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, Lz4SpecArgs{} SQY_DIAG_NULL);
+    return hipGetLastError();
+}
+
+hipError_t launch_lz4_linked_spec(const uint8_t* in, const Lz4Block* blocks, const Lz4SpecArgs& spec, uint64_t nwaves,
+                                  uint32_t max_block, uint8_t* scratch, uint64_t stride, uint32_t* csize, hipStream_t stream, uint32_t acceleration)
+{
+    if (nwaves == 0) return hipSuccess;
+    if (max_block == 0 || max_block > (4u << 20) || !spec.wave_first || !spec.wave_last || !spec.tables || (spec.mode != 1 && spec.mode != 2))
+        return hipErrorInvalidValue;
+    if (acceleration > 1)
+        hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, spec SQY_DIAG_NULL);
+    else
+        hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, spec SQY_DIAG_NULL);
+    return hipGetLastError();
+}
+
+// ok[k]: block k opens a frame, or the table it was parsed from (tables[k][0]) is what block k - 1 left (tables[k - 1][1]) re-based
+// by that block's size exactly as the walk re-bases it
+__global__ __launch_bounds__(256)
+void lz4_linked_verify_kernel(const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ tables, uint32_t max_block, uint32_t* __restrict__ ok)
+{
+    const uint64_t k = blockIdx.x;
+    __shared__ uint32_t differ;
+    if (threadIdx.x == 0) differ = 0;
+    __syncthreads();
+    if (!(blocks[k].flags & 1u)) {
+        const uint32_t tsh = lz4_linked_tag_shift(max_block), tmask = (1u << tsh) - 1u;
+        const uint32_t n_prev = blocks[k - 1].n;
+        const uint32_t* __restrict__ left = tables + (k - 1) * kLz4SpecTableWords + 4096u;
+        const uint32_t* __restrict__ used = tables + k * kLz4SpecTableWords;
+        uint32_t d = 0;
+        for (uint32_t i = threadIdx.x; i < 4096u; i += 256u) {
+            const uint32_t e = left[i];
+            const uint32_t pp = e >> tsh;
+            const uint32_t e2 = pp >= n_prev ? (((pp - n_prev) << tsh) | (e & tmask)) : 0u;
+            d |= e2 ^ used[i];
+        }
+        if (d) differ = 1;                                      // (benign race: every writer writes 1)
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) ok[k] = differ ? 0u : 1u;
+}
+
+hipError_t launch_lz4_linked_verify(const Lz4Block* blocks, uint64_t nblocks, const uint32_t* tables, uint32_t max_block, uint32_t* ok, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(lz4_linked_verify_kernel, dim3((unsigned)nblocks), dim3(256), 0, stream, blocks, tables, max_block, ok);
     return hipGetLastError();
 }
 

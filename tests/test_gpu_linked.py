@@ -104,3 +104,76 @@ def test_serial_layout_u16_planes_8mib(sqy, oracle):
     rc, blob = sqy.encode("bitswap1->lz4", vol, nthreads=1)
     assert rc == 0
     assert blob == oracle.pipeline_encode("bitswap1->lz4", vol, nthreads=1)
+
+
+# ---- block-linked frames parsed block-parallel (round 4) -------------------------------------------------------------------
+# Frames of three blocks and more are not walked by one wavefront any more: every block is parsed from a table rebuilt by a warm-up
+# over the >= 64 KiB in front of it, the tables are verified against what the block in front really left and the blocks that fail
+# are parsed again in order (sqy_kernels.h: Lz4SpecArgs).  The result has to be liblz4's whatever the guesses were worth: the knob
+# SQY_BLOCK_PARALLEL_WARMUP makes them worthless (0: every block starts from an empty table and is parsed again) or leaves them at
+# the default; `histmatch` data breaks the default guess for chosen blocks (a block of noise that begins with a match into the block
+# in front of it: liblz4's skip counter restarts there, the warm-up, which cannot see that far back, probes other positions from then on).
+def _histmatch(n, every, seed=11):
+    rng = np.random.default_rng(seed)
+    d = rng.integers(0, 256, n, dtype=np.uint8)
+    B = 256 << 10
+    for k, i in enumerate(range(B, n - 400, B)):
+        if k % every == 0:
+            d[i:i + 300] = d[i - 1000:i - 700]
+    return d
+
+
+def _profile_names(sqy):
+    return set(sqy.profile_get().keys())
+
+
+@pytest.mark.parametrize("warmup", [None, "0", "1", "200000", "1000000"])
+@pytest.mark.parametrize("name", ["zeros", "random", "noise3", "sparse", "periodic", "farrep", "runs", "rawmix", "hist1", "hist3", "planes"])
+def test_block_parallel_serial_layout(sqy, oracle, monkeypatch, name, warmup):
+    n = 24 * (256 << 10) + 54321
+    if name == "hist1":
+        data = _histmatch(n, 1)
+    elif name == "hist3":
+        data = _histmatch(n, 3)
+    elif name == "planes":
+        data = np.ascontiguousarray(oracle.bitswap1_encode_planes(synth.stack((12, 512, 512)).reshape(-1))).view(np.uint8).reshape(-1)
+    else:
+        data = dict(_streams(n, seed=21))[name]
+    vol = data.reshape(1, 1, -1)
+    want = oracle.pipeline_encode("lz4", vol, nthreads=1)
+    if warmup is not None:
+        monkeypatch.setenv("SQY_BLOCK_PARALLEL_WARMUP", warmup)
+    sqy.profile_reset(); sqy.profile_enable(True)
+    rc, blob = sqy.encode("lz4", vol, nthreads=1)
+    sqy.profile_enable(False)
+    assert rc == 0
+    assert blob == want, (name, warmup, len(blob), len(want))
+    names = _profile_names(sqy)
+    assert "lz4_linked_blocks" in names and "lz4_linked_verify" in names, names         # the block-parallel path ran
+    if warmup == "0" or (name in ("hist1", "hist3") and warmup in (None, "1")):
+        assert "lz4_linked_redo" in names, "the guess was expected to fail somewhere"  # .. and so did the second parse
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back.reshape(-1), data)
+    # the frame walk of rounds 2-3 gives the same bytes
+    monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")
+    rc, blob2 = sqy.encode("lz4", vol, nthreads=1)
+    assert rc == 0 and blob2 == want
+
+
+@pytest.mark.parametrize("cfg", ["blocksize_kb=64", "blocksize_kb=64,framestep_kb=448", "framestep_kb=1024", "blocksize_kb=1024,framestep_kb=3072",
+                                 "n_chunks_of_input=3", "n_chunks_of_input=1", "accel=-3"])
+@pytest.mark.parametrize("nthreads", [1, 2])
+def test_block_parallel_other_block_layouts(sqy, oracle, cfg, nthreads):
+    """block sizes of 64 KiB (the warm-up is exactly liblz4's reach), update sizes that are no multiple of the block size (short blocks in
+    the middle of a frame: the warm-up spans several), frames of many blocks in the chunked layout, liblz4's acceleration"""
+    n = 9 * (1 << 20) + 7777
+    for name in ("sparse", "periodic", "farrep", "noise3", "rawmix", "hist"):
+        data = _histmatch(n, 2, seed=5) if name == "hist" else dict(_streams(n, seed=9))[name]
+        vol = data.reshape(1, 1, -1)
+        pipe = "lz4(%s)" % cfg
+        rc, blob = sqy.encode(pipe, vol, nthreads=nthreads)
+        assert rc == 0, (cfg, name)
+        want = oracle.pipeline_encode(pipe, vol, nthreads=nthreads)
+        assert blob == want, (cfg, name, nthreads, len(blob), len(want))
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back.reshape(-1), data), (cfg, name)
