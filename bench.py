@@ -573,6 +573,37 @@ def main():
     sqeazy_amd.profile_enable(False)
     prof_alone = sqeazy_amd.profile_get()
     fence()
+    # the layout every default caller of the reference asks for (nthreads = 1: one block-linked frame), one call at a time; its blob is
+    # hashed against the digest the reference pieces give for that layout (tests/golden/headline.json "serial")
+    serial_layout = None
+    if rank == 0:
+        try:
+            sqeazy_amd.profile_reset()
+            sqeazy_amd.profile_enable(True)
+            sl = []
+            for _ in range(4):
+                tl = time.perf_counter()
+                rc, sn = sqeazy_amd.encode_device(PIPELINE, vol.data_ptr(), shape, np.uint16, outs[0][0].data_ptr(), cap, nthreads=1,
+                                                  stream=streams[0].cuda_stream)
+                torch.cuda.synchronize()
+                sl.append((time.perf_counter() - tl) * 1e3)
+                if rc != 0:
+                    raise RuntimeError("nthreads = 1 call failed")
+            sqeazy_amd.profile_enable(False)
+            sdig = hashlib.sha256(outs[0][0][:sn].cpu().numpy().tobytes()).hexdigest()
+            serial_layout = {"ms": round(min(sl[1:]), 4), "value": round(nbytes / (min(sl[1:]) / 1e3) / 1e9, 1), "unit": "GB/s", "blob_bytes": int(sn),
+                             "blob_sha256": sdig, "verified": None,
+                             "what": "SQYAMD_PipelineEncode_UI16_Device, nthreads = 1 (ONE block-linked LZ4 frame, lz4_utils.hpp:99-173), one call at a time; "
+                                     "blocks parsed block-parallel from verified table guesses (DESIGN.md section 3)",
+                             "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in sqeazy_amd.profile_get().items()}}
+            with open(os.path.join(ROOT, "tests", "golden", "headline.json")) as f:
+                for g in json.load(f)["stacks"]:
+                    if tuple(g["shape_zyx"]) == tuple(shape) and g["z_offset"] == 0 and g["z_total"] == world * shape[0] and "serial" in g:
+                        serial_layout["verified"] = sdig == g["serial"]["blob_sha256"]
+                        serial_layout["against"] = "tests/golden/headline.json (%s, serial): reference SSE bitswap + liblz4 1.9.3 encode_serial" % g["name"]
+        except Exception as e:   # reported, never required
+            serial_layout = {"error": repr(e)}
+    fence()
     for q in job_q:                      # the caller threads are done
         q.put(None)
     for th in callers:
@@ -621,6 +652,7 @@ def main():
                             "roofline_frac": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5),
                             "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in prof_alone.items()}},
             "verified": verify["verified"], "payload_sha256": verify.get("payload_sha256"), "verification": verify,
+            "serial_layout": serial_layout,
             "other_operating_points": alt,
             "entry_point": "SQYAMD_PipelineEncode_UI16_DeviceAt (device pointers; the blob may start anywhere in the destination: frames in place)",
             "build": ident,

@@ -51,8 +51,8 @@ SQY_FUNCTION_PREFIX int SQY_Version_Triple(int* version);
  *   dstlength   out only: bytes written (header + payload)
  *   nthreads    <=0 or > hardware threads: all hardware threads (src/sqeazy_algorithms.hpp:14-22).  The value selects
  *               the LZ4 LAYOUT exactly as in the reference (encoders/lz4.hpp:227-239): effective 1 -> ONE frame of
- *               block-linked 256 KiB blocks (lz4_utils.hpp:99-173; produced on the GPU by one wavefront per frame:
- *               bit-identical, but serial -- about 1.3 GB/s); >=2 -> one independent frame per 256 KiB chunk
+ *               block-linked 256 KiB blocks (lz4_utils.hpp:99-173; bit-identical; its blocks are parsed in parallel from
+ *               verified hash-table guesses, about half the rate of the chunked layout); >=2 -> one independent frame per 256 KiB chunk
  *               (lz4_utils.hpp:193-274; byte-identical for every count >= 2; the fast path). */
 SQY_FUNCTION_PREFIX int SQY_PipelineEncode_UI8(const char* pipeline, const char* src, long* shape, unsigned shape_size,
                                                char* dst, long* dstlength, int nthreads);

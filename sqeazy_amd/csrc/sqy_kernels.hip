@@ -78,7 +78,26 @@ __device__ __forceinline__ uint4 lds_ld_4dw(const lds_u8* p)
     const al4_u64 a = { q[0].x, q[0].y }, b = { q[1].x, q[1].y };
     return make_uint4(a.x, a.y, b.x, b.y);
 }
+// two dwords at a multiple of 4 (one ds_read2_b32)
+__device__ __forceinline__ uint2 lds_ld_2dw(const lds_u8* p)
+{
+    const volatile SQY_LDS al4_u64* q = reinterpret_cast<const volatile SQY_LDS al4_u64*>(p);
+    return make_uint2(q->x, q->y);
+}
+// the four bytes at any LDS address out of two aligned dwords (75 cycles + one v_alignbyte against 137 for a replayed ds_read_b32)
+__device__ __forceinline__ uint32_t lds_ld_u32_via_aligned(const lds_u8* base, uint32_t at)
+{
+    const uint2 d = lds_ld_2dw(base + (at & ~3u));
+    return __builtin_amdgcn_alignbyte(d.y, d.x, at & 3u);
+}
 __device__ __forceinline__ uint32_t glb_ld_u8(glb_u8* p) { return *p; }
+// 16 bytes past this CU's L1 (agent scope: the line may sit there from before this wave's own later stores to it), waited for
+__device__ __forceinline__ uint4 ld_u128_agent(const uint8_t* p)
+{
+    v4u v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ uint32_t glb_ld_u32(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u32*>(p)->v; }
 __device__ __forceinline__ uint64_t glb_ld_u64(glb_u8* p) { return reinterpret_cast<SQY_GLB const pk_u64*>(p)->v; }
 __device__ __forceinline__ uint4 glb_ld_u128(glb_u8* p)
@@ -3305,6 +3324,19 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };   // cnt <= DEC_IN - 16, at + cnt <= sz
         auto sbyte_at = [&](uint32_t at) -> uint32_t { return stage[at - sbase]; };
 
+        // cnt <= 1024 bytes from LDS (ring or stage: `from`, contiguous) onto the ring at dp (dp + cnt <= DEC_RING), 16 bytes per lane and
+        // the last cnt % 16 one per lane; every read is issued before the first write.  (A lane's 16-byte read may run up to 15 bytes
+        // past the source -- still inside this kernel's LDS array, and not used.)
+        auto wide_copy = [&](const lds_u8* from, uint32_t dp, uint32_t cnt) {
+            const uint32_t full = cnt >> 4, r = cnt & 15u;
+            v4u_any v = {0, 0, 0, 0};
+            uint32_t t = 0;
+            if ((uint32_t)lane < full) v = *reinterpret_cast<const SQY_LDS v4u_any*>(from + (uint32_t)lane * 16u);
+            if ((uint32_t)lane < r) t = from[full * 16u + (uint32_t)lane];
+            if ((uint32_t)lane < full) *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = v;
+            if ((uint32_t)lane < r) ring[dp + full * 16u + (uint32_t)lane] = (uint8_t)t;
+            wave_lds_sync();
+        };
         // match copy: `ml` bytes from `offset` bytes back, onto the ring at pos
         auto copy_match = [&](uint32_t offset, uint32_t ml) {
             if (DEC_RING < 65536u && offset > DEC_RING) {
@@ -3312,79 +3344,64 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                 // (sc1): the line may have been read before this wave's later stores to it.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* const gsrc = out + frame_out;
-                for (uint32_t j = 0; j < ml; j += 64) {
-                    const uint32_t cnt = ml - j < 64 ? ml - j : 64;
+                for (uint32_t j = 0; j < ml;) {                       // up to 1 KiB per step (round 4; before: 64 bytes)
+                    const uint32_t dp = pos & (DEC_RING - 1);
+                    uint32_t cnt = ml - j < 1024u ? ml - j : 1024u;
+                    cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
                     if (j + cnt + 2048u > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the source was written by this very match)
-                    uint32_t v = 0;
-                    if ((uint32_t)lane < cnt) v = __hip_atomic_load(gsrc + (pos - offset + (uint32_t)lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+                    const uint32_t full = cnt >> 4, r = cnt & 15u;
+                    const uint8_t* const g = gsrc + (pos - offset);
+                    uint4 v = make_uint4(0, 0, 0, 0);
+                    uint32_t t = 0;
+                    if ((uint32_t)lane < full) v = ld_u128_agent(g + (uint32_t)lane * 16u);
+                    if ((uint32_t)lane < r) t = __hip_atomic_load(g + full * 16u + (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((uint32_t)lane < full) { const v4u_any vv = {v.x, v.y, v.z, v.w}; *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = vv; }
+                    if ((uint32_t)lane < r) ring[dp + full * 16u + (uint32_t)lane] = (uint8_t)t;
                     wave_lds_sync();
                     pos += cnt;
+                    j += cnt;
                     flush(false);
                 }
                 return;
             }
-            if (ml <= 256u && offset >= ml) {
-                // the source ends in front of the destination: nothing to extend, the up to four 64-byte steps do not depend on
-                // each other -- all reads are issued before the first write, one LDS round trip for the whole match
-                uint32_t v[4];
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const uint32_t k = (uint32_t)lane + 64u * j;
-                    v[j] = 0;
-                    if (k < ml) v[j] = ring[(pos - offset + k) & (DEC_RING - 1)];
-                }
-#pragma unroll
-                for (uint32_t j = 0; j < 4; ++j) {
-                    const uint32_t k = (uint32_t)lane + 64u * j;
-                    if (k < ml) ring[(pos + k) & (DEC_RING - 1)] = (uint8_t)v[j];
-                }
+            // inside the ring.  A short match is one byte per lane (periodic extension when it overlaps its own output).  Longer ones
+            // go up to 1 KiB per step, 16 bytes per lane (round 4; before: 64 bytes per step up to 2 KiB): a step may copy as many
+            // bytes as are known to repeat in front of the cursor -- `period` of them, a multiple of the offset that doubles with every
+            // step that uses it up (byte p equals byte p - offset, hence p - period) --, so its source ends where its destination
+            // begins and all reads come before the writes: one LDS round trip per step.
+            if (ml <= 64u) {
+                const uint32_t lm = (offset >= 64u || offset >= ml) ? (uint32_t)lane : (uint32_t)lane % offset;
+                uint32_t v = 0;
+                if ((uint32_t)lane < ml) v = ring[(pos - offset + lm) & (DEC_RING - 1)];
+                if ((uint32_t)lane < ml) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
                 wave_lds_sync();
                 pos += ml;
                 flush(false);
                 return;
             }
-            // periodic extension, 64 bytes per step: byte p equals byte p - offset, so every step reads from the
-            // `offset` bytes in front of the write cursor (complete by then) and the ring never needs more than 64 KiB
-            // (an integer modulo is ~40 instructions: only when a step's source overlaps its destination)
-            const uint32_t lmod = (offset >= 64u || offset >= ml) ? (uint32_t)lane : (uint32_t)lane % offset;
-            // long matches switch to 1 KiB steps (16 bytes per lane) once enough of the match is written: byte p also
-            // equals byte p - off2 for any multiple off2 of the offset, and off2 >= 1024 makes a step's source disjoint
-            // from its destination
-            if (ml < 2048u) {                                       // the usual short match: nothing but the byte steps
-                for (uint32_t j = 0; j < ml; j += 64) {
-                    const uint32_t cnt = ml - j < 64 ? ml - j : 64;
-                    uint32_t v = 0;
-                    if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
-                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
-                    wave_lds_sync();
-                    pos += cnt;
-                    flush(false);
-                }
-                return;
-            }
-            const uint32_t off2 = offset >= 1024u ? offset : offset * ((1024u + offset - 1u) / offset);
-            uint32_t j = 0;
-            while (j < ml) {
-                const uint32_t sp = (pos - off2) & (DEC_RING - 1), dp = pos & (DEC_RING - 1);
-                if (ml - j >= 1024u && j + offset >= off2 && off2 <= pos && sp + 1024u <= DEC_RING && dp + 1024u <= DEC_RING) {
-                    const v4u_any v = *reinterpret_cast<const SQY_LDS v4u_any*>(ring + sp + (uint32_t)lane * 16u);
-                    wave_lds_sync();
-                    *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = v;
-                    wave_lds_sync();
-                    pos += 1024u;
-                    j += 1024u;
-                    flush(false);
-                    continue;
-                }
-                const uint32_t cnt = ml - j < 64 ? ml - j : 64;
-                uint32_t v = 0;
-                if ((uint32_t)lane < cnt) v = ring[(pos - offset + lmod) & (DEC_RING - 1)];
-                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+            uint32_t rem = ml, period = offset;
+            if (offset < 64u) {
+                // the first 64 bytes by periodic extension, then whole periods: the largest multiple of the offset inside what is written
+                const uint32_t lm = (uint32_t)lane % offset;
+                const uint32_t v = ring[(pos - offset + lm) & (DEC_RING - 1)];
+                ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
                 wave_lds_sync();
-                pos += cnt;
-                j += cnt;
+                pos += 64u;
+                rem -= 64u;
                 flush(false);
+                period = ((64u + offset) / offset) * offset;            // <= 64 + offset bytes repeat in front of the cursor
+            }
+            while (rem) {
+                const uint32_t sp = (pos - period) & (DEC_RING - 1), dp = pos & (DEC_RING - 1);
+                uint32_t cnt = rem < 1024u ? rem : 1024u;
+                cnt = cnt < period ? cnt : period;
+                cnt = cnt < DEC_RING - sp ? cnt : DEC_RING - sp;            // neither side wraps inside a step
+                cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
+                wide_copy(ring + sp, dp, cnt);
+                pos += cnt;
+                rem -= cnt;
+                flush(false);
+                if (cnt == period && period < 1024u) period <<= 1;
             }
         };
         while (ip < sz) {
@@ -3399,7 +3416,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                 const uint32_t wi = ip - sbase + (uint32_t)lane;
                 const uint32_t tokb = stage[wi];
                 const uint32_t flit = tokb >> 4, fml = tokb & 15u;
-                const uint32_t w = lds_ld_u32(stage + wi + 1u + flit);            // offset, first extension byte
+                const uint32_t w = lds_ld_u32_via_aligned(stage, wi + 1u + flit);  // offset, first extension byte (stage: 16-byte aligned)
                 const uint32_t offs = w & 0xffffu, ext = (w >> 16) & 0xffu;
                 const bool okl = flit < 15u && (fml < 15u || ext < 255u);
                 const uint32_t mlen = fml < 15u ? fml + 4u : 19u + ext;           // <= 273
@@ -3517,24 +3534,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                             const uint32_t inf = lane_read(info, sl);
                             const uint32_t off = inf >> 16, mln = (inf >> 4) & 0xfffu;
                             pos = base + lane_read(rel, sl) + (inf & 15u);
-                            if (mln <= 256u && off >= mln && off <= DEC_RING) {
-                                uint32_t v[4];
-#pragma unroll
-                                for (uint32_t j = 0; j < 4; ++j) {
-                                    const uint32_t kk = (uint32_t)lane + 64u * j;
-                                    v[j] = 0;
-                                    if (kk < mln) v[j] = ring[(pos - off + kk) & (DEC_RING - 1)];
-                                }
-#pragma unroll
-                                for (uint32_t j = 0; j < 4; ++j) {
-                                    const uint32_t kk = (uint32_t)lane + 64u * j;
-                                    if (kk < mln) ring[(pos + kk) & (DEC_RING - 1)] = (uint8_t)v[j];
-                                }
-                                wave_lds_sync();
-                                pos += mln;
-                                flush(false);
-                            } else
-                                copy_match(off, mln);
+                            copy_match(off, mln);
                         }
                         ip += cur;
                         backoff = 8;
@@ -3550,7 +3550,15 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             bool have_token = false;
             if (ip + 16u <= sz) {
                 need(ip, 16);
-                const v4u_any hw = *reinterpret_cast<const SQY_LDS v4u_any*>(stage + (ip - sbase));
+                // (five aligned dwords and four v_alignbyte instead of one 16-byte read at a byte address: no replay, ~100 cycles against 147)
+                uint4 hw;
+                {
+                    const uint32_t at = ip - sbase, sh = at & 3u;
+                    const uint4 d = lds_ld_4dw(stage + (at & ~3u));
+                    const uint32_t d4 = *reinterpret_cast<const volatile SQY_LDS uint32_t*>(stage + (at & ~3u) + 16u);
+                    hw = make_uint4(__builtin_amdgcn_alignbyte(d.y, d.x, sh), __builtin_amdgcn_alignbyte(d.z, d.y, sh),
+                                    __builtin_amdgcn_alignbyte(d.w, d.z, sh), __builtin_amdgcn_alignbyte(d4, d.w, sh));
+                }
                 const uint32_t w0 = sgpr(hw.x);
                 const uint32_t tok = w0 & 0xffu, flit = tok >> 4, fml = tok & 15u;
                 token = tok; have_token = true;
@@ -3624,11 +3632,13 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             if (bad || ip + lit > sz || pos - block_start + lit > block_bytes) { bad = true; break; }
             if (lit <= DEC_IN - 64u) {
                 if (lit) need(ip, lit);
-                for (uint32_t i = 0; i < lit; i += 64) {
-                    const uint32_t cnt = lit - i < 64 ? lit - i : 64;
-                    if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = stage[ip - sbase + i + lane];
-                    wave_lds_sync();
+                for (uint32_t i = 0; i < lit;) {                          // up to 1 KiB per step (round 4; before: 64 bytes)
+                    const uint32_t dp = pos & (DEC_RING - 1);
+                    uint32_t cnt = lit - i < 1024u ? lit - i : 1024u;
+                    cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
+                    wide_copy(stage + (ip - sbase + i), dp, cnt);
                     pos += cnt;
+                    i += cnt;
                     flush(false);
                 }
             } else {
