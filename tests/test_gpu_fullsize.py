@@ -211,3 +211,28 @@ def test_headline_four_calls_in_flight_equal_the_reference_digest(sqy):
     assert not errors, errors
     for t in range(T):
         assert results[t] and all(h == g["blob_sha256"] for h in results[t]), "thread %d produced a blob that differs from the reference digest" % t
+
+
+@pytest.mark.parametrize("prefix", ["C1", "C2", "north_star slab 0"])
+def test_headline_serial_layout_equals_the_reference_digest(sqy, prefix):
+    """nthreads = 1, what the reference's own callers pass: ONE block-linked frame (lz4_utils.hpp:99-173).  Round 4 parses its blocks
+    block-parallel from verified table guesses; the blob must equal what the reference SSE gather + liblz4's LZ4F_compressUpdate
+    sequence give for the headline stacks (tests/golden/headline.json "serial", oracle/gen_golden.py --headline-serial)"""
+    import torch
+    g = _headline(prefix)
+    shape = tuple(g["shape_zyx"])
+    dev = torch.device("cuda", 0)
+    vol = synth.stack_torch(shape, np.uint16, dev, z_offset=g["z_offset"], z_total=g["z_total"])
+    cap = sqy.max_compressed_length("bitswap1->lz4", shape, np.uint16)
+    out = torch.full((cap,), 0x5A, dtype=torch.uint8, device=dev)
+    for _ in range(2):                                                         # (the second call reuses the workspace: stale tables in it)
+        rc, n = sqy.encode_device("bitswap1->lz4", vol.data_ptr(), shape, np.uint16, out.data_ptr(), cap, nthreads=1)
+        assert rc == 0 and n == g["serial"]["blob_bytes"]
+        blob = out[:n].cpu().numpy().tobytes()
+        hs = g["serial"]["header_bytes"]
+        assert _sha(blob[hs:]) == g["serial"]["payload_sha256"], "serial-layout payload differs from the reference pieces' payload"
+        assert _sha(blob) == g["serial"]["blob_sha256"]
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol.cpu().numpy())
+    del vol, out
+    torch.cuda.empty_cache()
