@@ -3541,6 +3541,10 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                         continue;
                     }
                     if (fits) { one_by_one = backoff > nst ? backoff : nst; backoff = backoff < 256u ? backoff * 2u : 256u; }
+                } else {
+                    // not even the first sequence fits the batch's mould (15+ literals, a long match): the same back-off
+                    one_by_one = backoff;
+                    backoff = backoff < 256u ? backoff * 2u : 256u;
                 }
             }
             // one sequence at a time: whatever the batch does not take (long literal runs, long matches, the block's tail).
@@ -3617,6 +3621,63 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                             pos += flit;
                         }
                         ip += used;
+                        copy_match(offset, ml);
+                        continue;
+                    }
+                }
+                // The general sequence in TWO reads (round 4): the window holds the token and the literal-length bytes; behind the
+                // literals a second window holds the offset and the match-length bytes.  Its read is issued in front of the literal
+                // copy and looked at behind it, so the copy's LDS round trip hides it.  (Before: a dependent broadcast read per
+                // header byte -- six in a row for 15+ literals and a match of 19+ bytes, what the diff3x3x1 planes are made of.)
+                {
+                    const uint32_t w1 = sgpr(hw.y), w2 = sgpr(hw.z), w3 = sgpr(hw.w);
+                    const uint64_t lo = ((uint64_t)w1 << 32) | w0, hi = ((uint64_t)w3 << 32) | w2;
+                    auto wbyte = [&](uint32_t i) -> uint32_t { return i < 8u ? (uint32_t)(lo >> (8u * i)) & 0xffu : (uint32_t)(hi >> (8u * (i - 8u))) & 0xffu; };
+                    uint32_t lit = flit, used = 1u;
+                    bool lit_ok = flit < 15u;
+                    while (!lit_ok && used < 16u) {
+                        const uint32_t sb = wbyte(used++);
+                        lit += sb;
+                        lit_ok = sb != 255u;
+                    }
+                    const uint32_t ipl = ip + used;                                  // the first literal
+                    if (lit_ok && lit <= DEC_IN - 128u && ipl + lit + 16u <= sz) {
+                        if (pos - block_start + lit > block_bytes) { bad = true; break; }
+                        need(ip, used + lit + 16u);
+                        const uint32_t at = ipl + lit - sbase, sh = at & 3u;
+                        const uint4 d = lds_ld_4dw(stage + (at & ~3u));
+                        const uint32_t d4 = *reinterpret_cast<const volatile SQY_LDS uint32_t*>(stage + (at & ~3u) + 16u);
+                        for (uint32_t i = 0; i < lit;) {
+                            const uint32_t dp = pos & (DEC_RING - 1);
+                            uint32_t cnt = lit - i < 1024u ? lit - i : 1024u;
+                            cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
+                            wide_copy(stage + (ipl - sbase + i), dp, cnt);
+                            pos += cnt;
+                            i += cnt;
+                            flush(false);
+                        }
+                        const uint32_t x0 = sgpr(__builtin_amdgcn_alignbyte(d.y, d.x, sh)), x1 = sgpr(__builtin_amdgcn_alignbyte(d.z, d.y, sh));
+                        const uint32_t x2 = sgpr(__builtin_amdgcn_alignbyte(d.w, d.z, sh)), x3 = sgpr(__builtin_amdgcn_alignbyte(d4, d.w, sh));
+                        const uint64_t lo2 = ((uint64_t)x1 << 32) | x0, hi2 = ((uint64_t)x3 << 32) | x2;
+                        auto xbyte = [&](uint32_t i) -> uint32_t { return i < 8u ? (uint32_t)(lo2 >> (8u * i)) & 0xffu : (uint32_t)(hi2 >> (8u * (i - 8u))) & 0xffu; };
+                        const uint32_t offset = x0 & 0xffffu;
+                        uint32_t ml = fml, used2 = 2u;
+                        bool ml_ok = fml < 15u;
+                        while (!ml_ok && used2 < 16u) {
+                            const uint32_t sb = xbyte(used2++);
+                            ml += sb;
+                            ml_ok = sb != 255u;
+                        }
+                        ip = ipl + lit + used2;
+                        while (!ml_ok) {                                             // (a match of more than 3.3 KiB: byte by byte from here)
+                            if (ip >= sz) { bad = true; break; }
+                            need(ip, 1);
+                            const uint32_t sb = sbyte_at(ip++);
+                            ml += sb;
+                            ml_ok = sb != 255u;
+                        }
+                        ml += 4u;
+                        if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
                         copy_match(offset, ml);
                         continue;
                     }
