@@ -1275,14 +1275,32 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 }
                 uint8_t* out = out_buf(si, total);
                 if (!out) return 1;
-                {
-                    const bool side_ok = cx.ensure_side();           // (without it the copy simply follows on the same stream)
-                    ProfScope ps("lz4_frames_decode", stream, pend);
-                    SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, side_ok ? cx.side : nullptr, cx.fork, cx.join));
-                }
                 uint32_t bad = 0;
-                SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
-                SQY_HIP(hipStreamSynchronize(stream));
+                bool decoded = false;
+                // ONE block-linked frame (nthreads = 1 on the encoder's side): every block at once with the history as an unknown, the
+                // references resolved afterwards (sqy_kernels.hip: lz4_blocks_decode_sym_kernel).  A stream that is not a frame of
+                // full blocks, or is damaged, raises the flag: the one-wavefront walk below then decides, as in rounds 2-3.
+                if (nframes == 1 && !std::getenv("SQY_NO_BLOCK_PARALLEL") && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes)) {
+                    if (ws->spec.ensure(total * sizeof(uint16_t))) return 1;
+                    {
+                        ProfScope ps("lz4_linked_decode", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_linked_decode_parallel(cur, blk, hc[1], out, static_cast<uint16_t*>(ws->spec.p), total, block_bytes,
+                                                                       counts + 4, stream));
+                    }
+                    SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
+                    SQY_HIP(hipStreamSynchronize(stream));
+                    decoded = bad == 0;
+                    if (!decoded) SQY_HIP(hipMemsetAsync(counts + 4, 0, sizeof(uint32_t), stream));
+                }
+                if (!decoded) {
+                    {
+                        const bool side_ok = cx.ensure_side();           // (without it the copy simply follows on the same stream)
+                        ProfScope ps("lz4_frames_decode", stream, pend);
+                        SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, side_ok ? cx.side : nullptr, cx.fork, cx.join));
+                    }
+                    SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
+                    SQY_HIP(hipStreamSynchronize(stream));
+                }
                 if (bad) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 block, or a frame that does not decode to its share of the volume\n"); return stage_error(si); }
                 cur = out; cur_bytes = total;
                 break;

@@ -3774,6 +3774,467 @@ void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* 
     if ((uint32_t)tid < len0 - done) d[done + tid] = s[done + tid];
 }
 
+// ---- ONE block-linked frame (the serial layout, nthreads = 1) decoded block-parallel (round 4) --------------------------------------
+// A block of a linked frame may copy from the 64 KiB decoded in front of it, so rounds 2-3 decoded the frame with one wavefront
+// (0.34 GB/s on the 1 GiB bench stack).  The dependence is shallow, though: every byte of a block is a literal of the block or equals
+// ONE byte of the history in front of the block -- whatever chain of copies inside the block leads there.  So:
+//   1. lz4_blocks_decode_sym_kernel, one wavefront per compressed block, all blocks at once: decodes the block with the history as
+//      an unknown -- next to every output byte it keeps a 16-bit reference (0: the byte is known; d: the byte equals the byte d in
+//      front of the block's first byte), copied along with the bytes by every match.  The history itself enters as bytes with
+//      reference = their distance.  Output: the block's bytes (unknown ones as 0) and its references (`refs`, 2 bytes per byte).
+//      Stored blocks are plain copies (lz4_linked_stored_copy_kernel).
+//   2. lz4_linked_resolve_tails_kernel, one workgroup walking the blocks in order: only the last 64 KiB of block k-1 can be named by
+//      block k, so the chain that has to be followed in order is short -- the tail of block k is resolved from the resolved tail of
+//      block k-1, kept in LDS (64 LDS gathers per thread and block).
+//   3. lz4_linked_resolve_bodies_kernel, every block at once: the remaining bytes that carry a reference take the byte out of the
+//      (now final) tail in front of their block.
+// Every block but the last must decode to exactly block_bytes (LZ4F without autoFlush only cuts full blocks): checked; a stream that
+// is built differently, or is damaged, raises the flag and the host falls back to the one-wavefront walk (which owns the error codes).
+constexpr uint32_t SYM_RING = 16384, SYM_IN = 3072, SYM_TAIL = 65536;
+
+__global__ __launch_bounds__(256)
+void lz4_linked_stored_copy_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, uint8_t* __restrict__ out, uint64_t out_bytes,
+                                   uint64_t block_bytes, uint32_t slices_per_block, uint32_t* __restrict__ errflag)
+{
+    const uint32_t k = blockIdx.x / slices_per_block, slice = blockIdx.x % slices_per_block;
+    const uint4 e = blk[k];
+    if (!(e.z >> 31)) return;
+    const uint32_t sz = e.z & 0x7fffffffu;
+    const uint64_t o = (uint64_t)k * block_bytes;
+    const uint64_t expect = o < out_bytes ? (out_bytes - o < block_bytes ? out_bytes - o : block_bytes) : 0;
+    if ((uint64_t)sz != expect) { if (slice == 0 && threadIdx.x == 0) atomicExch(errflag, 1u); return; }
+    const uint32_t begin = slice * DEC_COPY_SLICE;
+    if (begin >= sz) return;
+    const uint32_t len0 = sz - begin < DEC_COPY_SLICE ? sz - begin : DEC_COPY_SLICE;
+    const uint8_t* __restrict__ s = in + (((uint64_t)e.y << 32) | e.x) + begin;
+    uint8_t* __restrict__ d = out + o + begin;
+    const int tid = threadIdx.x;
+    const uint32_t head0 = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(d) & 15)) & 15);
+    const uint32_t head = head0 < len0 ? head0 : len0;
+    if ((uint32_t)tid < head) d[tid] = s[tid];
+    const uint32_t nvec = (len0 - head) >> 4;
+    for (uint32_t i0 = tid; i0 < nvec; i0 += 1024) {
+        uint4 v[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j * 256u < nvec) v[j] = ld_u128(s + head + (size_t)(i0 + j * 256u) * 16);
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (i0 + j * 256u < nvec) *reinterpret_cast<uint4*>(d + head + (size_t)(i0 + j * 256u) * 16) = v[j];
+    }
+    const uint32_t done = head + (nvec << 4);
+    if ((uint32_t)tid < len0 - done) d[done + tid] = s[done + tid];
+}
+
+__global__ __launch_bounds__(64)
+void lz4_blocks_decode_sym_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, uint8_t* __restrict__ out,
+                                  uint16_t* __restrict__ refs, uint64_t out_bytes, uint64_t block_bytes, uint32_t* __restrict__ errflag)
+{
+    __shared__ __attribute__((aligned(16))) uint8_t sym_raw[SYM_RING + 2 * SYM_RING + SYM_IN + 64];
+    lds_u8* ring = (lds_u8*)sym_raw;                                            // the last 16 KiB of the block's output ..
+    SQY_LDS uint16_t* rref = (SQY_LDS uint16_t*)((lds_u8*)sym_raw + SYM_RING);  // .. and their references
+    lds_u8* stage = (lds_u8*)sym_raw + 3 * SYM_RING;
+    constexpr uint32_t MASK = SYM_RING - 1;
+    const int lane = threadIdx.x;
+    const uint32_t k = blockIdx.x;
+    const uint4 e = blk[k];
+    if (e.z >> 31) return;                                                      // stored: lz4_linked_stored_copy_kernel
+    const uint8_t* __restrict__ src = in + (((uint64_t)e.y << 32) | e.x);
+    const uint32_t sz = e.z & 0x7fffffffu;
+    const uint64_t base = (uint64_t)k * block_bytes;
+    if (base >= out_bytes) { if (lane == 0) atomicExch(errflag, 1u); return; }
+    const uint32_t expect = (uint32_t)(out_bytes - base < block_bytes ? out_bytes - base : block_bytes);
+    uint8_t* __restrict__ dout = out + base;
+    uint16_t* __restrict__ dref = refs + base;
+    // the history in front of the block, as far as the ring reaches: unknown bytes that refer to themselves (block 0 has none:
+    // its matches cannot reach in front of it, checked below)
+    for (uint32_t i = lane; i < SYM_RING; i += 64) { ring[i] = 0; rref[i] = (uint16_t)(k ? SYM_RING - i : 0u); }
+    wave_lds_sync();
+    const uint32_t reach = k ? 65535u : 0u;                                     // how far in front of the block a match may begin
+    uint32_t pos = 0, flushed = 0, ip = 0;
+    bool bad = false;
+
+    auto flush = [&](bool all) {
+        while (flushed + 1024u <= pos) {                                        // whole KiB pieces: bytes and references
+            const uint32_t ri = (flushed & MASK) + (uint32_t)lane * 16u;
+            const v4u d = *reinterpret_cast<const SQY_LDS v4u*>(ring + ri);
+            const v4u r0 = *reinterpret_cast<const SQY_LDS v4u*>(rref + ri), r1 = *reinterpret_cast<const SQY_LDS v4u*>(rref + ri + 8u);
+            *reinterpret_cast<v4u_any*>(dout + flushed + (uint32_t)lane * 16u) = d;
+            *reinterpret_cast<v4u_any*>(dref + flushed + (uint32_t)lane * 16u) = r0;
+            *reinterpret_cast<v4u_any*>(dref + flushed + (uint32_t)lane * 16u + 8u) = r1;
+            flushed += 1024u;
+        }
+        if (all) {
+            for (uint32_t i = flushed + (uint32_t)lane; i < pos; i += 64u) { dout[i] = ring[i & MASK]; dref[i] = rref[i & MASK]; }
+            flushed = pos;
+        }
+    };
+    uint32_t sbase = 0, shi = 0;
+    auto fill = [&](uint32_t at) {
+        sbase = at & ~15u;
+#pragma unroll
+        for (uint32_t j = 0; j < SYM_IN / 1024; ++j) {
+            const uint32_t a = sbase + j * 1024u + (uint32_t)lane * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a + 16u <= sz) v = ld_u128(src + a);
+            else if (a < sz) {
+                uint32_t wv[4] = {0, 0, 0, 0};
+                for (uint32_t q = 0; a + q < sz; ++q) wv[q >> 2] |= (uint32_t)src[a + q] << (8u * (q & 3u));
+                v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+            const v4u vv = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<SQY_LDS v4u*>(stage + j * 1024u + (uint32_t)lane * 16u) = vv;
+        }
+        wave_lds_sync();
+        shi = sbase + SYM_IN < sz ? sbase + SYM_IN : sz;
+    };
+    auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };   // cnt <= SYM_IN - 16, at + cnt <= sz
+    auto sbyte_at = [&](uint32_t at) -> uint32_t { return stage[at - sbase]; };
+    // 16 window bytes at block offset `at` (inside the stage) as four scalars
+    auto window = [&](uint32_t at) -> uint4 {
+        const uint32_t a = at - sbase, sh = a & 3u;
+        const uint4 d = lds_ld_4dw(stage + (a & ~3u));
+        const uint32_t d4 = *reinterpret_cast<const volatile SQY_LDS uint32_t*>(stage + (a & ~3u) + 16u);
+        return make_uint4(sgpr(__builtin_amdgcn_alignbyte(d.y, d.x, sh)), sgpr(__builtin_amdgcn_alignbyte(d.z, d.y, sh)),
+                          sgpr(__builtin_amdgcn_alignbyte(d.w, d.z, sh)), sgpr(__builtin_amdgcn_alignbyte(d4, d.w, sh)));
+    };
+    // cnt <= 1024 bytes with their references, LDS -> ring at dp (no wrap on either side); from_ref == nullptr: literals (reference 0)
+    auto wide_copy = [&](const lds_u8* from, const SQY_LDS uint16_t* from_ref, uint32_t dp, uint32_t cnt) {
+        const uint32_t full = cnt >> 4, r = cnt & 15u;
+        const uint32_t l16 = (uint32_t)lane * 16u;
+        v4u_any v = {0, 0, 0, 0}, ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+        uint32_t t = 0, tr = 0;
+        if ((uint32_t)lane < full) {
+            v = *reinterpret_cast<const SQY_LDS v4u_any*>(from + l16);
+            if (from_ref) { ra = *reinterpret_cast<const SQY_LDS v4u_any*>(from_ref + l16); rb = *reinterpret_cast<const SQY_LDS v4u_any*>(from_ref + l16 + 8u); }
+        }
+        if ((uint32_t)lane < r) { t = from[full * 16u + (uint32_t)lane]; if (from_ref) tr = from_ref[full * 16u + (uint32_t)lane]; }
+        if ((uint32_t)lane < full) {
+            *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + l16) = v;
+            *reinterpret_cast<SQY_LDS v4u_any*>(rref + dp + l16) = ra;
+            *reinterpret_cast<SQY_LDS v4u_any*>(rref + dp + l16 + 8u) = rb;
+        }
+        if ((uint32_t)lane < r) { ring[dp + full * 16u + (uint32_t)lane] = (uint8_t)t; rref[dp + full * 16u + (uint32_t)lane] = (uint16_t)tr; }
+        wave_lds_sync();
+    };
+    auto copy_literals = [&](uint32_t at, uint32_t lit) {                       // stage -> ring; [at, at + lit) is in the stage
+        for (uint32_t i = 0; i < lit;) {
+            const uint32_t dp = pos & MASK;
+            uint32_t cnt = lit - i < 1024u ? lit - i : 1024u;
+            cnt = cnt < SYM_RING - dp ? cnt : SYM_RING - dp;
+            wide_copy(stage + (at - sbase + i), nullptr, dp, cnt);
+            pos += cnt;
+            i += cnt;
+            flush(false);
+        }
+    };
+    auto copy_match = [&](uint32_t offset, uint32_t ml) {
+        uint32_t rem = ml;
+        if (offset > SYM_RING) {
+            // behind the ring: the block's own output, flushed at least 15 KiB ago (bytes and references, past this CU's L1) -- or
+            // the history in front of the block, where a byte is nothing but its distance
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            while (rem) {
+                const uint32_t dp = pos & MASK;
+                uint32_t cnt = rem < 1024u ? rem : 1024u;
+                cnt = cnt < SYM_RING - dp ? cnt : SYM_RING - dp;
+                const uint32_t full = cnt >> 4, r = cnt & 15u;
+                const int32_t q0 = (int32_t)(pos - offset) + lane * 16;         // block-relative position of this lane's first source byte
+                if ((uint32_t)lane < full) {
+                    uint32_t dw[4] = {0, 0, 0, 0}, rw[8];
+                    if (q0 + 15 >= 0) {                                          // (may begin up to 15 bytes in front of the block: patched below)
+                        const uint4 a = ld_u128_agent(dout + q0);
+                        const uint4 b0 = ld_u128_agent(reinterpret_cast<const uint8_t*>(dref + q0)), b1 = ld_u128_agent(reinterpret_cast<const uint8_t*>(dref + q0 + 8));
+                        dw[0] = a.x; dw[1] = a.y; dw[2] = a.z; dw[3] = a.w;
+                        rw[0] = b0.x; rw[1] = b0.y; rw[2] = b0.z; rw[3] = b0.w; rw[4] = b1.x; rw[5] = b1.y; rw[6] = b1.z; rw[7] = b1.w;
+                    }
+                    if (q0 < 0) {
+                        const uint32_t nneg = (uint32_t)(-q0) < 16u ? (uint32_t)(-q0) : 16u;      // leading bytes that lie in front of the block
+#pragma unroll
+                        for (uint32_t m = 0; m < 4; ++m) {
+                            const uint32_t lo = 4u * m;
+                            dw[m] = nneg >= lo + 4u ? 0u : (nneg <= lo ? dw[m] : dw[m] & (0xffffffffu << (8u * (nneg - lo))));
+                        }
+#pragma unroll
+                        for (uint32_t m = 0; m < 8; ++m) {
+                            const uint32_t j0 = 2u * m, j1 = 2u * m + 1u;
+                            const uint32_t a0 = j0 < nneg ? (uint32_t)(-(q0 + (int32_t)j0)) : (rw[m] & 0xffffu);
+                            const uint32_t a1 = j1 < nneg ? (uint32_t)(-(q0 + (int32_t)j1)) : (rw[m] >> 16);
+                            rw[m] = a0 | (a1 << 16);
+                        }
+                    }
+                    const v4u_any dv = {dw[0], dw[1], dw[2], dw[3]}, ra = {rw[0], rw[1], rw[2], rw[3]}, rb = {rw[4], rw[5], rw[6], rw[7]};
+                    *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = dv;
+                    *reinterpret_cast<SQY_LDS v4u_any*>(rref + dp + (uint32_t)lane * 16u) = ra;
+                    *reinterpret_cast<SQY_LDS v4u_any*>(rref + dp + (uint32_t)lane * 16u + 8u) = rb;
+                }
+                if ((uint32_t)lane < r) {
+                    const int32_t q = (int32_t)(pos - offset) + (int32_t)(full * 16u) + lane;
+                    uint32_t t = 0, tr;
+                    if (q < 0) tr = (uint32_t)(-q);
+                    else {
+                        t = __hip_atomic_load(dout + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tr = __hip_atomic_load(dref + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    ring[dp + full * 16u + (uint32_t)lane] = (uint8_t)t;
+                    rref[dp + full * 16u + (uint32_t)lane] = (uint16_t)tr;
+                }
+                wave_lds_sync();
+                pos += cnt;
+                rem -= cnt;
+                flush(false);
+                if (rem && (ml - rem) + 3072u > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the next source is what this match wrote itself)
+            }
+            return;
+        }
+        // inside the ring (bytes and references alike; the history's last 16 KiB sit there as references to themselves)
+        if (ml <= 64u) {
+            const uint32_t lm = (offset >= 64u || offset >= ml) ? (uint32_t)lane : (uint32_t)lane % offset;
+            uint32_t v = 0, rv = 0;
+            if ((uint32_t)lane < ml) { v = ring[(pos - offset + lm) & MASK]; rv = rref[(pos - offset + lm) & MASK]; }
+            if ((uint32_t)lane < ml) { ring[(pos + lane) & MASK] = (uint8_t)v; rref[(pos + lane) & MASK] = (uint16_t)rv; }
+            wave_lds_sync();
+            pos += ml;
+            flush(false);
+            return;
+        }
+        uint32_t period = offset;
+        if (offset < 64u) {
+            const uint32_t lm = (uint32_t)lane % offset;
+            const uint32_t v = ring[(pos - offset + lm) & MASK], rv = rref[(pos - offset + lm) & MASK];
+            ring[(pos + lane) & MASK] = (uint8_t)v; rref[(pos + lane) & MASK] = (uint16_t)rv;
+            wave_lds_sync();
+            pos += 64u;
+            rem -= 64u;
+            flush(false);
+            period = ((64u + offset) / offset) * offset;
+        }
+        while (rem) {
+            const uint32_t sp = (pos - period) & MASK, dp = pos & MASK;
+            uint32_t cnt = rem < 1024u ? rem : 1024u;
+            cnt = cnt < period ? cnt : period;
+            cnt = cnt < SYM_RING - sp ? cnt : SYM_RING - sp;
+            cnt = cnt < SYM_RING - dp ? cnt : SYM_RING - dp;
+            wide_copy(ring + sp, rref + sp, dp, cnt);
+            pos += cnt;
+            rem -= cnt;
+            flush(false);
+            if (cnt == period && period < 1024u) period <<= 1;
+        }
+    };
+
+    while (ip < sz && !bad) {
+        // token and literal-length bytes out of one window, the offset and match-length bytes out of a second one behind the
+        // literals (the block's last bytes, where a window would run past the block: byte by byte)
+        uint32_t token, lit, used = 1u;
+        bool lit_ok;
+        if (ip + 16u <= sz) {
+            need(ip, 16);
+            const uint4 hw = window(ip);
+            const uint64_t lo = ((uint64_t)hw.y << 32) | hw.x, hi = ((uint64_t)hw.w << 32) | hw.z;
+            token = hw.x & 0xffu;
+            lit = token >> 4;
+            lit_ok = lit < 15u;
+            while (!lit_ok && used < 16u) {
+                const uint32_t sb = used < 8u ? (uint32_t)(lo >> (8u * used)) & 0xffu : (uint32_t)(hi >> (8u * (used - 8u))) & 0xffu;
+                ++used;
+                lit += sb;
+                lit_ok = sb != 255u;
+            }
+        } else {
+            need(ip, 1);
+            token = sbyte_at(ip);
+            lit = token >> 4;
+            lit_ok = lit < 15u;
+        }
+        uint32_t ipl = ip + used;
+        while (!lit_ok) {
+            if (ipl >= sz) { bad = true; break; }
+            need(ipl, 1);
+            const uint32_t sb = sbyte_at(ipl++);
+            lit += sb;
+            lit_ok = sb != 255u;
+        }
+        if (bad || ipl + lit > sz || pos + lit > expect) { bad = true; break; }
+        const bool second_window = lit <= SYM_IN - 128u && ipl + lit + 16u <= sz;
+        uint4 xw = make_uint4(0, 0, 0, 0);
+        if (second_window) {
+            need(ip, (ipl - ip) + lit + 16u);                                   // (ipl - ip <= 16 whenever lit is this small)
+            xw = window(ipl + lit);
+            copy_literals(ipl, lit);
+        } else if (lit <= SYM_IN - 64u) {
+            if (lit) { need(ipl, lit); copy_literals(ipl, lit); }
+        } else {
+            for (uint32_t i = 0; i < lit; i += 64) {                            // a literal run longer than the stage: stream -> ring
+                const uint32_t cnt = lit - i < 64 ? lit - i : 64;
+                if ((uint32_t)lane < cnt) { ring[(pos + lane) & MASK] = src[ipl + i + lane]; rref[(pos + lane) & MASK] = 0; }
+                wave_lds_sync();
+                pos += cnt;
+                flush(false);
+            }
+        }
+        ip = ipl + lit;
+        if (ip >= sz) break;                                                    // the block's last sequence: literals only
+        uint32_t offset, ml = token & 15u;
+        bool ml_ok = ml < 15u;
+        if (second_window) {
+            const uint64_t lo = ((uint64_t)xw.y << 32) | xw.x, hi = ((uint64_t)xw.w << 32) | xw.z;
+            offset = xw.x & 0xffffu;
+            uint32_t used2 = 2u;
+            while (!ml_ok && used2 < 16u) {
+                const uint32_t sb = used2 < 8u ? (uint32_t)(lo >> (8u * used2)) & 0xffu : (uint32_t)(hi >> (8u * (used2 - 8u))) & 0xffu;
+                ++used2;
+                ml += sb;
+                ml_ok = sb != 255u;
+            }
+            ip += used2;
+        } else {
+            if (ip + 2u > sz) { bad = true; break; }
+            need(ip, 2);
+            offset = sbyte_at(ip) | (sbyte_at(ip + 1u) << 8);
+            ip += 2u;
+        }
+        while (!ml_ok) {
+            if (ip >= sz) { bad = true; break; }
+            need(ip, 1);
+            const uint32_t sb = sbyte_at(ip++);
+            ml += sb;
+            ml_ok = sb != 255u;
+        }
+        ml += 4u;
+        if (bad || offset == 0u || offset > pos + reach || pos + ml > expect) { bad = true; break; }
+        copy_match(offset, ml);
+    }
+    flush(true);
+    if (pos != expect) bad = true;                                              // (every block of the frame but the last is a full block)
+    if (bad && lane == 0) atomicExch(errflag, 1u);
+}
+
+// the tails, in order: one workgroup; LDS holds the resolved last 64 KiB of the block in front.  A thread owns 64 consecutive bytes;
+// the bytes and references of the NEXT block's tail are fetched while the block in hand is resolved.  Four bytes at a time: references
+// that count down (a straight copy out of the history: four consecutive bytes, one LDS read) or are all equal (a run), else byte by byte.
+__global__ __launch_bounds__(1024)
+void lz4_linked_resolve_tails_kernel(const uint4* __restrict__ blk, uint32_t nblocks, uint8_t* __restrict__ out, const uint16_t* __restrict__ refs,
+                                     uint64_t out_bytes, uint64_t block_bytes)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t tails_lds[];                 // 2 x 64 KiB
+    SQY_LDS uint8_t* prev = (SQY_LDS uint8_t*)tails_lds;
+    SQY_LDS uint8_t* cur = (SQY_LDS uint8_t*)tails_lds + SYM_TAIL;
+    __shared__ uint32_t rawbits[1024];                                                  // bit k: block k is stored (nblocks <= 32768, host)
+    const uint32_t t = threadIdx.x;
+    {
+        uint32_t bits = 0;
+        for (uint32_t j = 0; j < 32u; ++j) { const uint32_t b = t * 32u + j; if (b < nblocks && (blk[b].z >> 31)) bits |= 1u << j; }
+        rawbits[t] = bits;
+    }
+    __syncthreads();
+    auto is_raw = [&](uint32_t b) -> bool { return ((rawbits[b >> 5] >> (b & 31u)) & 1u) != 0u; };
+    // what block k asks of this thread: 0 nothing (stored, next one stored too), 1 bytes only (known bytes the next block will look at),
+    // 2 bytes and references (a compressed block behind the first)
+    auto wants = [&](uint32_t b) -> uint32_t {
+        if (b + 1 >= nblocks) return 0u;
+        if (is_raw(b) || b == 0) return is_raw(b + 1) ? 0u : 1u;
+        return 2u;
+    };
+    uint32_t d[16], rr[32];
+    auto fetch = [&](uint32_t b, uint32_t what) {
+        if (!what) return;
+        const uint64_t tb = (uint64_t)(b + 1) * block_bytes - SYM_TAIL;                 // first byte of the tail (blocks in front of the last are full)
+        const uint8_t* o = out + tb + (uint64_t)t * 64u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) { const uint4 v = ld_u128(o + j * 16u); d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w; }
+        if (what == 2u) {
+            const uint16_t* r = refs + tb + (uint64_t)t * 64u;
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) { const uint4 v = ld_u128(reinterpret_cast<const uint8_t*>(r + j * 8u)); rr[4 * j] = v.x; rr[4 * j + 1] = v.y; rr[4 * j + 2] = v.z; rr[4 * j + 3] = v.w; }
+        }
+    };
+    uint32_t what = wants(0);
+    fetch(0, what);
+    for (uint32_t k = 0; k + 1 < nblocks; ++k) {
+        // the block in hand, out of the registers
+        uint32_t c[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) c[j] = d[j];
+        uint32_t any = 0;
+        if (what == 2u) {
+#pragma unroll
+            for (uint32_t j = 0; j < 32; ++j) any |= rr[j];
+        }
+        uint32_t q[32];
+#pragma unroll
+        for (uint32_t j = 0; j < 32; ++j) q[j] = rr[j];
+        const uint32_t what_now = what;
+        // .. and the next one on its way
+        what = wants(k + 1);
+        fetch(k + 1, what);
+        if (what_now == 2u && any) {
+#pragma unroll
+            for (uint32_t m = 0; m < 16; ++m) {
+                const uint32_t a = q[2 * m], b = q[2 * m + 1];
+                if (!(a | b)) continue;
+                const uint32_t r0 = a & 0xffffu;
+                if (r0 >= 4u && a == r0 * 0x10001u - 0x10000u && b == a - 0x20002u) c[m] = lds_ld_u32(prev + (SYM_TAIL - r0));
+                else if (r0 && a == r0 * 0x10001u && b == a) c[m] = (uint32_t)prev[SYM_TAIL - r0] * 0x01010101u;
+                else {
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t rf = ((j < 2 ? a : b) >> (16u * (j & 1u))) & 0xffffu;
+                        if (rf) c[m] = (c[m] & ~(0xffu << (8u * j))) | ((uint32_t)prev[SYM_TAIL - rf] << (8u * j));
+                    }
+                }
+            }
+            const uint64_t tb = (uint64_t)(k + 1) * block_bytes - SYM_TAIL;
+            uint8_t* o = out + tb + (uint64_t)t * 64u;
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) st_u128(o + j * 16u, make_uint4(c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]));
+        }
+        if (what_now && !is_raw(k + 1)) {
+#pragma unroll
+            for (uint32_t j = 0; j < 4; ++j) {
+                const v4u v = {c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]};
+                *reinterpret_cast<SQY_LDS v4u*>(cur + t * 64u + j * 16u) = v;
+            }
+        }
+        __syncthreads();
+        SQY_LDS uint8_t* sw = prev; prev = cur; cur = sw;
+    }
+}
+
+// everything in front of the tails: a byte that carries a reference takes the byte out of the final tail in front of its block
+__global__ __launch_bounds__(256)
+void lz4_linked_resolve_bodies_kernel(const uint4* __restrict__ blk, uint32_t nblocks, uint8_t* __restrict__ out, const uint16_t* __restrict__ refs,
+                                      uint64_t out_bytes, uint64_t block_bytes, uint32_t pieces_per_block)
+{
+    const uint32_t k = 1u + blockIdx.x / pieces_per_block, piece = blockIdx.x % pieces_per_block;
+    if (k >= nblocks || (blk[k].z >> 31)) return;
+    const uint64_t base = (uint64_t)k * block_bytes;
+    const uint64_t n = out_bytes - base < block_bytes ? out_bytes - base : block_bytes;
+    // (the tail of every block but the last is final already)
+    const uint64_t body = k + 1 < nblocks ? n - SYM_TAIL : n;
+    const uint64_t nvec = body / 16u;
+    for (uint64_t v = (uint64_t)piece * 256u + threadIdx.x; v < nvec; v += (uint64_t)pieces_per_block * 256u) {
+        const uint4 ra = ld_u128(reinterpret_cast<const uint8_t*>(refs + base + v * 16u)), rb = ld_u128(reinterpret_cast<const uint8_t*>(refs + base + v * 16u + 8u));
+        if (!(ra.x | ra.y | ra.z | ra.w | rb.x | rb.y | rb.z | rb.w)) continue;
+        const uint32_t rr[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+        const uint4 dv = ld_u128(out + base + v * 16u);
+        uint32_t d[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+        for (uint32_t j = 0; j < 16; ++j) {
+            const uint32_t rf = (rr[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+            if (rf) {
+                const uint32_t b = out[base - rf];
+                d[j >> 2] = (d[j >> 2] & ~(0xffu << (8u * (j & 3u)))) | (b << (8u * (j & 3u)));
+            }
+        }
+        st_u128(out + base + v * 16u, make_uint4(d[0], d[1], d[2], d[3]));
+    }
+    if (piece == 0) {
+        for (uint64_t i = nvec * 16u + threadIdx.x; i < body; i += 256u) {
+            const uint32_t rf = refs[base + i];
+            if (rf) out[base + i] = out[base - rf];
+        }
+    }
+}
+
 // inverse bitswap1 (bitplane_reorder_scalar.hpp:81-116): one thread per group of W voxels
 template <typename T>
 __global__ __launch_bounds__(256)
@@ -4557,6 +5018,32 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
         e = hipStreamWaitEvent(stream, join, 0);
         if (e != hipSuccess) return e;
     }
+    return hipGetLastError();
+}
+
+// ONE block-linked frame, block-parallel (see lz4_blocks_decode_sym_kernel): blk = the frame's block list (lz4_frame_index), refs =
+// out_bytes 16-bit words of scratch.  *errflag != 0 afterwards: the stream is not a frame of full blocks, or is damaged -- decode it
+// again with the one-wavefront walk, whose result and error codes count.
+bool lz4_linked_decode_parallel_possible(uint32_t nblocks, uint64_t out_bytes, uint64_t block_bytes)
+{
+    return nblocks >= 3 && nblocks <= 32768u && block_bytes >= SYM_TAIL && block_bytes % 1024u == 0 && block_bytes <= (4u << 20) &&
+           out_bytes > (uint64_t)(nblocks - 1) * block_bytes && out_bytes <= (uint64_t)nblocks * block_bytes;
+}
+
+hipError_t launch_lz4_linked_decode_parallel(const uint8_t* in, const void* blk, uint32_t nblocks, uint8_t* out, uint16_t* refs, uint64_t out_bytes,
+                                             uint64_t block_bytes, uint32_t* errflag, hipStream_t stream)
+{
+    if (!lz4_linked_decode_parallel_possible(nblocks, out_bytes, block_bytes) || !refs) return hipErrorInvalidValue;
+    // (per call: the attribute belongs to the current device's copy of the kernel)
+    const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_linked_resolve_tails_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SYM_TAIL);
+    if (attr != hipSuccess) return attr;
+    const uint32_t slices = (uint32_t)((block_bytes + DEC_COPY_SLICE - 1) / DEC_COPY_SLICE);
+    hipLaunchKernelGGL(lz4_blocks_decode_sym_kernel, dim3(nblocks), dim3(64), 0, stream, in, (const uint4*)blk, out, refs, out_bytes, block_bytes, errflag);
+    hipLaunchKernelGGL(lz4_linked_stored_copy_kernel, dim3(nblocks * slices), dim3(256), 0, stream, in, (const uint4*)blk, out, out_bytes, block_bytes, slices, errflag);
+    hipLaunchKernelGGL(lz4_linked_resolve_tails_kernel, dim3(1), dim3(1024), 2 * SYM_TAIL, stream, (const uint4*)blk, nblocks, out, (const uint16_t*)refs, out_bytes, block_bytes);
+    const uint32_t pieces = 16;
+    hipLaunchKernelGGL(lz4_linked_resolve_bodies_kernel, dim3((nblocks - 1) * pieces), dim3(256), 0, stream, (const uint4*)blk, nblocks, out, (const uint16_t*)refs,
+                       out_bytes, block_bytes, pieces);
     return hipGetLastError();
 }
 

@@ -327,3 +327,83 @@ def test_frame_shuffle_decode_with_equal_metrics(sqy, oracle):
     assert rc == 0
     assert np.array_equal(back, oracle.pipeline_decode(blob))
     assert np.array_equal(back, vol)
+
+
+# ---- ONE block-linked frame decoded block-parallel (round 4) ---------------------------------------------------------------------
+# The serial layout's frame was decoded by one wavefront in rounds 2-3.  Now every block is decoded at once with the history in front of
+# it as an unknown (a 16-bit reference per byte), the last 64 KiB of every block are resolved in order, everything else at once
+# (sqy_kernels.hip: lz4_blocks_decode_sym_kernel).  Streams chosen so that references are copied around inside a block, cross several
+# block borders, reach 64 KiB back, come out of matches longer than their offset, and so that stored blocks sit between compressed ones.
+def _linked_streams(n, seed):
+    rng = np.random.default_rng(seed)
+    B = 256 << 10
+    yield "zeros", np.zeros(n, np.uint8)                                       # every byte of every block refers to the byte in front of it
+    yield "period7", np.tile(np.arange(7, dtype=np.uint8), n // 7 + 1)[:n]
+    p = np.tile(rng.integers(0, 256, 60001, dtype=np.uint8), n // 60001 + 1)[:n]
+    yield "period60001", p                                                     # every match reaches ~59 KiB back: far sources, across borders
+    a = np.zeros(n, np.uint8); idx = rng.integers(0, n, n // 50); a[idx] = rng.integers(1, 256, idx.size)
+    yield "sparse", a
+    yield "runs", np.repeat(rng.integers(0, 4, n // 64 + 1, dtype=np.uint8), 64)[:n]
+    d = rng.integers(0, 256, n, dtype=np.uint8)
+    for i in range(0, n, 2 * B):
+        d[i:i + B] = 0
+    yield "rawmix", d                                                          # stored and compressed blocks take turns
+    c = rng.integers(0, 256, n, dtype=np.uint8)
+    for i in range(66000, n - 300, 66000):
+        c[i:i + 300] = c[i - 65000:i - 65000 + 300]
+    yield "farrep", c
+    e = rng.integers(0, 256, n, dtype=np.uint8)                                # a block's first bytes copied on and on inside the block:
+    for b0 in range(B, n - B, B):                                              # references that travel through many matches
+        e[b0:b0 + 500] = e[b0 - 700:b0 - 200]
+        for j in range(1, 200):
+            e[b0 + j * 1000:b0 + j * 1000 + 400] = e[b0 + (j - 1) * 1000 + 50:b0 + (j - 1) * 1000 + 450]
+    yield "relay", e
+    yield "planes", np.ascontiguousarray(sqy_oracle_planes(synth.stack((12, 512, 512)))).view(np.uint8).reshape(-1)[:n]
+    yield "words", rng.integers(0, 256, (50, 12), dtype=np.uint8)[rng.integers(0, 50, n // 12 + 1)].reshape(-1)[:n]
+
+
+def sqy_oracle_planes(vol):
+    from oracle import sqy_oracle
+    return sqy_oracle.bitswap1_encode_planes(vol.reshape(-1))
+
+
+@pytest.mark.parametrize("cfg", ["", "blocksize_kb=64", "blocksize_kb=1024"])
+@pytest.mark.parametrize("name", [s[0] for s in _linked_streams(1 << 20, 0)])
+def test_serial_layout_decodes_block_parallel(sqy, oracle, monkeypatch, name, cfg):
+    n = 20 * (256 << 10) + 4567 if cfg != "blocksize_kb=1024" else 5 * (1 << 20) + 999
+    data = dict(_linked_streams(n, 31))[name]
+    vol = data.reshape(1, 1, -1)
+    pipe = "lz4(%s)" % cfg if cfg else "lz4"
+    blob = oracle.pipeline_encode(pipe, vol, nthreads=1)
+    sqy.profile_reset(); sqy.profile_enable(True)
+    rc, back = sqy.decode(blob)
+    sqy.profile_enable(False)
+    names = set(sqy.profile_get().keys())
+    assert rc == 0 and np.array_equal(back.reshape(-1), data), (name, cfg)
+    assert "lz4_linked_decode" in names and "lz4_frames_decode" not in names, names   # the block-parallel path, no fall-back
+    monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")                                  # the one-wavefront walk agrees
+    rc, back2 = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back2.reshape(-1), data)
+
+
+def test_serial_layout_damaged_streams_fall_back_to_the_walk(sqy, oracle, monkeypatch):
+    """damage inside a block, a block that does not decode to a full block, a cut stream: the block-parallel decode raises its flag and the
+    one-wavefront walk gives the verdict -- the same return code and bytes as with the block-parallel path switched off"""
+    rng = np.random.default_rng(3)
+    n = 12 * (256 << 10) + 100
+    a = np.zeros(n, np.uint8); idx = rng.integers(0, n, n // 30); a[idx] = rng.integers(1, 256, idx.size)
+    vol = a.reshape(1, 1, -1)
+    blob = oracle.pipeline_encode("lz4", vol, nthreads=1)
+    h = oracle.header_unpack(blob)
+    cases = []
+    for at in (h["size"] + 200, h["size"] + (len(blob) - h["size"]) // 2, len(blob) - 300):
+        b = bytearray(blob); b[at:at + 40] = bytes([0xF7] * 40); cases.append(bytes(b))
+    cases.append(blob[:len(blob) - 9])
+    for bad in cases:
+        monkeypatch.delenv("SQY_NO_BLOCK_PARALLEL", raising=False)
+        rc1, back1 = sqy.decode(bad)
+        monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")
+        rc2, back2 = sqy.decode(bad)
+        assert rc1 == rc2
+        if rc1 == 0:
+            assert np.array_equal(back1, back2)
