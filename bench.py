@@ -596,6 +596,20 @@ def main():
                              "what": "SQYAMD_PipelineEncode_UI16_Device, nthreads = 1 (ONE block-linked LZ4 frame, lz4_utils.hpp:99-173), one call at a time; "
                                      "blocks parsed block-parallel from verified table guesses (DESIGN.md section 3)",
                              "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in sqeazy_amd.profile_get().items()}}
+            # .. and back: the decode of that one frame (every block at once with the history as an unknown, DESIGN.md section 5 "decode")
+            import ctypes
+            back = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            dfn = sqeazy_amd.lib().SQYAMD_Decode_UI16_Device
+            dl = []
+            for _ in range(3):
+                tl = time.perf_counter()
+                drc = dfn(ctypes.c_void_p(outs[0][0].data_ptr()), ctypes.c_long(sn), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nbytes), None)
+                torch.cuda.synchronize()
+                dl.append((time.perf_counter() - tl) * 1e3)
+            serial_layout["decode"] = {"ms": round(min(dl[1:]), 4), "value": round(nbytes / (min(dl[1:]) / 1e3) / 1e9, 1), "unit": "GB/s", "rc": int(drc),
+                                       "round_trip_equal": bool((back.view(torch.uint16).reshape(shape) == vol).all().item()),
+                                       "what": "SQYAMD_Decode_UI16_Device on that blob"}
+            del back
             with open(os.path.join(ROOT, "tests", "golden", "headline.json")) as f:
                 for g in json.load(f)["stacks"]:
                     if tuple(g["shape_zyx"]) == tuple(shape) and g["z_offset"] == 0 and g["z_total"] == world * shape[0] and "serial" in g:
