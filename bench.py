@@ -152,8 +152,34 @@ def host_abi(vol_host, shape):
         if rc:
             raise RuntimeError("SQY_PipelineEncode_UI16 returned %d" % rc)
         best = dt if best is None else min(best, dt)
-    return {"value": round(vol_host.nbytes / best / 1e9, 3), "unit": "GB/s", "ms_per_call": round(best * 1e3, 2),
-            "entry_point": "SQY_PipelineEncode_UI16 (host pointers: %.2f GB up, kernels, %.2f GB down), best of 4" % (vol_host.nbytes / 1e9, n.value / 1e9)}
+    res = {"value": round(vol_host.nbytes / best / 1e9, 3), "unit": "GB/s", "ms_per_call": round(best * 1e3, 2),
+           "entry_point": "SQY_PipelineEncode_UI16 (host pointers: %.2f GB up, kernels, %.2f GB down), best of 4" % (vol_host.nbytes / 1e9, n.value / 1e9)}
+    # what a caller of the reference gets who changes nothing: nthreads = 1 (one block-linked frame) and SQY_Decode_UI16 of that blob
+    try:
+        best1 = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = L.SQY_PipelineEncode_UI16(PIPELINE.encode(), ctypes.c_void_p(vol_host.ctypes.data), shp, 3, ctypes.c_void_p(dst.ctypes.data), ctypes.byref(n), 1)
+            dt = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError("SQY_PipelineEncode_UI16(nthreads = 1) returned %d" % rc)
+            best1 = dt if best1 is None else min(best1, dt)
+        back = np.empty_like(vol_host)
+        bestd = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            rc = L.SQY_Decode_UI16(ctypes.c_void_p(dst.ctypes.data), ctypes.c_long(n.value), ctypes.c_void_p(back.ctypes.data), ctypes.c_int(1))
+            dt = time.perf_counter() - t0
+            if rc:
+                raise RuntimeError("SQY_Decode_UI16 returned %d" % rc)
+            bestd = dt if bestd is None else min(bestd, dt)
+        res["nthreads_1"] = {"encode_value": round(vol_host.nbytes / best1 / 1e9, 3), "encode_ms": round(best1 * 1e3, 2),
+                             "decode_value": round(vol_host.nbytes / bestd / 1e9, 3), "decode_ms": round(bestd * 1e3, 2), "unit": "GB/s",
+                             "round_trip_equal": bool(np.array_equal(back, vol_host)),
+                             "what": "SQY_PipelineEncode_UI16(.., nthreads = 1) and SQY_Decode_UI16 of its blob, host pointers, best of 3"}
+    except Exception as e:   # reported, never required
+        res["nthreads_1"] = {"error": repr(e)}
+    return res
 
 
 def secondary_configs(dev):
@@ -597,7 +623,6 @@ def main():
                                      "blocks parsed block-parallel from verified table guesses (DESIGN.md section 3)",
                              "kernels_ms": {k: round(v[0] / max(v[1], 1), 4) for k, v in sqeazy_amd.profile_get().items()}}
             # .. and back: the decode of that one frame (every block at once with the history as an unknown, DESIGN.md section 5 "decode")
-            import ctypes
             back = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             dfn = sqeazy_amd.lib().SQYAMD_Decode_UI16_Device
             dl = []
