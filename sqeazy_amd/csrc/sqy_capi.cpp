@@ -126,6 +126,7 @@ struct DevBuf {
         const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
         if (hipMalloc(&p, want) != hipSuccess) {
             std::fprintf(stderr, "[sqeazy]\t unable to allocate %zu bytes of HBM workspace\n", want);
+            (void)hipGetLastError();          // (not left behind for the launch checks of a caller that carries on without this buffer)
             p = nullptr;
             return 1;
         }
@@ -862,7 +863,9 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     const bool spec_off = std::getenv("SQY_NO_BLOCK_PARALLEL") != nullptr;
                     uint64_t warmup = 65536;
                     if (const char* wv = std::getenv("SQY_BLOCK_PARALLEL_WARMUP")) warmup = std::strtoull(wv, nullptr, 10);
-                    if (!spec_off && longest >= 3 && nframes < 1024) {
+                    const uint64_t list_bytes = nblocks * sizeof(uint32_t);
+                    // (without room for the tables -- 32 KiB per block -- the walk, which needs none)
+                    if (!spec_off && longest >= 3 && nframes < 1024 && !ws->spec.ensure(nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t) + 3 * list_bytes)) {
                         std::vector<uint32_t> wfirst(nblocks), wlast(nblocks), ok(nblocks);
                         for (uint64_t f = 0; f < nframes; ++f)
                             for (uint32_t k = plan.frame_first[f]; k < plan.frame_first[f + 1]; ++k) {
@@ -871,8 +874,6 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                 while (j > plan.frame_first[f] && have < warmup) { --j; have += plan.blocks[j].n; }
                                 wfirst[k] = j; wlast[k] = (uint32_t)k;
                             }
-                        const uint64_t list_bytes = nblocks * sizeof(uint32_t);
-                        if (ws->spec.ensure(nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t) + 3 * list_bytes)) return 1;
                         sqy::Lz4SpecArgs sa;
                         sa.tables = static_cast<uint32_t*>(ws->spec.p);
                         uint32_t* d_wfirst = sa.tables + nblocks * sqy::kLz4SpecTableWords;
@@ -1280,16 +1281,18 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 // ONE block-linked frame (nthreads = 1 on the encoder's side): every block at once with the history as an unknown, the
                 // references resolved afterwards (sqy_kernels.hip: lz4_blocks_decode_sym_kernel).  A stream that is not a frame of
                 // full blocks, or is damaged, raises the flag: the one-wavefront walk below then decides, as in rounds 2-3.
-                if (nframes == 1 && !std::getenv("SQY_NO_BLOCK_PARALLEL") && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes)) {
-                    if (ws->spec.ensure(total * sizeof(uint16_t))) return 1;
+                if (nframes == 1 && !std::getenv("SQY_NO_BLOCK_PARALLEL") && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes) &&
+                    !ws->spec.ensure(total * sizeof(uint16_t))) {                      // (no room for the references: the walk needs none)
+                    hipError_t le;
                     {
                         ProfScope ps("lz4_linked_decode", stream, pend);
-                        SQY_HIP(sqy::launch_lz4_linked_decode_parallel(cur, blk, hc[1], out, static_cast<uint16_t*>(ws->spec.p), total, block_bytes,
-                                                                       counts + 4, stream));
+                        le = sqy::launch_lz4_linked_decode_parallel(cur, blk, hc[1], out, static_cast<uint16_t*>(ws->spec.p), total, block_bytes,
+                                                                    counts + 4, stream);
                     }
+                    if (le != hipSuccess) (void)hipGetLastError();                    // (e.g. no 128 KiB of LDS for the tails: the walk below)
                     SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
                     SQY_HIP(hipStreamSynchronize(stream));
-                    decoded = bad == 0;
+                    decoded = le == hipSuccess && bad == 0;
                     if (!decoded) SQY_HIP(hipMemsetAsync(counts + 4, 0, sizeof(uint32_t), stream));
                 }
                 if (!decoded) {
