@@ -1282,12 +1282,14 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 // references resolved afterwards (sqy_kernels.hip: lz4_blocks_decode_sym_kernel).  A stream that is not a frame of
                 // full blocks, or is damaged, raises the flag: the one-wavefront walk below then decides, as in rounds 2-3.
                 if (nframes == 1 && !std::getenv("SQY_NO_BLOCK_PARALLEL") && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes) &&
-                    !ws->spec.ensure(total * sizeof(uint16_t))) {                      // (no room for the references: the walk needs none)
+                    !ws->spec.ensure(((total * sizeof(uint16_t) + 255) & ~(uint64_t)255) + sqy::lz4_linked_decode_scan_scratch_bytes(hc[1]))) {
+                    // (no room for the references: the walk needs none)
                     hipError_t le;
                     {
                         ProfScope ps("lz4_linked_decode", stream, pend);
+                        uint8_t* scan = static_cast<uint8_t*>(ws->spec.p) + ((total * sizeof(uint16_t) + 255) & ~(uint64_t)255);
                         le = sqy::launch_lz4_linked_decode_parallel(cur, blk, hc[1], out, static_cast<uint16_t*>(ws->spec.p), total, block_bytes,
-                                                                    counts + 4, stream);
+                                                                    counts + 4, stream, std::getenv("SQY_NO_TAIL_SCAN") ? nullptr : scan);
                     }
                     if (le != hipSuccess) (void)hipGetLastError();                    // (e.g. no 128 KiB of LDS for the tails: the walk below)
                     SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));

@@ -177,8 +177,11 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
 // references in `refs`, out_bytes words), the tails resolved in order by one workgroup, the rest at once.  blk: the frame's blocks
 // (launch_lz4_frame_index).  *errflag != 0 afterwards: not a frame of full blocks, or damaged -- the one-wavefront walk decides.
 bool lz4_linked_decode_parallel_possible(uint32_t nblocks, uint64_t out_bytes, uint64_t block_bytes);
+// scan_scratch (lz4_linked_decode_scan_scratch_bytes(nblocks) bytes, optional): long frames resolve their tails as a scan over ranges of
+// blocks instead of one walk
+uint64_t lz4_linked_decode_scan_scratch_bytes(uint32_t nblocks);
 hipError_t launch_lz4_linked_decode_parallel(const uint8_t* in, const void* blk, uint32_t nblocks, uint8_t* out, uint16_t* refs, uint64_t out_bytes,
-                                             uint64_t block_bytes, uint32_t* errflag, hipStream_t stream);
+                                             uint64_t block_bytes, uint32_t* errflag, hipStream_t stream, uint8_t* scan_scratch = nullptr);
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
                                     uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream = nullptr, hipEvent_t fork = nullptr,

@@ -3791,6 +3791,7 @@ void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* 
 // Every block but the last must decode to exactly block_bytes (LZ4F without autoFlush only cuts full blocks): checked; a stream that
 // is built differently, or is damaged, raises the flag and the host falls back to the one-wavefront walk (which owns the error codes).
 constexpr uint32_t SYM_RING = 16384, SYM_IN = 3072, SYM_TAIL = 65536;
+constexpr uint32_t SYM_RANGE = 64;                    // blocks per range of the tails' scan
 
 __global__ __launch_bounds__(256)
 void lz4_linked_stored_copy_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, uint8_t* __restrict__ out, uint64_t out_bytes,
@@ -4111,9 +4112,11 @@ void lz4_blocks_decode_sym_kernel(const uint8_t* __restrict__ in, const uint4* _
 // the tails, in order: one workgroup; LDS holds the resolved last 64 KiB of the block in front.  A thread owns 64 consecutive bytes;
 // the bytes and references of the NEXT block's tail are fetched while the block in hand is resolved.  Four bytes at a time: references
 // that count down (a straight copy out of the history: four consecutive bytes, one LDS read) or are all equal (a run), else byte by byte.
+// (range_len != 0: workgroup w walks the blocks [w * range_len, (w + 1) * range_len) only, and starts from the resolved tail in front of
+// its range, range_start + w * 64 KiB -- what lz4_linked_chain_ranges_kernel left there; workgroup 0 needs none)
 __global__ __launch_bounds__(1024)
 void lz4_linked_resolve_tails_kernel(const uint4* __restrict__ blk, uint32_t nblocks, uint8_t* __restrict__ out, const uint16_t* __restrict__ refs,
-                                     uint64_t out_bytes, uint64_t block_bytes)
+                                     uint64_t out_bytes, uint64_t block_bytes, uint32_t range_len, const uint8_t* __restrict__ range_start)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t tails_lds[];                 // 2 x 64 KiB
     SQY_LDS uint8_t* prev = (SQY_LDS uint8_t*)tails_lds;
@@ -4124,6 +4127,16 @@ void lz4_linked_resolve_tails_kernel(const uint4* __restrict__ blk, uint32_t nbl
         uint32_t bits = 0;
         for (uint32_t j = 0; j < 32u; ++j) { const uint32_t b = t * 32u + j; if (b < nblocks && (blk[b].z >> 31)) bits |= 1u << j; }
         rawbits[t] = bits;
+    }
+    const uint32_t k_first = range_len ? blockIdx.x * range_len : 0u;
+    const uint32_t k_end = range_len && (k_first + range_len) < nblocks - 1u ? k_first + range_len : nblocks - 1u;   // tails of [k_first, k_end)
+    if (k_first && range_start) {
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint4 v = ld_u128(range_start + (uint64_t)blockIdx.x * SYM_TAIL + t * 64u + j * 16u);
+            const v4u vv = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<SQY_LDS v4u*>(prev + t * 64u + j * 16u) = vv;
+        }
     }
     __syncthreads();
     auto is_raw = [&](uint32_t b) -> bool { return ((rawbits[b >> 5] >> (b & 31u)) & 1u) != 0u; };
@@ -4147,9 +4160,9 @@ void lz4_linked_resolve_tails_kernel(const uint4* __restrict__ blk, uint32_t nbl
             for (uint32_t j = 0; j < 8; ++j) { const uint4 v = ld_u128(reinterpret_cast<const uint8_t*>(r + j * 8u)); rr[4 * j] = v.x; rr[4 * j + 1] = v.y; rr[4 * j + 2] = v.z; rr[4 * j + 3] = v.w; }
         }
     };
-    uint32_t what = wants(0);
-    fetch(0, what);
-    for (uint32_t k = 0; k + 1 < nblocks; ++k) {
+    uint32_t what = k_first < k_end ? wants(k_first) : 0u;
+    fetch(k_first, what);
+    for (uint32_t k = k_first; k < k_end; ++k) {
         // the block in hand, out of the registers
         uint32_t c[16];
 #pragma unroll
@@ -4164,7 +4177,7 @@ void lz4_linked_resolve_tails_kernel(const uint4* __restrict__ blk, uint32_t nbl
         for (uint32_t j = 0; j < 32; ++j) q[j] = rr[j];
         const uint32_t what_now = what;
         // .. and the next one on its way
-        what = wants(k + 1);
+        what = k + 1 < k_end ? wants(k + 1) : 0u;
         fetch(k + 1, what);
         if (what_now == 2u && any) {
 #pragma unroll
@@ -4193,6 +4206,117 @@ void lz4_linked_resolve_tails_kernel(const uint4* __restrict__ blk, uint32_t nbl
                 const v4u v = {c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]};
                 *reinterpret_cast<SQY_LDS v4u*>(cur + t * 64u + j * 16u) = v;
             }
+        }
+        __syncthreads();
+        SQY_LDS uint8_t* sw = prev; prev = cur; cur = sw;
+    }
+}
+
+// The walk over the tails as a scan (long frames).  What block k does to a tail is a map from the tail in front of it to its own
+// (byte i = a literal, or the byte at distance d of the tail in front); maps compose.  So the blocks are cut into ranges:
+//   lz4_linked_compose_tails_kernel, one workgroup per range, all ranges at once: composes the maps of the range's blocks, from the
+//     identity, in LDS -- a symbolic tail: per byte a 16-bit word that is a literal or a distance into the tail IN FRONT OF THE RANGE,
+//     and a bit that says which (128 + 8 KiB);
+//   lz4_linked_chain_ranges_kernel, one workgroup: applies the composed maps in order -- the true tail in front of every range;
+//   lz4_linked_resolve_tails_kernel with range_len: every range walks its blocks from its true start, all ranges at once.
+// n / W + W steps in a row instead of n.
+constexpr uint32_t SYM_MAP_BYTES = 2 * SYM_TAIL + SYM_TAIL / 8;                         // a composed map in memory: 64 Ki words, 64 Ki bits
+
+__global__ __launch_bounds__(1024)
+void lz4_linked_compose_tails_kernel(const uint4* __restrict__ blk, uint32_t nblocks, const uint8_t* __restrict__ out, const uint16_t* __restrict__ refs,
+                                     uint64_t block_bytes, uint32_t range_len, uint8_t* __restrict__ maps)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t compose_lds[];
+    SQY_LDS uint16_t* sv = (SQY_LDS uint16_t*)compose_lds;                              // word i of the symbolic tail
+    SQY_LDS uint32_t* isref = (SQY_LDS uint32_t*)((SQY_LDS uint8_t*)compose_lds + 2 * SYM_TAIL);   // bit i: word i is a distance, not a literal
+    const uint32_t t = threadIdx.x;
+    const uint32_t k_first = blockIdx.x * range_len;
+    const uint32_t k_end = (k_first + range_len) < nblocks - 1u ? k_first + range_len : nblocks - 1u;
+    // the identity: byte i of the tail in front of the range is itself, SYM_TAIL - i in front of the range's first byte
+    for (uint32_t j = 0; j < 64u; ++j) sv[t * 64u + j] = (uint16_t)(SYM_TAIL - (t * 64u + j));     // (word 0: 65536 -> 0; no reference can name it, distances stop at 65535)
+    isref[2u * t] = 0xffffffffu; isref[2u * t + 1u] = 0xffffffffu;
+    __syncthreads();
+    for (uint32_t k = k_first; k < k_end; ++k) {
+        const uint64_t tb = (uint64_t)(k + 1) * block_bytes - SYM_TAIL;
+        const uint8_t* o = out + tb + (uint64_t)t * 64u;
+        const bool raw = (blk[k].z >> 31) != 0u;
+        uint32_t d[16], nv[32], nb[2] = {0u, 0u};
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) { const uint4 v = ld_u128(o + j * 16u); d[4 * j] = v.x; d[4 * j + 1] = v.y; d[4 * j + 2] = v.z; d[4 * j + 3] = v.w; }
+        if (raw || k == 0) {
+#pragma unroll
+            for (uint32_t j = 0; j < 32; ++j) {
+                const uint32_t b0 = (d[j >> 1] >> (16u * (j & 1u))) & 0xffu, b1 = (d[j >> 1] >> (16u * (j & 1u) + 8u)) & 0xffu;
+                nv[j] = b0 | (b1 << 16);
+            }
+        } else {
+            const uint16_t* r = refs + tb + (uint64_t)t * 64u;
+            uint32_t rr[32];
+#pragma unroll
+            for (uint32_t j = 0; j < 8; ++j) { const uint4 v = ld_u128(reinterpret_cast<const uint8_t*>(r + j * 8u)); rr[4 * j] = v.x; rr[4 * j + 1] = v.y; rr[4 * j + 2] = v.z; rr[4 * j + 3] = v.w; }
+#pragma unroll
+            for (uint32_t j = 0; j < 64; ++j) {
+                const uint32_t rf = (rr[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+                uint32_t w = (d[j >> 2] >> (8u * (j & 3u))) & 0xffu, f = 0u;
+                if (rf) {
+                    const uint32_t idx = SYM_TAIL - rf;
+                    w = sv[idx];
+                    f = (isref[idx >> 5] >> (idx & 31u)) & 1u;
+                }
+                if (j & 1u) nv[j >> 1] |= w << 16; else nv[j >> 1] = w;
+                nb[j >> 5] |= f << (j & 31u);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) {
+            const v4u v = {nv[4 * j], nv[4 * j + 1], nv[4 * j + 2], nv[4 * j + 3]};
+            *reinterpret_cast<SQY_LDS v4u*>(sv + t * 64u + j * 8u) = v;
+        }
+        isref[2u * t] = nb[0]; isref[2u * t + 1u] = nb[1];
+        __syncthreads();
+    }
+    uint8_t* m = maps + (uint64_t)blockIdx.x * SYM_MAP_BYTES;
+#pragma unroll
+    for (uint32_t j = 0; j < 8; ++j) {
+        const v4u v = *reinterpret_cast<const SQY_LDS v4u*>(sv + t * 64u + j * 8u);
+        st_u128(m + (uint64_t)t * 128u + j * 16u, make_uint4(v.x, v.y, v.z, v.w));
+    }
+    reinterpret_cast<uint32_t*>(m + 2 * SYM_TAIL)[2u * t] = isref[2u * t];
+    reinterpret_cast<uint32_t*>(m + 2 * SYM_TAIL)[2u * t + 1u] = isref[2u * t + 1u];
+}
+
+// starts[w] (64 KiB each) = the true tail in front of range w, for w = 1 .. nranges - 1 (nothing lies in front of range 0)
+__global__ __launch_bounds__(1024)
+void lz4_linked_chain_ranges_kernel(const uint8_t* __restrict__ maps, uint32_t nranges, uint8_t* __restrict__ starts)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t chain_lds[];                 // 2 x 64 KiB
+    SQY_LDS uint8_t* prev = (SQY_LDS uint8_t*)chain_lds;
+    SQY_LDS uint8_t* cur = (SQY_LDS uint8_t*)chain_lds + SYM_TAIL;
+    const uint32_t t = threadIdx.x;
+    for (uint32_t j = 0; j < 16u; ++j) reinterpret_cast<SQY_LDS uint32_t*>(prev)[t * 16u + j] = 0u;
+    __syncthreads();
+    for (uint32_t w = 0; w + 1 < nranges; ++w) {
+        const uint8_t* m = maps + (uint64_t)w * SYM_MAP_BYTES;
+        uint32_t wv[32];
+#pragma unroll
+        for (uint32_t j = 0; j < 8; ++j) { const uint4 v = ld_u128(m + (uint64_t)t * 128u + j * 16u); wv[4 * j] = v.x; wv[4 * j + 1] = v.y; wv[4 * j + 2] = v.z; wv[4 * j + 3] = v.w; }
+        const uint32_t f0 = reinterpret_cast<const uint32_t*>(m + 2 * SYM_TAIL)[2u * t], f1 = reinterpret_cast<const uint32_t*>(m + 2 * SYM_TAIL)[2u * t + 1u];
+        uint32_t c[16];
+#pragma unroll
+        for (uint32_t j = 0; j < 64; ++j) {
+            const uint32_t x = (wv[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
+            const uint32_t f = ((j < 32u ? f0 : f1) >> (j & 31u)) & 1u;
+            // (distance 0 -- the identity's word 0, which nothing can name -- never comes out of a composed map of a real block)
+            const uint32_t b = f ? (uint32_t)prev[(SYM_TAIL - x) & (SYM_TAIL - 1u)] : (x & 0xffu);
+            if (j & 3u) c[j >> 2] |= b << (8u * (j & 3u)); else c[j >> 2] = b;
+        }
+        uint8_t* o = starts + (uint64_t)(w + 1) * SYM_TAIL + (uint64_t)t * 64u;
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            st_u128(o + j * 16u, make_uint4(c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]));
+            const v4u v = {c[4 * j], c[4 * j + 1], c[4 * j + 2], c[4 * j + 3]};
+            *reinterpret_cast<SQY_LDS v4u*>(cur + t * 64u + j * 16u) = v;
         }
         __syncthreads();
         SQY_LDS uint8_t* sw = prev; prev = cur; cur = sw;
@@ -5030,8 +5154,14 @@ bool lz4_linked_decode_parallel_possible(uint32_t nblocks, uint64_t out_bytes, u
            out_bytes > (uint64_t)(nblocks - 1) * block_bytes && out_bytes <= (uint64_t)nblocks * block_bytes;
 }
 
+uint64_t lz4_linked_decode_scan_scratch_bytes(uint32_t nblocks)
+{
+    const uint64_t nranges = ((uint64_t)nblocks + SYM_RANGE - 2u) / SYM_RANGE;
+    return nranges * ((uint64_t)SYM_MAP_BYTES + SYM_TAIL);
+}
+
 hipError_t launch_lz4_linked_decode_parallel(const uint8_t* in, const void* blk, uint32_t nblocks, uint8_t* out, uint16_t* refs, uint64_t out_bytes,
-                                             uint64_t block_bytes, uint32_t* errflag, hipStream_t stream)
+                                             uint64_t block_bytes, uint32_t* errflag, hipStream_t stream, uint8_t* scan_scratch)
 {
     if (!lz4_linked_decode_parallel_possible(nblocks, out_bytes, block_bytes) || !refs) return hipErrorInvalidValue;
     // (per call: the attribute belongs to the current device's copy of the kernel)
@@ -5040,7 +5170,22 @@ hipError_t launch_lz4_linked_decode_parallel(const uint8_t* in, const void* blk,
     const uint32_t slices = (uint32_t)((block_bytes + DEC_COPY_SLICE - 1) / DEC_COPY_SLICE);
     hipLaunchKernelGGL(lz4_blocks_decode_sym_kernel, dim3(nblocks), dim3(64), 0, stream, in, (const uint4*)blk, out, refs, out_bytes, block_bytes, errflag);
     hipLaunchKernelGGL(lz4_linked_stored_copy_kernel, dim3(nblocks * slices), dim3(256), 0, stream, in, (const uint4*)blk, out, out_bytes, block_bytes, slices, errflag);
-    hipLaunchKernelGGL(lz4_linked_resolve_tails_kernel, dim3(1), dim3(1024), 2 * SYM_TAIL, stream, (const uint4*)blk, nblocks, out, (const uint16_t*)refs, out_bytes, block_bytes);
+    // the tails: one walk, or (long frames, scratch given) ranges of SYM_RANGE blocks composed at once, chained, and walked at once
+    const uint32_t nranges = (nblocks - 1u + SYM_RANGE - 1u) / SYM_RANGE;
+    if (scan_scratch && nranges >= 4u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_linked_compose_tails_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, SYM_MAP_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(lz4_linked_chain_ranges_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * SYM_TAIL);
+        if (e != hipSuccess) return e;
+        uint8_t* maps = scan_scratch;
+        uint8_t* starts = scan_scratch + (uint64_t)nranges * SYM_MAP_BYTES;
+        hipLaunchKernelGGL(lz4_linked_compose_tails_kernel, dim3(nranges), dim3(1024), SYM_MAP_BYTES, stream, (const uint4*)blk, nblocks, (const uint8_t*)out,
+                           (const uint16_t*)refs, block_bytes, SYM_RANGE, maps);
+        hipLaunchKernelGGL(lz4_linked_chain_ranges_kernel, dim3(1), dim3(1024), 2 * SYM_TAIL, stream, (const uint8_t*)maps, nranges, starts);
+        hipLaunchKernelGGL(lz4_linked_resolve_tails_kernel, dim3(nranges), dim3(1024), 2 * SYM_TAIL, stream, (const uint4*)blk, nblocks, out, (const uint16_t*)refs,
+                           out_bytes, block_bytes, SYM_RANGE, (const uint8_t*)starts);
+    } else
+        hipLaunchKernelGGL(lz4_linked_resolve_tails_kernel, dim3(1), dim3(1024), 2 * SYM_TAIL, stream, (const uint4*)blk, nblocks, out, (const uint16_t*)refs,
+                           out_bytes, block_bytes, 0u, (const uint8_t*)nullptr);
     const uint32_t pieces = 16;
     hipLaunchKernelGGL(lz4_linked_resolve_bodies_kernel, dim3((nblocks - 1) * pieces), dim3(256), 0, stream, (const uint4*)blk, nblocks, out, (const uint16_t*)refs,
                        out_bytes, block_bytes, pieces);

@@ -407,3 +407,33 @@ def test_serial_layout_damaged_streams_fall_back_to_the_walk(sqy, oracle, monkey
         assert rc1 == rc2
         if rc1 == 0:
             assert np.array_equal(back1, back2)
+
+
+@pytest.mark.parametrize("name", ["zeros", "period60001", "sparse", "rawmix", "relay", "planes", "runs"])
+def test_serial_layout_long_frames_resolve_their_tails_as_a_scan(sqy, oracle, monkeypatch, name):
+    """frames of a few hundred blocks: the tails are not walked by one workgroup but composed per range of 64 blocks, chained, and walked by
+    all ranges at once (lz4_linked_compose_tails_kernel ..); 64 KiB blocks so that a test-sized stream has 300 of them; the one walk
+    (SQY_NO_TAIL_SCAN) and the one-wavefront decode (SQY_NO_BLOCK_PARALLEL) agree"""
+    n = 300 * (64 << 10) + 777
+    if name == "planes":
+        data = np.ascontiguousarray(sqy_oracle_planes(synth.stack((40, 512, 512)))).view(np.uint8).reshape(-1)[:n]
+    elif name == "relay":
+        rng = np.random.default_rng(17)
+        B = 64 << 10
+        data = rng.integers(0, 256, n, dtype=np.uint8)
+        for b0 in range(B, n - B, B):                                          # every block relays a piece of the block in front of it
+            data[b0:b0 + 3000] = data[b0 - 3100:b0 - 100]
+            data[b0 + B - 5000:b0 + B - 2000] = data[b0 + 10:b0 + 3010]
+    else:
+        data = dict(_linked_streams(n, 77))[name]
+    vol = data.reshape(1, 1, -1)
+    blob = oracle.pipeline_encode("lz4(blocksize_kb=64)", vol, nthreads=1)
+    sqy.profile_reset(); sqy.profile_enable(True)
+    rc, back = sqy.decode(blob)
+    sqy.profile_enable(False)
+    names = set(sqy.profile_get().keys())
+    assert rc == 0 and np.array_equal(back.reshape(-1), data), name
+    assert "lz4_linked_decode" in names and "lz4_frames_decode" not in names, names
+    monkeypatch.setenv("SQY_NO_TAIL_SCAN", "1")
+    rc, back2 = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back2.reshape(-1), data)
