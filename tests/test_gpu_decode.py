@@ -437,3 +437,24 @@ def test_serial_layout_long_frames_resolve_their_tails_as_a_scan(sqy, oracle, mo
     monkeypatch.setenv("SQY_NO_TAIL_SCAN", "1")
     rc, back2 = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back2.reshape(-1), data)
+
+
+def test_serial_layout_frame_cut_into_uneven_blocks_falls_back(sqy, oracle):
+    """a valid block-linked frame whose blocks are NOT all full (another LZ4F writer that flushes early could produce it; sqeazy's encoders do
+    not): the block-parallel decode notices (a block does not decode to one block size), the one-wavefront walk decodes it"""
+    rng = np.random.default_rng(5)
+    sizes = [256 << 10, (256 << 10) - 1000, 256 << 10, 256 << 10, 12345]       # (the total still looks like four full blocks and a rest)
+    data = rng.integers(0, 256, sum(sizes), dtype=np.uint8)
+    payload = bytearray([0x04, 0x22, 0x4D, 0x18, 0x40, 0x50, 0x77])          # magic, FLG (v1, blocks linked), BD (256 KiB), HC
+    at = 0
+    for sz in sizes:
+        payload += int(sz | 0x80000000).to_bytes(4, "little") + data[at:at + sz].tobytes()   # stored blocks
+        at += sz
+    payload += bytes(4)
+    blob = oracle.header_pack(np.uint8, (1, 1, data.size), LZ4_NAME, len(payload)) + bytes(payload)
+    sqy.profile_reset(); sqy.profile_enable(True)
+    rc, back = sqy.decode(blob)
+    sqy.profile_enable(False)
+    names = set(sqy.profile_get().keys())
+    assert rc == 0 and np.array_equal(back.reshape(-1), data)
+    assert "lz4_linked_decode" in names and "lz4_frames_decode" in names, names      # tried, refused, walked
