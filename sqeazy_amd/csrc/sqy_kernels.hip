@@ -3168,12 +3168,15 @@ void lz4_frame_rank_kernel(const uint8_t* __restrict__ in, uint64_t n, const Fra
     }
 }
 
-// Serial walk (one lane chases the size fields): any layout, exact error codes.
+// Serial walk (the size fields are chased one after the other): any layout, exact error codes.  The wavefront's lanes all run the
+// same walk (uniform values, lane 0 stores); they part only behind a STORED block, where lane j looks at the place the (j+1)-th next
+// size field would be if the blocks that follow were stored blocks of the same size -- as in the noise planes of a block-linked frame,
+// runs of hundreds of them: the leading lanes that find exactly that field are that many blocks, taken in one step (round 4).
 __global__ __launch_bounds__(64)
 void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* __restrict__ blk, uint32_t* __restrict__ frame_first,
                             uint64_t max_blocks, uint32_t* __restrict__ counts)
 {
-    if (threadIdx.x != 0) return;
+    const uint32_t lane = threadIdx.x;
     // every step fetches 16 bytes at once: behind a block's data sit the end mark (or the next block's size) and --
     // after an end mark -- the next frame's 7 header bytes and its first block size: one dependent load per
     // single-block frame.
@@ -3198,7 +3201,7 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
         const bool block_checksum = (flg >> 4) & 1;
         // frame_first has max_blocks + 2 entries; a stream of block-less frames must not run past it
         if (nframes >= max_blocks) { err = 5; break; }
-        frame_first[nframes] = nblocks;
+        if (lane == 0) frame_first[nframes] = nblocks;
         uint32_t field = (w[1] >> 24) | (w[2] << 8);                    // bytes 7..10
         off += 7;
         uint32_t j = 0;
@@ -3208,10 +3211,22 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
             if (field == 0) break;                                      // end mark (a frame without blocks)
             const uint32_t sz = field & 0x7fffffffu;
             if (off + sz > n || nblocks >= max_blocks) { err = 4; break; }
-            blk[nblocks] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), field, j);
+            if (lane == 0) blk[nblocks] = make_uint4((uint32_t)off, (uint32_t)(off >> 32), field, j);
             ++nblocks; ++j;
             ncomp += !(field >> 31);
             off += sz + (block_checksum ? 4 : 0);
+            if ((field >> 31) && sz) {
+                // a run of stored blocks of this size?  lane j: the field at off + j * (4 + sz [+ 4]) must be this very field, its block inside the stream
+                const uint64_t step = 4ull + sz + (block_checksum ? 4 : 0);
+                const uint64_t pj = off + (uint64_t)lane * step;
+                const bool ok = pj + step <= n && ld_u32(in + pj) == field;
+                const uint64_t okm = ballot(ok);
+                uint32_t run = okm == ~0ull ? 64u : ctz64(~okm);
+                if ((uint64_t)run > max_blocks - nblocks) run = (uint32_t)(max_blocks - nblocks);
+                if (lane < run) { const uint64_t o = pj + 4; blk[nblocks + lane] = make_uint4((uint32_t)o, (uint32_t)(o >> 32), field, j + lane); }
+                nblocks += run; j += run;
+                off += (uint64_t)run * step;
+            }
             load16(off, w);                                             // next size field or end mark, and 12 bytes behind it
             field = w[0];
             if (field == 0 && off + 4 <= n) {                           // end mark: the 12 bytes behind it open the next frame
@@ -3224,8 +3239,10 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
         if (err) break;
         ++nframes;
     }
-    frame_first[nframes] = nblocks;
-    counts[0] = nframes; counts[1] = nblocks; counts[2] = err; counts[3] = ncomp;
+    if (lane == 0) {
+        frame_first[nframes] = nblocks;
+        counts[0] = nframes; counts[1] = nblocks; counts[2] = err; counts[3] = ncomp;
+    }
 }
 
 // One wavefront per frame; the last 64 KiB of decoded output live in an LDS ring so that match copies (which may
