@@ -906,8 +906,10 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                             if (std::getenv("SQY_BLOCK_PARALLEL_STATS")) {
                                 uint64_t nbad = 0;
                                 for (uint64_t r = 0; r < nruns; ++r) nbad += wlast[r] - wfirst[r] + 1;
-                                std::fprintf(stderr, "[sqeazy]\t lz4 block-parallel: round %llu, %llu of %llu blocks to parse again in %llu runs\n",
+                                std::fprintf(stderr, "[sqeazy]\t lz4 block-parallel: round %llu, %llu of %llu blocks to parse again in %llu runs",
                                              (unsigned long long)round, (unsigned long long)nbad, (unsigned long long)nblocks, (unsigned long long)nruns);
+                                for (uint64_t r = 0; r < nruns && r < 24; ++r) std::fprintf(stderr, "%s%u..%u", r ? ", " : ": blocks ", wfirst[r], wlast[r]);
+                                std::fprintf(stderr, "\n");
                             }
                             if (nruns == 0) break;
                             if (round > nblocks) {
