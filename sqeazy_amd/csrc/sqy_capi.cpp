@@ -1217,6 +1217,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
     const uint8_t* cur = d_src + h.size;
     uint64_t cur_bytes = h.payload_bytes;
     bool use_ping = true;
+    bool diff_in_place = false;            // the bit-plane inverse wrote into the volume itself; the diff3x3x1 inverse works there
     auto out_buf = [&](size_t stage_index, uint64_t bytes) -> uint8_t* {
         if (stage_index == 0) return static_cast<uint8_t*>(d_dst);               // the first stage's inverse produces the volume
         DevBuf& b = use_ping ? ws->ping : ws->pong;
@@ -1332,7 +1333,16 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                     // (odd sizes: the two stages one after the other; out16 is the quantiser's output buffer below)
                     if (si - 1 != 0) use_ping = !use_ping;                 // hand the buffer back to the quantiser stage
                 }
-                uint8_t* out = out_buf(si, stage_in_bytes);
+                // diff3x3x1 as the pipeline's first stage (16-bit, the usual geometry): its inverse can only change the leading columns of
+                // a row, so the planes are transposed straight into the volume and the inverse works there (round 4; before: into a
+                // work buffer, from which the inverse copied every untouched column -- 0.75 ms of a 2 GiB slab's 1.1)
+                uint8_t* out = nullptr;
+                if (si == 1 && pipe.stages[0].kind == StageKind::diff3x3x1 && e_in == 2 && h.shape.size() == 3 && n_in == n &&
+                    (reinterpret_cast<uintptr_t>(d_dst) & 15) == 0 && sqy::diff3x3x1_decode_chain_columns(h.shape[0], h.shape[1], h.shape[2], 2)) {
+                    out = static_cast<uint8_t*>(d_dst);
+                    diff_in_place = true;
+                } else
+                    out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 ProfScope ps("bitswap1_decode", stream, pend);
                 SQY_HIP(sqy::launch_bitswap1_decode(cur, out, n_in, e_in, stream));
@@ -1432,10 +1442,17 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 if (ws->lz4_scratch.ensure(sqy::diff3x3x1_decode_scratch_bytes(h.shape[2]))) return 1;
+                void* left_tmp = nullptr;
+                if (si == 0 && diff_in_place && cur == out) {              // the bit-plane inverse wrote the volume's own memory (above)
+                    DevBuf& tb = use_ping ? ws->ping : ws->pong;
+                    use_ping = !use_ping;
+                    if (tb.ensure(std::max<uint64_t>(stage_in_bytes, 16))) return 1;
+                    left_tmp = tb.p;
+                }
                 ProfScope ps("diff3x3x1_decode", stream, pend);
                 const bool side_ok = cx.ensure_side();
                 SQY_HIP(sqy::launch_diff3x3x1_decode(cur, out, h.shape[0], h.shape[1], h.shape[2], e_in, ws->lz4_scratch.p, stream, tail,
-                                                     side_ok ? cx.side : nullptr, cx.fork, cx.join));
+                                                     side_ok ? cx.side : nullptr, cx.fork, cx.join, left_tmp));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }

@@ -193,9 +193,13 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
 // one launch per frame over the columns the stage can touch (frame z needs the decoded frame z-1), the other columns one plain copy
 // -- on copy_stream next to the chain when that, fork and join are given.  (scratch: unused since round 3)
 uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X);
+// diff3x3x1_decode_chain_columns: how many leading columns of a row go through that chain in the usual 16-bit geometry (a multiple of 8;
+// 0: another geometry).  left_tmp != nullptr (that geometry, in == out, both 16-byte aligned): the volume is decoded where it lies --
+// the encoded chain columns are first copied to left_tmp (same indices, a buffer of the volume's size), nothing else moves
+uint64_t diff3x3x1_decode_chain_columns(uint64_t Z, uint64_t Y, uint64_t X, int elem_size);
 hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
                                    hipStream_t stream, bool schar = false, hipStream_t copy_stream = nullptr, hipEvent_t fork = nullptr,
-                                   hipEvent_t join = nullptr);
+                                   hipEvent_t join = nullptr, void* left_tmp = nullptr);
 hipError_t launch_quantiser_decode(const uint8_t* in, uint16_t* out, uint64_t len, const uint16_t* lut, hipStream_t stream);
 hipError_t launch_frame_scatter(const void* in, void* out, uint64_t Z, uint64_t frame_bytes, const uint64_t* map, hipStream_t stream);
 

@@ -5253,8 +5253,22 @@ hipError_t launch_bitswap1_decode(const void* in, void* out, uint64_t len, int e
 // scratch for the one-launch kernel: 256 strips x 2 edges x 2 frame parities x ceil(X / 3) words, and the abort word
 uint64_t diff3x3x1_decode_scratch_bytes(uint64_t X) { (void)X; return 0; }      // (the frame chain below needs none)
 
+// the usual geometry of the inverse (16-bit, every row's reach inside its row): the columns that go through the chain of launches --
+// the ones the stage can touch and their right-hand neighbour, whole 16-byte vectors; 0: another geometry
+uint64_t diff3x3x1_decode_chain_columns(uint64_t Z, uint64_t Y, uint64_t X, int elem_size)
+{
+    if (Z * Y * X == 0) return 0;
+    const uint64_t zlim = X < Z ? X : Z;
+    const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
+    const bool single = (noff == 1);
+    const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
+    if (!(elem_size == 2 && !single && hx + 2 <= X && Y <= 65535 && Z <= 65535 && X <= 0xffffffffull && X % 8 == 0)) return 0;
+    const uint64_t w = ((2 + hx) + 7) / 8 * 8;
+    return w > X ? X : w;
+}
+
 hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64_t Y, uint64_t X, int elem_size, void* scratch,
-                                   hipStream_t stream, bool schar, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join)
+                                   hipStream_t stream, bool schar, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join, void* left_tmp)
 {
     (void)scratch;
     const uint64_t length = Z * Y * X, frame = Y * X;
@@ -5263,6 +5277,9 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
     const uint64_t noff = (zlim >= 1 ? (zlim - 1) : 0) * (Y >= 2 ? (Y - 2) : 0);
     const int single = (noff == 1);
     const uint64_t hx = single ? 0 : (Z >= 2 ? Z - 2 : 0);
+    // left_tmp (in == out, the volume decoded where it lies): only promised for the geometry below
+    if (left_tmp && !(in == out && diff3x3x1_decode_chain_columns(Z, Y, X, elem_size) &&
+                      ((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(left_tmp)) & 15) == 0)) return hipErrorInvalidValue;
     // The usual geometry (16-bit, every row's reach inside its row): frame z needs the DECODED frame z-1 -- a chain of one launch
     // per frame, in stream order.  Only columns x < 1 + hx can change (hx from the depth of the stack): those go
     // through the chain (1 MiB per frame of a 2048 x 2048 x 256 slab: launch-bound, ~3.5 us each), everything to the right of
@@ -5273,10 +5290,22 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
         // so that the chain never reads what the copy writes
         uint64_t w = ((2 + hx) + 7) / 8 * 8;
         if (w > X) w = X;
+        uint32_t rpb = 1;
+        while (rpb < 16u && (w / 8u) * rpb * 2u <= 256u) rpb *= 2u;
+        const unsigned bx = (unsigned)((w / 8u + (256u / rpb) - 1u) / (256u / rpb));
+        const dim3 grid(bx, (unsigned)((Y + rpb - 1) / rpb), 1);
+        if (left_tmp) {
+            // decoded where it lies (in == out; round 4): nothing to the right of the chain's columns has to move at all.  The chain's
+            // strips read encoded rows of their neighbours' strips -- which those neighbours overwrite -- so the encoded LEFT columns go
+            // to left_tmp first (13 % of a 2048-wide slab) and the chain reads them there.
+            hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, dim3(grid.x, grid.y, (unsigned)Z), dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)left_tmp,
+                               (uint32_t)Y, (uint32_t)X, 0u, 0u, (uint32_t)X, (uint32_t)w, rpb, 0u, 0u);
+            in = left_tmp;
+        }
         hipStream_t cs = stream;
-        if (w < X && copy_stream && fork && join && hipEventRecord(fork, stream) == hipSuccess && hipStreamWaitEvent(copy_stream, fork, 0) == hipSuccess)
+        if (w < X && !left_tmp && copy_stream && fork && join && hipEventRecord(fork, stream) == hipSuccess && hipStreamWaitEvent(copy_stream, fork, 0) == hipSuccess)
             cs = copy_stream;                                                 // (the copy runs next to the chain)
-        if (w < X) {
+        if (w < X && !left_tmp) {
             // columns [w, X) of every frame: copy
             const uint64_t cols = X - w;
             uint32_t rpb = 1;
@@ -5285,10 +5314,6 @@ hipError_t launch_diff3x3x1_decode(const void* in, void* out, uint64_t Z, uint64
             hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, dim3(bx, (unsigned)((Y + rpb - 1) / rpb), (unsigned)Z), dim3(256), 0, cs,
                                (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X, 0u, 0u, (uint32_t)X, (uint32_t)X, rpb, 0u, (uint32_t)w);
         }
-        uint32_t rpb = 1;
-        while (rpb < 16u && (w / 8u) * rpb * 2u <= 256u) rpb *= 2u;
-        const unsigned bx = (unsigned)((w / 8u + (256u / rpb) - 1u) / (256u / rpb));
-        const dim3 grid(bx, (unsigned)((Y + rpb - 1) / rpb), 1);
         // frames that cannot change (z = 0, z >= zlim) in one launch each run, the others one by one
         hipLaunchKernelGGL(diff3x3x1_u16_rows_kernel<true>, grid, dim3(256), 0, stream, (const uint16_t*)in, (uint16_t*)out, (uint32_t)Y, (uint32_t)X,
                            (uint32_t)hx, (uint32_t)zlim, (uint32_t)X, (uint32_t)w, rpb, 0u, 0u);
