@@ -64,12 +64,12 @@ while time.time() - t0 < budget:
         z, y, x = min(z, 100), min(y, 100), min(x, 100)
     if "diff3x3x1" in pipe and rng.random() < 0.5:
         x = max(8, x - x % 8)                                   # the strip kernel's geometry
-    nth = 1 if rng.random() < 0.3 else 0
+    nth = 1 if rng.random() < float(os.environ.get("STRESS_SERIAL", "0.3")) else 0     # (the serial layout: block-parallel encode and decode since round 4)
     if dtype == np.uint16 and rng.random() < 0.35:
         # frames in place (and the holes in them): a 16-bit bitswap1 in front of a chunked lz4, whole tiles of 8192 voxels
         pipe = str(rng.choice(["bitswap1->lz4", "diff3x3x1->bitswap1->lz4", "bitswap1->lz4(blocksize_kb=64,framestep_kb=64)"]))
         y, x = max(64, y - y % 64), max(128, x - x % 128)
-        nth = 0
+        nth = 0 if rng.random() < 0.7 else nth
     vol = data((z, y, x), dtype, int(rng.integers(0, 10)))
     try:
         want = o.pipeline_encode(pipe, vol, nthreads=nth)
