@@ -2996,16 +2996,15 @@ __global__ __launch_bounds__(256)
 void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, FrameSlot* __restrict__ table, uint32_t mask,
                                  FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand)
 {
-    // thread t inspects start positions [16 t, 16 t + 16); it needs the bytes [16 t - 4, 16 t + 27).  Four such windows per thread and
+    // a thread inspects 16 start positions [base, base + 16); it needs the bytes [base - 4, base + 28).  Four such windows per thread and
     // step, all their loads issued before the first is looked at
-    const uint64_t nvec = (n + 15) / 16;
     const uint64_t stride = (uint64_t)gridDim.x * 256;
-    auto inspect = [&](uint64_t base, const uint32_t (&w)[9]) {
+    auto inspect = [&](uint64_t base, const uint32_t (&w)[9], uint32_t kmax) {
         // the magic's first TWO bytes (04 22) at one of the 16 positions?  The reject has to hold for whole wavefronts: a lone 04 sits in
         // one window of sixteen, i.e. in nearly every wavefront's 64 windows -- a test for that byte alone sends every wave through the
         // sixteen compares below.  Byte flags by the has-zero trick (never misses a zero byte, may flag a byte above one: fine for a
-        // reject).  (Measured: the scan stays at 2.6 TB/s either way -- its 16-byte loads start 4 bytes in front of a window and hit two
-        // sectors each; not pursued, 0.2 of a 1.9 ms decode.)
+        // reject).  (Round 3 measured: the scan stays at 2.6 TB/s either way -- its 16-byte loads started 4 bytes in front of a window and
+        // hit two sectors each; round 4 loads aligned vectors, below.)
         uint32_t pair = 0;
 #pragma unroll
         for (int i = 1; i <= 4; ++i) {
@@ -3016,6 +3015,7 @@ void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, Fra
         if (!(pair & 0x80808080u)) return;
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
+            if ((uint32_t)k >= kmax) break;                                // (only the window in front of the first aligned vector stops early)
             // little-endian window of 12 bytes starting at base + k: dwords d0 (bytes 0..3), d1 (4..7), d2 (8..11)
             const int i = 1 + (k >> 2), sh = 8 * (k & 3);
             const uint32_t d0 = sh ? (w[i] >> sh) | (w[i + 1] << (32 - sh)) : w[i];
@@ -3037,39 +3037,63 @@ void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, Fra
             }
         }
     };
-    for (uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t0 < nvec; t0 += 4 * stride) {
-        uint4 a[4], b[4];
-        uint32_t w0[4];
-        bool fast[4];
+    // Round 4: every lane loads ONE aligned 16-byte vector per window; the 12 bytes behind it are the first dwords of the next lane's
+    // vector and the 4 bytes in front of it the last dword of the lane before (ds_bpermute, no memory) -- only a wave's first and last
+    // lane fetch those themselves.  (Before: 36 bytes loaded per 16 inspected, at the payload's arbitrary alignment: 2.6 TB/s.)
+    // Start positions [0, A) in front of the first aligned vector and the ragged end go through the byte-wise window.
+    const uint64_t A = (16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u;
+    const uint64_t nal = n > A + 32 ? (n - A - 16) / 16 : 0;            // aligned vectors whose window [base - 4, base + 28) lies inside the stream (base >= 4 checked below)
+    auto slow_window = [&](uint64_t base, uint32_t kmax) {
+        uint32_t w[9];
+        for (int i = 0; i < 9; ++i) {
+            uint32_t v = 0;
+            for (int k = 0; k < 4; ++k) {
+                const int64_t p = (int64_t)base - 4 + 4 * i + k;
+                const uint32_t byte = (p >= 0 && (uint64_t)p < n) ? in[p] : 0xFFu;
+                v |= byte << (8 * k);
+            }
+            w[i] = v;
+        }
+        inspect(base, w, kmax);
+    };
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t0 - lane < nal; t0 += 4 * stride) {      // (whole waves stay together: bpermute)
+        uint4 a[4];
+        uint32_t nx[4][3], pv[4];
+        bool on[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint64_t base = (t0 + (uint64_t)u * stride) * 16;
-            fast[u] = t0 + (uint64_t)u * stride < nvec && base >= 16 && base + 32 <= n;
-            if (fast[u]) { a[u] = ld_u128(in + base); b[u] = ld_u128(in + base + 16); w0[u] = ld_u32(in + base - 4); }   // the payload starts at any alignment
+            const uint64_t t = t0 + (uint64_t)u * stride;
+            on[u] = t < nal;
+            a[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
+            if (t <= nal) a[u] = *reinterpret_cast<const uint4*>(in + A + t * 16);      // (vector nal exists too: its first dwords are the lane before's tail)
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint64_t t = t0 + (uint64_t)u * stride;
-            if (t >= nvec) break;
-            const uint64_t base = t * 16;
-            uint32_t w[9];                                               // w[0] = bytes base-4.., w[1..4] = base.., w[5..8] = base+16..
-            if (fast[u]) {
-                w[0] = w0[u];
-                w[1] = a[u].x; w[2] = a[u].y; w[3] = a[u].z; w[4] = a[u].w; w[5] = b[u].x; w[6] = b[u].y; w[7] = b[u].z; w[8] = b[u].w;
-            } else {
-                for (int i = 0; i < 9; ++i) {
-                    uint32_t v = 0;
-                    for (int k = 0; k < 4; ++k) {
-                        const int64_t p = (int64_t)base - 4 + 4 * i + k;
-                        const uint32_t byte = (p >= 0 && (uint64_t)p < n) ? in[p] : 0xFFu;
-                        v |= byte << (8 * k);
-                    }
-                    w[i] = v;
-                }
+            const uint64_t base = A + t * 16;
+            const int up = (int)(((lane + 1u) & 63u) * 4u), dn = (int)(((lane + 63u) & 63u) * 4u);
+            nx[u][0] = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)a[u].x);
+            nx[u][1] = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)a[u].y);
+            nx[u][2] = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)a[u].z);
+            pv[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(dn, (int)a[u].w);
+            if (on[u] && lane == 63u) {                                   // the wave's last vector: what follows it belongs to another wave
+                nx[u][0] = ld_u32(in + base + 16); nx[u][1] = ld_u32(in + base + 20); nx[u][2] = ld_u32(in + base + 24);
             }
-            inspect(base, w);
+            if (on[u] && lane == 0u) pv[u] = base >= 4 ? ld_u32(in + base - 4) : 0xffffffffu;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
+            const uint64_t base = A + (t0 + (uint64_t)u * stride) * 16;
+            if (base < 4) { slow_window(base, 16u); continue; }           // (a payload that starts within 4 bytes of an aligned address)
+            const uint32_t w[9] = {pv[u], a[u].x, a[u].y, a[u].z, a[u].w, nx[u][0], nx[u][1], nx[u][2], 0u};
+            inspect(base, w, 16u);
         }
     }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && A) slow_window(0, (uint32_t)(A < n ? A : n));          // start positions [0, A)
+    // the ragged end: start positions from the first vector not taken above
+    for (uint64_t base = A + nal * 16 + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; base < n; base += stride * 16) slow_window(base, 16u);
 }
 
 // one workgroup of 1024 threads; work arrays succ[2][N+2], dist[2][N+2], mark[N+2]: in LDS as 16-bit indices when the candidates fit
