@@ -1218,6 +1218,8 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
     uint64_t cur_bytes = h.payload_bytes;
     bool use_ping = true;
     bool diff_in_place = false;            // the bit-plane inverse wrote into the volume itself; the diff3x3x1 inverse works there
+    const uint32_t* lz4_flag = nullptr;    // the LZ4 decoder's error flag, read when the call ends
+    int lz4_flag_stage = 0;
     auto out_buf = [&](size_t stage_index, uint64_t bytes) -> uint8_t* {
         if (stage_index == 0) return static_cast<uint8_t*>(d_dst);               // the first stage's inverse produces the volume
         DevBuf& b = use_ping ? ws->ping : ws->pong;
@@ -1306,10 +1308,11 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                         ProfScope ps("lz4_frames_decode", stream, pend);
                         SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, side_ok ? cx.side : nullptr, cx.fork, cx.join));
                     }
-                    SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
-                    SQY_HIP(hipStreamSynchronize(stream));
+                    // (the decoder's verdict is read at the END of the call, with the call's last synchronisation: the stages in between are
+                    // plain data movement and stay inside their buffers whatever the bytes are -- one host round trip less per decode)
+                    lz4_flag = counts + 4;
+                    lz4_flag_stage = (int)si;
                 }
-                if (bad) { std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 block, or a frame that does not decode to its share of the volume\n"); return stage_error(si); }
                 cur = out; cur_bytes = total;
                 break;
             }
@@ -1515,8 +1518,13 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
         }
     }
     if (cur != d_dst) SQY_HIP(hipMemcpyAsync(d_dst, cur, raw_bytes, hipMemcpyDeviceToDevice, stream));
+    if (lz4_flag) SQY_HIP(hipMemcpyAsync(ws->pinned, lz4_flag, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
     SQY_HIP(hipStreamSynchronize(stream));
     if (g_prof_on.load()) prof_collect(cx.pending);
+    if (lz4_flag && *static_cast<const uint32_t*>(ws->pinned)) {
+        std::fprintf(stderr, "[sqy::lz4] corrupt LZ4 block, or a frame that does not decode to its share of the volume\n");
+        return stage_error((size_t)lz4_flag_stage);
+    }
     return 0;
 }
 
