@@ -834,7 +834,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     if (n_redo && dense_pass(n_redo)) return 1;
                 } else if (lz4_total) {
                     // block-linked frames: the serial layout (nthreads == 1) or chunks that span several LZ4 blocks.  The table
-                    // of a frame is carried from block to block, so one wavefront walks each frame (lz4_utils.hpp:99-173)
+                    // of a frame is carried from block to block (lz4_utils.hpp:99-173): one wavefront walks each frame -- or, below, every
+                    // block is parsed at once from a guess of that table that is checked afterwards
                     const sqy::Lz4Plan plan = sqy::lz4_plan_blocks(lz4_total, lz4_chunk, st.lz4.block_bytes(), serial);
                     if (!plan.ok || plan.blocks.empty()) {
                         std::fprintf(stderr, "[sqeazy]\t lz4: block layout not available on MI355X\n");
