@@ -161,7 +161,7 @@ def test_block_parallel_serial_layout(sqy, oracle, monkeypatch, name, warmup):
 
 
 @pytest.mark.parametrize("cfg", ["blocksize_kb=64", "blocksize_kb=64,framestep_kb=448", "framestep_kb=1024", "blocksize_kb=1024,framestep_kb=3072",
-                                 "n_chunks_of_input=3", "n_chunks_of_input=1", "accel=-3"])
+                                 "blocksize_kb=4096", "n_chunks_of_input=3", "n_chunks_of_input=1", "accel=-3"])
 @pytest.mark.parametrize("nthreads", [1, 2])
 def test_block_parallel_other_block_layouts(sqy, oracle, cfg, nthreads):
     """block sizes of 64 KiB (the warm-up is exactly liblz4's reach), update sizes that are no multiple of the block size (short blocks in
