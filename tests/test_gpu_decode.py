@@ -458,3 +458,101 @@ def test_serial_layout_frame_cut_into_uneven_blocks_falls_back(sqy, oracle):
     names = set(sqy.profile_get().keys())
     assert rc == 0 and np.array_equal(back.reshape(-1), data)
     assert "lz4_linked_decode" in names and "lz4_frames_decode" in names, names      # tried, refused, walked
+
+
+# ---- hand-made LZ4 sequences: offsets and lengths on every boundary the decoders' copy paths know --------------------------------
+# (16 bytes per lane, 1 KiB per step, the 16 KiB ring of the small-ring kernels, 64 KiB reach, references across block borders).  The
+# streams come from no encoder: a frame of linked 64 KiB blocks is written sequence by sequence, the expected bytes by a byte-wise
+# reference decode in Python.  Decoded three ways: block-parallel, with one walk over the tails, by the one-wavefront walk.
+def _handmade_linked_frame(seed, nblocks, block=64 << 10):
+    import xxhash
+    rng = np.random.default_rng(seed)
+    OFFS = [1, 2, 3, 4, 7, 8, 15, 16, 17, 31, 63, 64, 65, 255, 256, 1023, 1024, 1025, 4095, 16383, 16384, 16385, 16400, 32768, 40000, 65534, 65535]
+    LENS = [4, 5, 15, 16, 17, 18, 19, 63, 64, 65, 255, 256, 257, 273, 274, 1023, 1024, 1025, 2047, 2048, 2049, 5000]
+    out = bytearray()
+    payload = bytearray([0x04, 0x22, 0x4D, 0x18, 0x40, 0x40])
+    payload.append((xxhash.xxh32(bytes(payload[4:6]), seed=0).intdigest() >> 8) & 0xFF)
+    for b in range(nblocks):
+        last = b == nblocks - 1
+        target = block if not last else int(rng.integers(2000, block - 100))
+        start = len(out)
+        comp = bytearray()
+        while True:
+            room = target - (len(out) - start)
+            lit = int(rng.choice([0, 1, 2, 5, 14, 15, 16, 30, 269, 270, 271, 600])) if rng.random() < 0.8 else int(rng.integers(0, 40))
+            if room < 64 or lit + 4 + 12 > room:                     # close the block: literals only (at least the 12 bytes LZ4 wants at a block's end)
+                lit = room
+                tok = min(lit, 15) << 4
+                comp.append(tok)
+                if lit >= 15:
+                    r = lit - 15
+                    comp += bytes([255] * (r // 255) + [r % 255])
+                lits = rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+                comp += lits; out += lits
+                break
+            avail = min(len(out) + lit, 65535)                       # how far back a match may reach (the frame's own output only)
+            offs = [o for o in OFFS if o <= avail]
+            if not offs:
+                lit = max(lit, 8); avail = min(len(out) + lit, 65535); offs = [o for o in OFFS if o <= avail]
+            off = int(rng.choice(offs)) if rng.random() < 0.8 else int(rng.integers(1, avail + 1))
+            maxml = room - lit - 12
+            lens = [m for m in LENS if m <= maxml]
+            ml = int(rng.choice(lens)) if rng.random() < 0.8 else int(rng.integers(4, min(maxml, 3000) + 1))
+            tok = (min(lit, 15) << 4) | min(ml - 4, 15)
+            comp.append(tok)
+            if lit >= 15:
+                r = lit - 15
+                comp += bytes([255] * (r // 255) + [r % 255])
+            lits = rng.integers(0, 256, lit, dtype=np.uint8).tobytes()
+            comp += lits; out += lits
+            comp += off.to_bytes(2, "little")
+            if ml - 4 >= 15:
+                r = ml - 4 - 15
+                comp += bytes([255] * (r // 255) + [r % 255])
+            for _ in range(ml):                                      # byte-wise: overlapping matches extend themselves
+                out.append(out[-off])
+        assert len(out) - start == target
+        payload += len(comp).to_bytes(4, "little") + comp
+    payload += bytes(4)
+    return bytes(payload), np.frombuffer(bytes(out), np.uint8)
+
+
+@pytest.mark.parametrize("seed,nblocks", [(1, 5), (2, 9), (3, 40), (4, 300), (5, 3)])
+def test_handmade_sequences_on_every_boundary(sqy, oracle, monkeypatch, seed, nblocks):
+    payload, want = _handmade_linked_frame(seed, nblocks)
+    name = "lz4(accel=1,blocksize_kb=64,framestep_kb=256,n_chunks_of_input=0)"
+    blob = oracle.header_pack(np.uint8, (1, 1, want.size), name, len(payload)) + payload
+    assert np.array_equal(oracle.pipeline_decode(blob).reshape(-1), want)      # the oracle's decoder agrees with the byte-wise reference
+    sqy.profile_reset(); sqy.profile_enable(True)
+    rc, back = sqy.decode(blob)
+    sqy.profile_enable(False)
+    names = set(sqy.profile_get().keys())
+    assert rc == 0 and np.array_equal(back.reshape(-1), want), "block-parallel decode differs"
+    assert "lz4_linked_decode" in names and "lz4_frames_decode" not in names, names
+    monkeypatch.setenv("SQY_NO_TAIL_SCAN", "1")
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back.reshape(-1), want), "one walk over the tails differs"
+    monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back.reshape(-1), want), "one-wavefront decode differs"
+
+
+@pytest.mark.parametrize("nframes", [12, 900])
+def test_handmade_sequences_chunked_layout(sqy, oracle, nframes):
+    """the same hand-made sequences as independent single-block frames (the chunked layout): 12 frames take the 64 KiB-ring kernel, 900 the
+    16 KiB-ring one (matches behind the ring come from the output buffer); 30 distinct frames, repeated"""
+    # (_handmade_linked_frame makes its LAST block short; a frame of the chunked layout must fill its chunk unless it is the stream's last:
+    # of two-block frames the first block, which is full and names nothing in front of itself, becomes a frame of its own)
+    full = []
+    for s_ in range(30):
+        payload, want = _handmade_linked_frame(200 + s_, 2, block=64 << 10)
+        first_sz = int.from_bytes(payload[7:11], "little")
+        full.append((payload[:11 + first_sz] + bytes(4), want[:64 << 10]))
+    frames = [full[i % 30] for i in range(nframes - 1)] + [_handmade_linked_frame(100, 1, block=64 << 10)]
+    payload = b"".join(f[0] for f in frames)
+    want = np.concatenate([f[1] for f in frames])
+    name = "lz4(accel=1,blocksize_kb=64,framestep_kb=64,n_chunks_of_input=0)"
+    blob = oracle.header_pack(np.uint8, (1, 1, want.size), name, len(payload)) + payload
+    assert np.array_equal(oracle.pipeline_decode(blob).reshape(-1), want)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back.reshape(-1), want)
