@@ -2992,10 +2992,29 @@ __device__ __forceinline__ uint32_t cand_slot(uint64_t pos, uint32_t mask)
     return (uint32_t)(((pos + 1) * 0x9E3779B97F4A7C15ull) >> 40) & mask;
 }
 
+// A look at the first frame in front of everything (round 4): when a second block follows its first block, the stream is the serial
+// layout's ONE block-linked frame (or chunks of several blocks) -- nothing the ranking covers, it would scan the whole payload
+// (0.2-0.3 ms per GiB) only to give up.  *hint = 1 makes the two kernels below return at once; the host then takes the walk, as it does
+// whenever the ranking gives up.
+__global__ void lz4_frame_probe_kernel(const uint8_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ hint)
+{
+    uint32_t multi = 0;
+    if (n >= 19 && ld_u32(in) == 0x184D2204u) {
+        const uint32_t flg = in[4];
+        const uint32_t field = ld_u32(in + 7);
+        if ((flg >> 6) == 1 && !(flg & 0x0D) && field != 0) {
+            const uint64_t next = 11ull + (field & 0x7fffffffu) + (((flg >> 4) & 1u) ? 4u : 0u);
+            if (next + 4 <= n && ld_u32(in + next) != 0u) multi = 1;
+        }
+    }
+    *hint = multi;
+}
+
 __global__ __launch_bounds__(256)
 void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, FrameSlot* __restrict__ table, uint32_t mask,
-                                 FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand)
+                                 FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand, const uint32_t* __restrict__ hint)
 {
+    if (*hint) return;
     // a thread inspects 16 start positions [base, base + 16); it needs the bytes [base - 4, base + 28).  Four such windows per thread and
     // step, all their loads issued before the first is looked at
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -3175,10 +3194,11 @@ __global__ __launch_bounds__(1024)
 void lz4_frame_rank_kernel(const uint8_t* __restrict__ in, uint64_t n, const FrameSlot* __restrict__ table, uint32_t mask,
                            const FrameCand* __restrict__ list, uint32_t cap, const uint32_t* __restrict__ ncand,
                            uint32_t* __restrict__ work, uint4* __restrict__ blk, uint32_t* __restrict__ frame_first,
-                           uint64_t max_blocks, uint32_t* __restrict__ counts, uint32_t lds_entries)
+                           uint64_t max_blocks, uint32_t* __restrict__ counts, uint32_t lds_entries, const uint32_t* __restrict__ hint)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t rank_lds[];
     __shared__ uint32_t head_s;
+    if (*hint) { if (threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 100; } return; }     // (lz4_frame_probe_kernel: frames of several blocks)
     const uint32_t N = *ncand;
     if (N == 0 || N > cap) { if (threadIdx.x == 0) { counts[0] = 0; counts[1] = 0; counts[2] = 100; } return; }
     const uint32_t M = N + 2;
@@ -5127,8 +5147,10 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
     const uint64_t gcap = (uint64_t)num_cus() * 16;
     if (blocks > gcap) blocks = gcap;
     if (blocks == 0) blocks = 1;
+    uint32_t* hint = counts + 5;                                          // (counts: [0..3] the index, [4] the decoders' flag, [5] this)
+    hipLaunchKernelGGL(lz4_frame_probe_kernel, dim3(1), dim3(1), 0, stream, in, n, hint);
     hipLaunchKernelGGL(lz4_frame_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, table, (uint32_t)(slots - 1), list,
-                       (uint32_t)cap, ncand);
+                       (uint32_t)cap, ncand, (const uint32_t*)hint);
     // LDS for the rank kernel's work arrays: 9 bytes per candidate (the frames expected + room for false magics), when that fits
     uint64_t lds_entries = (expected_frames + 1024 + 2 + 7) & ~(uint64_t)7;
     if (lds_entries > 16000) lds_entries = 0;                            // (144 KiB of the CU's 160)
@@ -5143,7 +5165,7 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
     }
     hipLaunchKernelGGL(lz4_frame_rank_kernel, dim3(1), dim3(1024), lds_entries ? lds_bytes : 0, stream, in, n, (const FrameSlot*)table, (uint32_t)(slots - 1),
                        (const FrameCand*)list, (uint32_t)cap, (const uint32_t*)ncand, work, (uint4*)blk, frame_first, max_blocks, counts,
-                       (uint32_t)lds_entries);
+                       (uint32_t)lds_entries, (const uint32_t*)hint);
     return hipGetLastError();
 }
 
