@@ -4315,17 +4315,45 @@ void lz4_linked_compose_tails_kernel(const uint4* __restrict__ blk, uint32_t nbl
             uint32_t rr[32];
 #pragma unroll
             for (uint32_t j = 0; j < 8; ++j) { const uint4 v = ld_u128(reinterpret_cast<const uint8_t*>(r + j * 8u)); rr[4 * j] = v.x; rr[4 * j + 1] = v.y; rr[4 * j + 2] = v.z; rr[4 * j + 3] = v.w; }
+            // four bytes at a time: references that count down (a straight copy: four consecutive words of the symbolic tail, one 8-byte
+            // read, and their four bits) or are all equal (a run), else byte by byte
 #pragma unroll
-            for (uint32_t j = 0; j < 64; ++j) {
-                const uint32_t rf = (rr[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
-                uint32_t w = (d[j >> 2] >> (8u * (j & 3u))) & 0xffu, f = 0u;
-                if (rf) {
-                    const uint32_t idx = SYM_TAIL - rf;
-                    w = sv[idx];
-                    f = (isref[idx >> 5] >> (idx & 31u)) & 1u;
+            for (uint32_t m = 0; m < 16; ++m) {
+                const uint32_t a = rr[2 * m], b = rr[2 * m + 1];
+                const uint32_t r0 = a & 0xffffu;
+                const uint32_t dm = d[m];
+                if (!(a | b)) {
+                    nv[2 * m] = (dm & 0xffu) | ((dm & 0xff00u) << 8);
+                    nv[2 * m + 1] = ((dm >> 16) & 0xffu) | ((dm >> 24) << 16);
+                } else if (r0 >= 4u && a == r0 * 0x10001u - 0x10000u && b == a - 0x20002u) {
+                    const uint32_t idx = SYM_TAIL - r0;
+                    const uint64_t w4 = lds_ld_u64((const lds_u8*)sv + 2u * idx);
+                    nv[2 * m] = (uint32_t)w4; nv[2 * m + 1] = (uint32_t)(w4 >> 32);
+                    const uint32_t sh = idx & 31u;
+                    uint32_t f4 = isref[idx >> 5] >> sh;
+                    if (sh > 28u) f4 |= isref[(idx >> 5) + 1u] << (32u - sh);
+                    nb[m >> 3] |= (f4 & 0xfu) << ((4u * m) & 31u);
+                } else if (r0 && a == r0 * 0x10001u && b == a) {
+                    const uint32_t idx = SYM_TAIL - r0;
+                    const uint32_t w = sv[idx], f = (isref[idx >> 5] >> (idx & 31u)) & 1u;
+                    nv[2 * m] = w * 0x10001u; nv[2 * m + 1] = w * 0x10001u;
+                    nb[m >> 3] |= (f ? 0xfu : 0u) << ((4u * m) & 31u);
+                } else {
+                    uint32_t w2[4];
+#pragma unroll
+                    for (uint32_t j = 0; j < 4; ++j) {
+                        const uint32_t rf = ((j < 2 ? a : b) >> (16u * (j & 1u))) & 0xffffu;
+                        uint32_t w = (dm >> (8u * j)) & 0xffu, f = 0u;
+                        if (rf) {
+                            const uint32_t idx = SYM_TAIL - rf;
+                            w = sv[idx];
+                            f = (isref[idx >> 5] >> (idx & 31u)) & 1u;
+                        }
+                        w2[j] = w;
+                        nb[m >> 3] |= f << ((4u * m + j) & 31u);
+                    }
+                    nv[2 * m] = w2[0] | (w2[1] << 16); nv[2 * m + 1] = w2[2] | (w2[3] << 16);
                 }
-                if (j & 1u) nv[j >> 1] |= w << 16; else nv[j >> 1] = w;
-                nb[j >> 5] |= f << (j & 31u);
             }
         }
         __syncthreads();
@@ -4365,12 +4393,24 @@ void lz4_linked_chain_ranges_kernel(const uint8_t* __restrict__ maps, uint32_t n
         const uint32_t f0 = reinterpret_cast<const uint32_t*>(m + 2 * SYM_TAIL)[2u * t], f1 = reinterpret_cast<const uint32_t*>(m + 2 * SYM_TAIL)[2u * t + 1u];
         uint32_t c[16];
 #pragma unroll
-        for (uint32_t j = 0; j < 64; ++j) {
-            const uint32_t x = (wv[j >> 1] >> (16u * (j & 1u))) & 0xffffu;
-            const uint32_t f = ((j < 32u ? f0 : f1) >> (j & 31u)) & 1u;
-            // (distance 0 -- the identity's word 0, which nothing can name -- never comes out of a composed map of a real block)
-            const uint32_t b = f ? (uint32_t)prev[(SYM_TAIL - x) & (SYM_TAIL - 1u)] : (x & 0xffu);
-            if (j & 3u) c[j >> 2] |= b << (8u * (j & 3u)); else c[j >> 2] = b;
+        for (uint32_t m = 0; m < 16; ++m) {                              // four bytes at a time, as in the compose kernel
+            const uint32_t a = wv[2 * m], b = wv[2 * m + 1];
+            const uint32_t f4 = ((m < 8u ? f0 : f1) >> ((4u * m) & 31u)) & 0xfu;
+            const uint32_t x0 = a & 0xffffu;
+            if (!f4) c[m] = (a & 0xffu) | ((a >> 8) & 0xff00u) | ((b & 0xffu) << 16) | ((b >> 16) << 24);
+            else if (f4 == 0xfu && x0 >= 4u && a == x0 * 0x10001u - 0x10000u && b == a - 0x20002u) c[m] = lds_ld_u32(prev + (SYM_TAIL - x0));
+            else if (f4 == 0xfu && x0 && a == x0 * 0x10001u && b == a) c[m] = (uint32_t)prev[SYM_TAIL - x0] * 0x01010101u;
+            else {
+                uint32_t cm = 0;
+#pragma unroll
+                for (uint32_t j = 0; j < 4; ++j) {
+                    const uint32_t x = ((j < 2 ? a : b) >> (16u * (j & 1u))) & 0xffffu;
+                    // (distance 0 -- the identity's word 0, which nothing can name -- never comes out of a composed map of a real block)
+                    const uint32_t bb = ((f4 >> j) & 1u) ? (uint32_t)prev[(SYM_TAIL - x) & (SYM_TAIL - 1u)] : (x & 0xffu);
+                    cm |= bb << (8u * j);
+                }
+                c[m] = cm;
+            }
         }
         uint8_t* o = starts + (uint64_t)(w + 1) * SYM_TAIL + (uint64_t)t * 64u;
 #pragma unroll
