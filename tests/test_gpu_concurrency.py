@@ -100,3 +100,37 @@ def test_diff_decode_next_to_encodes_in_flight(sqy, oracle):
             th.join(timeout=600)
     assert not errors, errors[:3]
     assert time.perf_counter() - t0 < 120
+
+
+def test_serial_layout_calls_in_flight(sqy, oracle):
+    """the block-parallel paths of the serial layout (nthreads = 1: table guesses + verify + second parse on the way in, symbolic decode
+    + tail scan on the way out) from ten host threads at once, each context with its own tables and references"""
+    rng = np.random.default_rng(4)
+    n = 30 * (256 << 10) + 999
+    a = np.zeros(n, np.uint8); idx = rng.integers(0, n, n // 40); a[idx] = rng.integers(1, 256, idx.size)
+    b = rng.integers(0, 256, n, dtype=np.uint8)
+    for i in range(256 << 10, n - 400, 256 << 10):               # guesses that fail: a second parse runs as well
+        b[i:i + 300] = b[i - 1000:i - 700]
+    jobs = [("lz4", a.reshape(1, 1, -1)), ("lz4", b.reshape(1, 1, -1)), ("bitswap1->lz4", synth.stack((40, 256, 256), np.uint16)),
+            ("lz4(blocksize_kb=64)", np.repeat(rng.integers(0, 4, n // 64 + 1, dtype=np.uint8), 64)[:n].reshape(1, 1, -1))]
+    want = [oracle.pipeline_encode(p, v, nthreads=1) for p, v in jobs]
+    errors = []
+
+    def worker(t):
+        try:
+            for it in range(5):
+                k = (t + it) % len(jobs)
+                p, v = jobs[k]
+                rc, blob = sqy.encode(p, v, nthreads=1)
+                assert rc == 0 and blob == want[k], ("encode", t, it, p)
+                rc, dec = sqy.decode(blob)
+                assert rc == 0 and np.array_equal(dec, v), ("decode", t, it, p)
+        except Exception as e:   # pragma: no cover
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(10)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=600)
+    assert not errors, errors[:3]
