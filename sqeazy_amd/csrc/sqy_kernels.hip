@@ -5209,6 +5209,7 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
     return hipGetLastError();
 }
 
+constexpr uint32_t SQY_RING8_MIN = 2560;
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
                                     uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join)
@@ -5227,7 +5228,12 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     }
     // more compressed blocks than the 64 KiB-ring kernel keeps resident (2 per CU) plus half a round: the small ring's four-fold
     // occupancy wins; below that the frames are few and long, and every match served from LDS wins
-    if (ncompressed > 768u && nframes > 768u)
+    // (round 4) more compressed frames than even the 16 KiB-ring kernel keeps resident (8 per CU) plus a quarter: the 8 KiB ring's 13 waves
+    // per CU win although more matches reach behind the ring -- the C3 slab's 3584 frames 3.37 -> 2.65 ms (a 4 KiB ring: no better)
+    if (ncompressed > SQY_RING8_MIN && nframes > SQY_RING8_MIN)
+        hipLaunchKernelGGL(lz4_frames_decode_kernel<8192>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
+                           out_bytes, frame_stride, block_bytes, errflag);
+    else if (ncompressed > 768u && nframes > 768u)
         hipLaunchKernelGGL(lz4_frames_decode_kernel<16384>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
                            out_bytes, frame_stride, block_bytes, errflag);
     else

@@ -94,7 +94,8 @@ def _frame_with_far_matches(rng, n, kind):
 
 
 @pytest.mark.parametrize("pipeline,frame_bytes,nframes", [("lz4", 256 << 10, 800), ("lz4(blocksize_kb=64)", 64 << 10, 1100),
-                                                         ("lz4(blocksize_kb=64,framestep_kb=256)", 256 << 10, 780)])
+                                                         ("lz4(blocksize_kb=64,framestep_kb=256)", 256 << 10, 780),
+                                                         ("lz4(blocksize_kb=64,framestep_kb=64)", 64 << 10, 3000)])     # (> 2560 compressed frames: the 8 KiB ring)
 def test_decode_many_frames_small_ring(sqy, oracle, pipeline, frame_bytes, nframes):
     """more than 768 compressed frames select the 16 KiB-ring decode kernel: matches that reach further back than the ring
     (up to 64 KiB, also across the blocks of a multi-block frame, also longer than their offset) come from the output buffer"""
@@ -537,10 +538,10 @@ def test_handmade_sequences_on_every_boundary(sqy, oracle, monkeypatch, seed, nb
     assert rc == 0 and np.array_equal(back.reshape(-1), want), "one-wavefront decode differs"
 
 
-@pytest.mark.parametrize("nframes", [12, 900])
+@pytest.mark.parametrize("nframes", [12, 900, 2800])
 def test_handmade_sequences_chunked_layout(sqy, oracle, nframes):
     """the same hand-made sequences as independent single-block frames (the chunked layout): 12 frames take the 64 KiB-ring kernel, 900 the
-    16 KiB-ring one (matches behind the ring come from the output buffer); 30 distinct frames, repeated"""
+    16 KiB-ring one, 2800 the 8 KiB-ring one (matches behind the ring come from the output buffer); 30 distinct frames, repeated"""
     # (_handmade_linked_frame makes its LAST block short; a frame of the chunked layout must fill its chunk unless it is the stream's last:
     # of two-block frames the first block, which is full and names nothing in front of itself, becomes a frame of its own)
     full = []
