@@ -189,7 +189,7 @@ def secondary_configs(dev):
     from sqeazy_amd import synth
     out = {}
 
-    def one(pipeline, shape, dtype, algo_per_voxel, vol=None, reps=3, extra=0):
+    def one(pipeline, shape, dtype, algo_per_voxel, vol=None, reps=3, extra=0, decode=False):
         v = vol if vol is not None else synth.stack_torch(shape, dtype, dev)
         cap = sqeazy_amd.max_compressed_length(pipeline, shape, dtype) + extra
         buf = torch.empty(cap, dtype=torch.uint8, device=dev)
@@ -211,6 +211,30 @@ def secondary_configs(dev):
         res = {"ms_per_call": round(best * 1e3, 3), "input_GBps": round(nvox * np.dtype(dtype).itemsize / best / 1e9, 1),
                "algorithmic_bytes": int(algo), "roofline_frac": round(algo / best / 1e9 / HBM_PEAK_GBS, 5), "blob_bytes": int(m),
                "kernels_ms": {k: round(a / max(c, 1), 3) for k, (a, c) in prof.items()}}
+        if decode:
+            # .. and back (SQYAMD_Decode_*_Device on that blob, device to device), for the record
+            try:
+                nb = nvox * np.dtype(dtype).itemsize
+                back = torch.empty(nb, dtype=torch.uint8, device=dev)
+                dfn = sqeazy_amd.lib().SQYAMD_Decode_UI16_Device if np.dtype(dtype) == np.uint16 else sqeazy_amd.lib().SQYAMD_Decode_UI8_Device
+                dbest, dprof = None, {}
+                for _ in range(3):
+                    sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    drc = dfn(ctypes.c_void_p(buf.data_ptr() + off), ctypes.c_long(m), ctypes.c_void_p(back.data_ptr()), ctypes.c_long(nb), None)
+                    torch.cuda.synchronize(); dt = time.perf_counter() - t0
+                    sqeazy_amd.profile_enable(False)
+                    if drc:
+                        raise RuntimeError("decode returned %d" % drc)
+                    if dbest is None or dt < dbest:
+                        dbest, dprof = dt, sqeazy_amd.profile_get()
+                res["decode"] = {"ms_per_call": round(dbest * 1e3, 3), "output_GBps": round(nb / dbest / 1e9, 1),
+                                 "kernels_ms": {k: round(a / max(c, 1), 3) for k, (a, c) in dprof.items()}}
+                if "quantiser" not in pipeline and "frame_shuffle" not in pipeline:
+                    res["decode"]["round_trip_equal"] = bool((back.view(torch.uint16 if np.dtype(dtype) == np.uint16 else torch.uint8).reshape(shape) == v).all().item())
+                del back
+            except Exception as e:   # reported, never required
+                res["decode"] = {"error": repr(e)}
         del buf
         if vol is None:
             del v
@@ -228,9 +252,13 @@ def secondary_configs(dev):
         torch.cuda.empty_cache()
     except Exception as e:   # reported, never required
         out["C2 stack + 40000"] = {"error": repr(e)}
-    out["C3_slab 2048x2048x256 u16 diff3x3x1->bitswap1->lz4"], _ = one("diff3x3x1->bitswap1->lz4", (256, 2048, 2048), np.uint16, 2)
-    out["C4 1024x1024x1024 u8 frame_shuffle->lz4"], _ = one("frame_shuffle->lz4", (1024, 1024, 1024), np.uint8, 2, extra=1 << 16)
-    out["C5_slab 2048x2048x256 u16 quantiser->bitswap1->lz4"], _ = one("quantiser->bitswap1->lz4", (256, 2048, 2048), np.uint16, 4)
+    try:
+        out["C2 1024x1024x512 u16 bitswap1->lz4 (the default run's stack, one call at a time, with its decode)"], _ = one(PIPELINE, SHAPE, np.uint16, 2, decode=True)
+    except Exception as e:   # reported, never required
+        out["C2 with decode"] = {"error": repr(e)}
+    out["C3_slab 2048x2048x256 u16 diff3x3x1->bitswap1->lz4"], _ = one("diff3x3x1->bitswap1->lz4", (256, 2048, 2048), np.uint16, 2, decode=True)
+    out["C4 1024x1024x1024 u8 frame_shuffle->lz4"], _ = one("frame_shuffle->lz4", (1024, 1024, 1024), np.uint8, 2, extra=1 << 16, decode=True)
+    out["C5_slab 2048x2048x256 u16 quantiser->bitswap1->lz4"], _ = one("quantiser->bitswap1->lz4", (256, 2048, 2048), np.uint16, 4, decode=True)
     # north_star's target on one GPU: 2048^3 uint16, bitswap1->lz4, eight sequential 2 GiB slab calls (inputs resident when each call starts)
     total_t, total_algo, total_in, slabs = 0.0, 0, 0, []
     for i in range(8):
