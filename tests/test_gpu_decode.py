@@ -89,6 +89,9 @@ def _frame_with_far_matches(rng, n, kind):
             a[pos:pos + ln] = a[pos - back:pos - back + ln]
             pos += ln + int(rng.integers(0, 40))
         return a
+    if kind == 6:                                              # a period between the 8 KiB and the 16 KiB ring: behind one, inside the other
+        p = int(rng.integers(8200, 16300))
+        return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
     p = int(rng.integers(1, 300))
     return np.tile(rng.integers(0, 256, p, dtype=np.uint8), n // p + 1)[:n]
 
@@ -100,7 +103,7 @@ def test_decode_many_frames_small_ring(sqy, oracle, pipeline, frame_bytes, nfram
     """more than 768 compressed frames select the 16 KiB-ring decode kernel: matches that reach further back than the ring
     (up to 64 KiB, also across the blocks of a multi-block frame, also longer than their offset) come from the output buffer"""
     rng = np.random.default_rng(nframes)
-    d = np.concatenate([_frame_with_far_matches(rng, frame_bytes, f % 6) for f in range(nframes)] + [rng.integers(0, 256, 777, dtype=np.uint8)])
+    d = np.concatenate([_frame_with_far_matches(rng, frame_bytes, f % 8) for f in range(nframes)] + [rng.integers(0, 256, 777, dtype=np.uint8)])
     vol = d.reshape(1, 1, -1)
     blob = oracle.pipeline_encode(pipeline, vol)
     rc, back = sqy.decode(blob)
