@@ -69,8 +69,10 @@ def lib_identity():
             "hipcc_flags": "--offload-arch=%s %s" % (build.ARCH, " ".join(build.FLAGS))}
 
 
-def measured_traffic(sha, kernel):
-    """PMC bytes per launch of `kernel` from the newest profiles/*_pmc_hbm.json that was collected on this very build"""
+def measured_traffic(sha, kernel, launches_per_call):
+    """PMC bytes per launch of `kernel` from the newest profiles/*_pmc_hbm.json that was collected on this very build, and the sum over
+    the kernels of ONE timed encode call (`launches_per_call`: kernel -> launches per call in the timed region; the PMC file of a full
+    bench run also holds the decode and serial-layout kernels of the other legs, which are no part of the step)"""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     for name in sorted(os.listdir(pdir)) if os.path.isdir(pdir) else []:
@@ -80,7 +82,9 @@ def measured_traffic(sha, kernel):
             except Exception:
                 continue
             if j.get("library_sha256") == sha and kernel in j.get("traffic", {}):
-                best = {"bytes_per_launch": j["traffic"][kernel], "per_call_all_kernels": sum(j["traffic"].values()), "source": "profiles/" + name}
+                per_call = sum(j["traffic"][k] * n for k, n in launches_per_call.items() if k in j["traffic"])
+                best = {"bytes_per_launch": j["traffic"][kernel], "per_call_all_kernels": int(round(per_call)),
+                        "kernels_missing": sorted(k for k in launches_per_call if k not in j["traffic"]), "source": "profiles/" + name}
     return best
 
 
@@ -189,18 +193,18 @@ def secondary_configs(dev):
     from sqeazy_amd import synth
     out = {}
 
-    def one(pipeline, shape, dtype, algo_per_voxel, vol=None, reps=3, extra=0, decode=False):
+    def one(pipeline, shape, dtype, algo_per_voxel, vol=None, reps=3, extra=0, decode=False, nthreads=0):
         v = vol if vol is not None else synth.stack_torch(shape, dtype, dev)
         cap = sqeazy_amd.max_compressed_length(pipeline, shape, dtype) + extra
         buf = torch.empty(cap, dtype=torch.uint8, device=dev)
-        rc, off, m = sqeazy_amd.encode_device_at(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+        rc, off, m = sqeazy_amd.encode_device_at(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap, nthreads=nthreads)
         if rc:
             raise RuntimeError("%s returned %d" % (pipeline, rc))
         best, prof = None, {}
         for _ in range(reps):
             sqeazy_amd.profile_reset(); sqeazy_amd.profile_enable(True)
             torch.cuda.synchronize(); t0 = time.perf_counter()
-            rc, off, m = sqeazy_amd.encode_device_at(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap)
+            rc, off, m = sqeazy_amd.encode_device_at(pipeline, v.data_ptr(), shape, dtype, buf.data_ptr(), cap, nthreads=nthreads)
             torch.cuda.synchronize(); dt = time.perf_counter() - t0
             sqeazy_amd.profile_enable(False)
             if best is None or dt < best:
@@ -228,7 +232,9 @@ def secondary_configs(dev):
                         raise RuntimeError("decode returned %d" % drc)
                     if dbest is None or dt < dbest:
                         dbest, dprof = dt, sqeazy_amd.profile_get()
+                # algorithmic bytes of a decode: the blob read once, the volume written once
                 res["decode"] = {"ms_per_call": round(dbest * 1e3, 3), "output_GBps": round(nb / dbest / 1e9, 1),
+                                 "algorithmic_bytes": int(m + nb), "roofline_frac": round((m + nb) / dbest / 1e9 / HBM_PEAK_GBS, 5),
                                  "kernels_ms": {k: round(a / max(c, 1), 3) for k, (a, c) in dprof.items()}}
                 if "quantiser" not in pipeline and "frame_shuffle" not in pipeline:
                     res["decode"]["round_trip_equal"] = bool((back.view(torch.uint16 if np.dtype(dtype) == np.uint16 else torch.uint8).reshape(shape) == v).all().item())
@@ -259,6 +265,14 @@ def secondary_configs(dev):
     out["C3_slab 2048x2048x256 u16 diff3x3x1->bitswap1->lz4"], _ = one("diff3x3x1->bitswap1->lz4", (256, 2048, 2048), np.uint16, 2, decode=True)
     out["C4 1024x1024x1024 u8 frame_shuffle->lz4"], _ = one("frame_shuffle->lz4", (1024, 1024, 1024), np.uint8, 2, extra=1 << 16, decode=True)
     out["C5_slab 2048x2048x256 u16 quantiser->bitswap1->lz4"], _ = one("quantiser->bitswap1->lz4", (256, 2048, 2048), np.uint16, 4, decode=True)
+    # the same slabs in the layout every unchanged caller of the reference asks for (nthreads = 1: ONE block-linked LZ4 frame; the HDF5 filter
+    # and the sqy tool default to it), so that a regression of that layout shows in the line (round-4 advice)
+    for key, pipeline, apv in (("C3_slab serial layout (nthreads = 1) 2048x2048x256 u16 diff3x3x1->bitswap1->lz4", "diff3x3x1->bitswap1->lz4", 2),
+                               ("C5_slab serial layout (nthreads = 1) 2048x2048x256 u16 quantiser->bitswap1->lz4", "quantiser->bitswap1->lz4", 4)):
+        try:
+            out[key], _ = one(pipeline, (256, 2048, 2048), np.uint16, apv, reps=1, decode=True, nthreads=1)
+        except Exception as e:   # reported, never required
+            out[key] = {"error": repr(e)}
     # north_star's target on one GPU: 2048^3 uint16, bitswap1->lz4, eight sequential 2 GiB slab calls (inputs resident when each call starts)
     total_t, total_algo, total_in, slabs = 0.0, 0, 0, []
     for i in range(8):
@@ -395,6 +409,9 @@ def main():
     # rank r holds frames [r*Z, (r+1)*Z) of an (N*Z, Y, X) synthetic stack
     vol = synth.stack_torch(shape, np.uint16, dev, z_offset=rank * shape[0], z_total=world * shape[0])
     nbytes = vol.numel() * 2
+    # one copy of the input per call in flight (4 GiB of HBM at the default): no two calls of the timed region read the same addresses,
+    # so nothing the caches keep of one call's input can serve another's
+    vols = [vol] + [vol.clone() for _ in range(max(1, args.inflight) - 1)]
     cap = sqeazy_amd.max_compressed_length(PIPELINE, shape, np.uint16)
     index_rows = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(8)] if dist_on else []   # container index of the last steps
     sys.setswitchinterval(1e-4)      # caller threads hand the GIL over promptly (default 5 ms would show up as whole milliseconds per step)
@@ -418,7 +435,7 @@ def main():
 
     def prepared(t, b):
         doff, dlen = ctypes.c_long(0), ctypes.c_long(0)
-        args = (pipe_b, ctypes.c_void_p(vol.data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][b].data_ptr()), ctypes.c_long(cap),
+        args = (pipe_b, ctypes.c_void_p(vols[t].data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][b].data_ptr()), ctypes.c_long(cap),
                 ctypes.byref(doff), ctypes.byref(dlen), ctypes.c_int(0), ctypes.c_void_p(streams[t].cuda_stream))
         return args, doff, dlen
 
@@ -522,18 +539,39 @@ def main():
     def timed_blocks(gather):
         """blocks of exactly --steps steps, each fenced on both sides, max over ranks per block, until --min-seconds are timed"""
         times, payload = [], 0
+        local = []                                          # this rank's own clock per block (N > 1 diagnostics)
         while sum(times) < args.min_seconds and len(times) < 200:
             fence()
             t0 = time.perf_counter()
             payload = run_steps(args.steps, gather)
+            t_own = time.perf_counter() - t0                # up to the last step's return on THIS rank, before the closing fence
             fence()
             dt = time.perf_counter() - t0
+            local.append((t_own, dt))
             if dist_on:
                 t = torch.tensor([dt], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t.item())
             times.append(dt)
+        local_blocks[bool(gather)] = local
         return times, payload
+
+    local_blocks = {}
+
+    def per_rank_report(gather):
+        """every rank's own median ms per step (before / after the closing fence) and what RCCL says the world is, on rank 0's line:
+        makes a first real N > 1 run readable -- a slow rank, a rank that waits at the fence, a world that is not the one asked for"""
+        if not dist_on:
+            return None
+        loc = local_blocks.get(bool(gather)) or [(0.0, 0.0)]
+        mine = torch.tensor([statistics.median(a for a, _ in loc) / args.steps * 1e3, statistics.median(b for _, b in loc) / args.steps * 1e3,
+                             float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
+        allr = torch.zeros(world * 3, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(allr, mine)
+        rows = allr.reshape(world, 3).tolist()
+        return {"ms_per_step_own": [round(r[0], 4) for r in rows], "ms_per_step_fenced": [round(r[1], 4) for r in rows],
+                "device_index": [int(r[2]) for r in rows], "world_size_rccl": int(dist.get_world_size()), "backend": dist.get_backend(),
+                "world_size_env": int(os.environ.get("WORLD_SIZE", "1"))}
 
     run_steps(inflight)          # untimed priming: every caller thread's context allocates its HBM workspace once
     if args.warmup:
@@ -548,10 +586,15 @@ def main():
     # digest the reference pieces themselves give for this stack (tests/golden/headline.json: reference SSE bit-plane gather + liblz4
     # 1.9.3 frames, oracle/gen_golden.py --headline; a data file, nothing of oracle/ runs here)
     digests = []
+    timed_blob_bytes, timed_header_bytes = None, None      # of a blob of the timed region itself, read before any other leg reuses a buffer
     for t in range(inflight):
         if last_blob[t] is not None:
             b, off, n = last_blob[t]
-            digests.append(hashlib.sha256(outs[t][b][off:off + n].cpu().numpy().tobytes()).hexdigest())
+            raw = outs[t][b][off:off + n].cpu().numpy().tobytes()
+            digests.append(hashlib.sha256(raw).hexdigest())
+            if timed_blob_bytes is None:
+                timed_blob_bytes, timed_header_bytes = n, sqeazy_amd.header_size(raw[:65536])
+            del raw
     verify = {"verified": False, "blobs_hashed": len(digests), "blob_sha256": digests[0] if digests else None,
               "threads_agree": len(set(digests)) == 1}
     try:
@@ -567,10 +610,17 @@ def main():
     if "against" not in verify:
         verify["against"] = "no reference digest for this shape (only the BASELINE stack has one); threads compared with each other"
 
-    gather_times = None
+    per_rank = per_rank_report(False)
+    gather_times, gather_stats, per_rank_gather = None, None, None
     if gatherer is not None:
         run_steps(max(2, inflight), True)
+        g0 = dict(gatherer.stats)
         gather_times, _ = timed_blocks(True)
+        g1 = dict(gatherer.stats)
+        ng = max(g1["gathers"] - g0["gathers"], 1)
+        gather_stats = {"gathers_timed": g1["gathers"] - g0["gathers"], "bytes_gathered_per_step": int((g1["bytes"] - g0["bytes"]) / ng),
+                        "gather_ms_per_step": round((g1["seconds"] - g0["seconds"]) / ng * 1e3, 4)}
+        per_rank_gather = per_rank_report(True)
 
     # other operating points of the same step, for comparison with earlier rounds (round-3 advice): fewer calls in flight, and the entry
     # point that leaves the blob at the start of the destination (no frames in place: the payload is gathered)
@@ -586,10 +636,10 @@ def main():
                     dlen, doff = ctypes.c_long(0), ctypes.c_long(0)
                     for _ in range(t, args.steps, n_inflight):
                         if fn_name.endswith("DeviceAt"):
-                            rc = fn(pipe_b, ctypes.c_void_p(vol.data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][0].data_ptr()), ctypes.c_long(cap),
+                            rc = fn(pipe_b, ctypes.c_void_p(vols[t].data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][0].data_ptr()), ctypes.c_long(cap),
                                     ctypes.byref(doff), ctypes.byref(dlen), ctypes.c_int(0), ctypes.c_void_p(streams[t].cuda_stream))
                         else:
-                            rc = fn(pipe_b, ctypes.c_void_p(vol.data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][0].data_ptr()), ctypes.c_long(cap),
+                            rc = fn(pipe_b, ctypes.c_void_p(vols[t].data_ptr()), shape_c, ctypes.c_uint(3), ctypes.c_void_p(outs[t][0].data_ptr()), ctypes.c_long(cap),
                                     ctypes.byref(dlen), ctypes.c_int(0), ctypes.c_void_p(streams[t].cuda_stream))
                         if rc:
                             raise RuntimeError("%s returned %d" % (fn_name, rc))
@@ -678,8 +728,10 @@ def main():
 
     if rank == 0:
         dt = statistics.median(times)
-        hdr = sqeazy_amd.header_size(bytes(outs[0][0][single_off:single_off + 4096].cpu().numpy().tobytes()))
-        payload_bytes = payload - hdr
+        if timed_blob_bytes is None:
+            raise SystemExit("bench.py: the timed region produced no blob")
+        payload = timed_blob_bytes
+        payload_bytes = timed_blob_bytes - timed_header_bytes     # LZ4 frames only: what the path's algorithmic bytes count as written
         # dominant kernel by device time; per-launch average over every launch of the timed blocks
         dom, (dom_ms, dom_n) = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
         avg_ms = dom_ms / max(dom_n, 1)
@@ -724,10 +776,15 @@ def main():
             "entry_point": "SQYAMD_PipelineEncode_UI16_DeviceAt (device pointers; the blob may start anywhere in the destination: frames in place)",
             "build": ident,
         }
-        tr = measured_traffic(ident["sha256"], dom)
+        # launches of every kernel per encode call inside the timed region (1 each on this stack; a dense second pass would count too)
+        ncalls = max(nblocks * args.steps, 1)
+        tr = measured_traffic(ident["sha256"], dom, {k: v[1] / ncalls for k, v in prof.items()})
         if tr:
             line["roofline"]["traffic"] = tr["bytes_per_launch"]
-            line["roofline"]["traffic_all_kernels_per_call"] = tr["per_call_all_kernels"]
+            line["roofline"]["traffic_all_kernels_per_call"] = tr["per_call_all_kernels"]     # the kernels of ONE timed encode call
+            line["roofline"]["traffic_ratio"] = round(tr["per_call_all_kernels"] / algo_bytes, 4)   # HBM bytes moved / algorithmic bytes
+            if tr["kernels_missing"]:
+                line["roofline"]["traffic_kernels_missing"] = tr["kernels_missing"]
             line["roofline"]["traffic_source"] = tr["source"]
         else:
             line["roofline"]["traffic_source"] = "no rocprofv3 PMC pass of this build under profiles/ (tools/profile_run.sh)"
@@ -737,6 +794,12 @@ def main():
                                    "ms_per_step": round(gdt / args.steps * 1e3, 4), "blocks": len(gather_times),
                                    "what": "the same steps with the compressed slab of every rank gathered to rank 0 over RCCL (sizes all_gather + "
                                            "ncclSend/ncclRecv) inside the step, posted from a gather thread and overlapped with the next encodes"}
+            # the gather by itself (rank 0's gather thread: size exchange + transfers + the wait for them) and every rank's own clock
+            line["with_gather"].update(gather_stats or {})
+            line["with_gather"]["per_rank"] = per_rank_gather
+        if per_rank is not None:
+            line["per_rank"] = per_rank
+            line["world_size_rccl"] = per_rank["world_size_rccl"]
         if world == 1 and not args.quick:
             vol_host = vol.cpu().numpy()
             if not args.no_cpu_baseline:
@@ -750,6 +813,7 @@ def main():
                 line["host_abi"] = {"value": None, "error": repr(e)}
             del vol_host
             del vol
+            vols.clear()
             outs.clear()
             torch.cuda.empty_cache()
             sqeazy_amd.lib().SQYAMD_Release_Workspace()
@@ -757,6 +821,24 @@ def main():
                 line["config"]["secondary"] = secondary_configs(dev)
             except Exception as e:
                 line["config"]["secondary"] = {"error": repr(e)}
+            # north_star's own target (2048^3 uint16, bitswap1->lz4, one GPU) as a top-level key and as scalars of `config`, so that it
+            # survives a reader that keeps only the scalar fields of the line
+            sec = line["config"]["secondary"]
+            ns = {}
+            for key, short in (("ONE Slabs call from a plain C program", "one_slabs_call_plain_c"), ("ONE Slabs call (8 slabs", "one_slabs_call"),
+                               ("8 sequential", "eight_sequential_calls")):
+                for k, v in sec.items():
+                    if k.startswith("north_star") and key in k and isinstance(v, dict) and "ms_total" in v:
+                        ns[short] = {"ms_total": v["ms_total"], "input_GBps": v["input_GBps"], "roofline_frac": v["roofline_frac"],
+                                     "entry_point": v.get("entry_point", "SQYAMD_PipelineEncode_UI16_DeviceAt, one call after the other"
+                                                          if short == "eight_sequential_calls" else "SQYAMD_PipelineEncode_Slabs_UI16_Device (tools/slabs_c_test.c)")}
+            if ns:
+                best_key = max(ns, key=lambda k: ns[k]["roofline_frac"])
+                line["north_star"] = {"workload": "2048x2048x2048 uint16, bitswap1->lz4, 8 z-slabs of 2048x2048x256 on ONE MI355X, inputs resident in HBM",
+                                      "target_roofline_frac": 0.5, "best": best_key, **ns}
+                line["config"]["north_star_2048cube_ms_total"] = ns[best_key]["ms_total"]
+                line["config"]["north_star_2048cube_roofline_frac"] = ns[best_key]["roofline_frac"]
+                line["config"]["north_star_2048cube_entry_point"] = best_key
         print(json.dumps(line), flush=True)
     if dist_on:
         dist.barrier()

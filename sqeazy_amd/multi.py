@@ -94,6 +94,9 @@ class SlabGatherer:
         self.is_root = dist.get_rank(group) == root
         self.bufs = [torch.empty(int(capacity_bytes), dtype=torch.uint8, device=device) for _ in range(depth)] if self.is_root else []
         self.done = 0                    # gathers completed
+        # what the gather itself costs, for the record (bench.py's `with_gather`): wall time of gather_blobs on the gather thread
+        # incl. the wait for its transfers, and the compressed bytes of all ranks it moved
+        self.stats = {"gathers": 0, "bytes": 0, "seconds": 0.0}
         self.last = None                 # (sizes, flat view into one of the ingress buffers) of the newest completed gather, on root
         self.error = None
         self._poisoned = False
@@ -114,8 +117,17 @@ class SlabGatherer:
                 # a rank that failed keeps taking part in the size exchange with the poison value -1: its peers then raise in the
                 # same gather instead of waiting for sends that never come (until the RCCL time-out)
                 try:
+                    import time
                     dst = self.bufs[self.done % len(self.bufs)] if self.is_root else None
+                    t0 = time.perf_counter()
                     res = gather_blobs(blob, nbytes if self.error is None else -1, dst_buffer=dst, group=self.group, root=self.root)
+                    if getattr(self.device, "type", "cpu") == "cuda":
+                        # RCCL's wait() only orders the transfers on this thread's stream: the blob goes back to its encoder thread
+                        # (on_done) when they are DONE, not when they are queued
+                        torch.cuda.current_stream().synchronize()
+                    self.stats["gathers"] += 1
+                    self.stats["bytes"] += int(sum(res[0]))
+                    self.stats["seconds"] += time.perf_counter() - t0
                     if self.error is None:
                         self.last = res
                 except Exception as e:

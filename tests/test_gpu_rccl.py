@@ -113,3 +113,13 @@ def test_bench_self_spawn_and_distributed_path_on_one_gpu():
     assert "with_gather" in line and line["with_gather"]["value"] > 0          # the RCCL gather path ran
     assert line["verified"] is True and line["verification"]["threads_agree"]  # and what was timed equals the reference digest
     assert "sharded" in line["config"]["workload"] or line["n_gpus"] == 1
+    # what makes a first real N > 1 run readable: every rank's own clock, the world RCCL reports, what the
+    # gather moved per step and what it cost by itself
+    pr = line["per_rank"]
+    assert line["world_size_rccl"] == 1 and pr["world_size_rccl"] == 1 and pr["backend"] == "nccl"
+    assert len(pr["ms_per_step_own"]) == 1 and pr["ms_per_step_own"][0] > 0 and pr["ms_per_step_fenced"][0] >= pr["ms_per_step_own"][0]
+    wg = line["with_gather"]
+    assert wg["gathers_timed"] >= 3 and wg["gather_ms_per_step"] > 0
+    assert wg["bytes_gathered_per_step"] == line["config"]["blob_bytes"]           # a world of one: its own blob per step
+    assert len(wg["per_rank"]["ms_per_step_own"]) == 1
+    assert line["config"]["payload_bytes"] < line["config"]["blob_bytes"]          # (header excluded, from the timed call's own blob)
