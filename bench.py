@@ -387,6 +387,9 @@ def main():
     from sqeazy_amd import multi, synth
 
     sqeazy_amd.lib()   # fails loudly when the HIP library has not been built
+    # The caller threads' streams below carry nothing but these calls: the library may chain the bit-plane transposes of the calls in
+    # flight across them (a hipStreamWaitEvent between caller streams; off unless the caller says so, include/sqeazy_amd.h).  +3 %.
+    sqeazy_amd.set_option("transpose_chain_caller_streams", 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
 
@@ -753,6 +756,7 @@ def main():
                 ", slab blobs stay sharded on their GPUs, sizes all_gathered over RCCL" if world > 1 else ""),
                 "input_bytes_per_gpu": nbytes, "payload_bytes": payload_bytes, "blob_bytes": payload, "calls_in_flight_per_gpu": inflight,
                 "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                "options": {k: sqeazy_amd.get_option(k) for k in ("transpose_chain", "transpose_chain_caller_streams", "block_parallel")},
                 "single_call_latency_ms": round(single_ms, 4),
                 "one_call_at_a_time": {"value": round(nbytes / (single_ms / 1e3) / 1e9, 1), "unit": "GB/s",
                                        "roofline_frac_whole_call": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}},

@@ -73,9 +73,11 @@ SQY_FUNCTION_PREFIX int SQY_Pipeline_Max_Compressed_Length_3D_UI16(const char* p
 /* inc/sqeazy.h:219-243, src/sqeazy.cpp:233-268.  true iff the string parses as head filters -> sink -> tail filters
  * (src/sqeazy_pipelines.hpp:31-77) AND every stage is implemented here.  Head filters: diff3x3x1, bitswap1, bitshuffle,
  * raster_reorder, tile_shuffle, frame_shuffle, zcurve_reorder; sinks: pass_through, quantiser (16-bit input; every
- * weighting_function with a finite exponent, decode_lut_path), lz4 (accel 1 or 2); tail filters on the sink's bytes: bitswap1,
- * bitshuffle, lz4.  false where the reference says true: the background filters (remove_background, rmbkrd_neighbor5x5x5,
- * rmestbkrd), the video sinks, and diff3x3x1 / raster_reorder / tile_shuffle / frame_shuffle / zcurve_reorder as TAIL filters. */
+ * weighting_function with a finite exponent, decode_lut_path), lz4 (accel <= 2, negative = liblz4's acceleration; last stage);
+ * tail filters on the sink's `char` stream: diff3x3x1, bitswap1, bitshuffle, lz4, raster_reorder, tile_shuffle, frame_shuffle,
+ * zcurve_reorder -- the reference's whole list but the video codecs.  false where the reference says true: the background filters
+ * (remove_background, rmbkrd_neighbor5x5x5, rmestbkrd), the video sinks / filters (h264, hevc), lz4 with accel >= 3 (LZ4HC),
+ * stages behind an lz4 sink.  (A geometry the reference leaves undefined for a stage is refused at encode time: error 1.) */
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI16(const char* pipeline_string);
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible_UI8(const char* pipeline_string);
 SQY_FUNCTION_PREFIX bool SQY_Pipeline_Possible(const char* pipeline_string, int sizeofpixel);
@@ -179,6 +181,21 @@ SQY_FUNCTION_PREFIX const char* SQYAMD_Profile_Get(int i, double* total_ms, long
 
 /* release the cached HBM workspace of the current device */
 SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
+
+/* Run-time options (measurement / test switches; none changes a byte of any result).  The environment is read once, when the
+ * library is loaded (the names in brackets); afterwards only these two calls change / read them -- thread safe.
+ *   "transpose_chain"                 1 [SQY_NO_TRANSPOSE_CHAIN=1 -> 0]  the bit-plane transposes of calls in flight on streams the
+ *                                     LIBRARY owns (host-pointer entry points, the Slabs workers) run one after the other
+ *   "transpose_chain_caller_streams"  0 [SQY_TRANSPOSE_CHAIN_CALLER_STREAMS=1]  .. on streams the CALLER brings as well.  This puts a
+ *                                     hipStreamWaitEvent between two caller streams: only for callers whose streams carry nothing but
+ *                                     these calls (a backlog or a host function on one stream would hold the other up)
+ *   "block_parallel"                  1 [SQY_NO_BLOCK_PARALLEL=1 -> 0]  block-linked frames (nthreads = 1) encoded / decoded block-parallel
+ *   "block_parallel_warmup"           65536 [SQY_BLOCK_PARALLEL_WARMUP=<bytes>, 0 .. 2^30]  stream parsed in front of a block to guess its table
+ *   "block_parallel_stats"            0 [SQY_BLOCK_PARALLEL_STATS=1]  print the blocks whose guess failed
+ *   "tail_scan"                       1 [SQY_NO_TAIL_SCAN=1 -> 0]  serial-layout decode: the walk over the block tails as a scan
+ * Set: 0 = done, 1 = unknown name or value out of range.  Get: the value, -1 for an unknown name. */
+SQY_FUNCTION_PREFIX int SQYAMD_Set_Option(const char* name, long value);
+SQY_FUNCTION_PREFIX long SQYAMD_Get_Option(const char* name);
 
 /* Header helpers for callers that store blobs in containers of their own (the HDF5 filter's cd_values carry a header:
  * inc/sqeazy_h5_filter.hpp:117-121, src/hdf5_utils.hpp:730-738).  The reference does this through its C++ header class

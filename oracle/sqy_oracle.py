@@ -462,13 +462,18 @@ def zcurve_reorder(a, tile_size=2, decode=False):
     return out.reshape(a.shape)
 
 
-def tile_shuffle_encode(a, tile_size=32):
+def tile_shuffle_encode(a, tile_size=32, char=False):
     """detail::tile_shuffle::encode_full (encoders/tile_shuffle_utils.hpp:104-224): tiles of tile^3 voxels, the metric of a
     tile is its SEQUENTIAL binary32 sum divided by the voxel count and CONVERTED TO THE VOXEL TYPE, tiles are appended in the
     order of the sorted metrics, slot i taking the FIRST tile whose metric equals sorted[i] (tiles with equal metrics all map
     to the first of them).  Shapes with a remainder take the reference's encode_with_remainder (Boost P^2 median over tiles
-    read past their end, a thread-timing dependent map): not restated.  returns (volume-shaped output, decode_map)"""
+    read past their end, a thread-timing dependent map): not restated.  returns (volume-shaped output, decode_map)
+    char=True: the tail filter form, tile_shuffle_scheme<char> on the sink's stream -- the sum adds SIGNED bytes and the metric is a
+    (signed) char: `in_value_t` is char in :176-190, the float quotient converts to it by truncation and std::sort orders chars."""
     a = np.ascontiguousarray(a)
+    if char:
+        out, dmap = tile_shuffle_encode(a.view(np.int8), tile_size)
+        return out.view(a.dtype), dmap
     ts = int(tile_size)
     if a.ndim != 3 or ts <= 0 or any(d % ts for d in a.shape) or any(d < ts for d in a.shape):
         raise ValueError("tile_shuffle: only shapes that are whole multiples of the tile are restated")
@@ -720,7 +725,8 @@ def header_pack(dtype, shape, pipename, payload_bytes, version=SQY_VERSION, head
               '        "headref": %s' % q(headref),
               "    }",
               "}"]
-    text = ("\n".join(lines) + "\n").encode("ascii") + HEADER_END
+    # (latin-1: one byte per character -- Boost's writer passes bytes >= 0x80 through as they are, tests/test_header_tag_impl.cpp:87)
+    text = ("\n".join(lines) + "\n").encode("latin-1") + HEADER_END
     if len(text) % dtype.itemsize:
         text = b" " * (dtype.itemsize - len(text) % dtype.itemsize) + text
     return text
@@ -733,7 +739,7 @@ def header_unpack(blob):
     pos = blob.find(HEADER_END)
     if pos < 0:
         raise ValueError("no sqy header")
-    text = blob[:pos].decode("ascii")
+    text = blob[:pos].decode("latin-1")
 
     dims = []
 
@@ -810,9 +816,12 @@ def pipeline_name(stages):
 def build_stages(pipeline, dtype=None):
     stages = [_Stage(n, c) for n, c in parse_pairs(pipeline)]
     if dtype is not None:
-        for s in stages:                                     # defaults that depend on the voxel type
+        seen_sink = False
+        for s in stages:                                     # defaults that depend on the voxel type (behind the sink: char)
             if s.name == "raster_reorder" and s.tile is None:
-                s.tile = 16 // np.dtype(dtype).itemsize
+                s.tile = 16 // (1 if seen_sink else np.dtype(dtype).itemsize)
+            if s.name in SINKS:
+                seen_sink = True
     return stages
 
 
@@ -845,6 +854,13 @@ def pipeline_encode(pipeline, vol, nthreads=2):
     cur = vol
     seen_sink = False
     payload = None
+
+    def tail_view(x):
+        """what a 3-D tail filter sees (dynamic_pipeline.hpp:658-666): the sink's char stream in the volume's shape when the sink wrote
+        one byte per voxel, else {1, 1, bytes}"""
+        x = np.ascontiguousarray(x).reshape(-1).view(np.uint8)
+        return x.reshape(vol.shape) if x.size == vol.size else x.reshape(1, 1, -1)
+
     for s in stages:
         is_sink = (not seen_sink) and s.name in SINKS
         if s.name == "bitswap1":
@@ -852,17 +868,19 @@ def pipeline_encode(pipeline, vol, nthreads=2):
         elif s.name == "diff3x3x1":
             # behind a sink the stream is `char`; it keeps the volume's shape only when the sink wrote one byte per voxel
             # (dynamic_pipeline.hpp:658-666: otherwise {1, 1, bytes}, which diff3x3x1 cannot take)
-            if seen_sink and cur.shape != vol.shape:
-                raise ValueError("diff3x3x1: shape outside the reference's defined behaviour")
+            if seen_sink:
+                cur = tail_view(cur)
+                if cur.shape != vol.shape:
+                    raise ValueError("diff3x3x1: shape outside the reference's defined behaviour")
             cur = diff3x3x1_encode(cur, char=seen_sink)
         elif s.name == "frame_shuffle":
-            if seen_sink and cur.shape != vol.shape:
-                cur = cur.reshape(1, 1, -1)
+            if seen_sink:
+                cur = tail_view(cur)
             cur, dmap = frame_shuffle_encode(cur, char=seen_sink, chunk=s.chunk)
             s.map = to_verbatim(dmap)
         elif s.name == "raster_reorder":
-            if seen_sink:
-                raise NotImplementedError("raster_reorder as a tail filter is not restated")
+            if seen_sink:                      # raster_reorder_scheme<char> (sqeazy_pipelines.hpp:64-77): a pure reorder of bytes
+                cur = tail_view(cur)
             if s.tile is None:
                 s.tile = 16 // cur.dtype.itemsize
             cur = raster_reorder(cur, s.tile)
@@ -870,12 +888,12 @@ def pipeline_encode(pipeline, vol, nthreads=2):
             cur = np.ascontiguousarray(cur).reshape(-1).view(np.uint8)     # pass_through_scheme_impl.hpp:66-79: a copy, re-typed to bytes
         elif s.name == "zcurve_reorder":
             if seen_sink:
-                raise NotImplementedError("zcurve_reorder as a tail filter is not restated")
+                cur = tail_view(cur)
             cur = zcurve_reorder(cur, s.tile)
         elif s.name == "tile_shuffle":
             if seen_sink:
-                raise NotImplementedError("tile_shuffle as a tail filter is not restated")
-            cur, dmap = tile_shuffle_encode(cur, s.tile)
+                cur = tail_view(cur)
+            cur, dmap = tile_shuffle_encode(cur, s.tile, char=seen_sink)
             s.map = to_verbatim(dmap)
         elif s.name == "bitshuffle":
             cur = bitshuffle(cur, s.block)
@@ -906,6 +924,11 @@ def pipeline_decode(blob):
     n = int(np.prod(h["shape"]))
     sink_idx = next((i for i, s in enumerate(stages) if s.name in SINKS), None)
     cur = body
+
+    def tail_view(x):
+        x = np.ascontiguousarray(x).reshape(-1).view(np.uint8)
+        return x.reshape(h["shape"]) if x.size == n else x.reshape(1, 1, -1)
+
     # tail filters^-1 then sink^-1 then head filters^-1
     order = list(range(len(stages)))[::-1]
     cur_dtype = np.uint8
@@ -937,16 +960,16 @@ def pipeline_decode(blob):
                 dec = np.frombuffer(base64.b64decode(lut), dtype=dtype)
             cur = dec[np.ascontiguousarray(cur).view(np.uint8)]
         elif s.name == "raster_reorder":
-            cur = raster_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
+            cur = raster_reorder(tail_view(cur) if after_sink else np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
         elif s.name == "pass_through":
             pass
         elif s.name == "zcurve_reorder":
-            cur = zcurve_reorder(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
+            cur = zcurve_reorder(tail_view(cur) if after_sink else np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), s.tile, decode=True)
         elif s.name == "tile_shuffle":
             import base64
             m = s.map[len("<verbatim>"):-len("</verbatim>")]
             dmap = np.frombuffer(base64.b64decode(m), dtype=np.uint64)
-            cur = tile_shuffle_decode(np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), dmap, s.tile)
+            cur = tile_shuffle_decode(tail_view(cur) if after_sink else np.ascontiguousarray(cur).view(dtype).reshape(h["shape"]), dmap, s.tile)
         elif s.name == "bitshuffle":
             t = np.uint8 if after_sink else dtype
             cur = bitshuffle(np.ascontiguousarray(cur).view(t), s.block, decode=True)
@@ -955,8 +978,7 @@ def pipeline_decode(blob):
             m = s.map[len("<verbatim>"):-len("</verbatim>")]
             dmap = np.frombuffer(base64.b64decode(m), dtype=np.uint64)
             if after_sink:
-                v = np.ascontiguousarray(cur).view(np.uint8)
-                v = v.reshape(h["shape"]) if v.size == n else v.reshape(1, 1, -1)
+                v = tail_view(cur)
             else:
                 v = np.ascontiguousarray(cur).view(dtype).reshape(h["shape"])
             # (frames with equal metrics: the map names one frame several times and others not at all -- those the reference leaves as

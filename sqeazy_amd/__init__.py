@@ -30,7 +30,7 @@ EXPORTED_SYMBOLS = (
     "SQYAMD_PipelineEncode_UI16_Cap", "SQYAMD_PipelineEncode_UI8_Cap",
     "SQYAMD_Decode_UI16_Device", "SQYAMD_Decode_UI8_Device",
     "SQYAMD_Profile_Enable", "SQYAMD_Profile_Reset", "SQYAMD_Profile_Get",
-    "SQYAMD_Release_Workspace", "SQYAMD_Version", "SQYAMD_Header_Pipeline", "SQYAMD_Header_Build",
+    "SQYAMD_Release_Workspace", "SQYAMD_Set_Option", "SQYAMD_Get_Option", "SQYAMD_Version", "SQYAMD_Header_Pipeline", "SQYAMD_Header_Build",
     "SQYAMD_Comm_UniqueId", "SQYAMD_Comm_Init", "SQYAMD_Comm_Destroy", "SQYAMD_Gather_Blobs",
 )
 
@@ -60,6 +60,9 @@ def lib():
         L.SQY_Pipeline_Possible_UI8.restype = ctypes.c_bool
         L.SQY_Pipeline_Possible.restype = ctypes.c_bool
         L.SQYAMD_Version.restype = ctypes.c_char_p
+        L.SQYAMD_Set_Option.argtypes = [ctypes.c_char_p, ctypes.c_long]
+        L.SQYAMD_Get_Option.argtypes = [ctypes.c_char_p]
+        L.SQYAMD_Get_Option.restype = ctypes.c_long
         L.SQYAMD_Profile_Get.restype = ctypes.c_char_p
         L.SQYAMD_Profile_Get.argtypes = [ctypes.c_int, ctypes.POINTER(ctypes.c_double), c_long_p]
         for f in ("SQY_PipelineEncode_UI8", "SQY_PipelineEncode_UI16"):
@@ -245,6 +248,32 @@ def decode(blob, nthreads=0):
     src = np.frombuffer(blob, dtype=np.uint8)
     rc = getattr(lib(), "SQY_Decode_" + _suffix(dtype))(src.ctypes.data, ctypes.c_long(len(blob)), out.ctypes.data, ctypes.c_int(nthreads))
     return (rc, None) if rc else (0, out)
+
+
+def set_option(name, value):
+    """SQYAMD_Set_Option (run-time switches, include/sqeazy_amd.h); raises on an unknown name / a value out of range"""
+    if lib().SQYAMD_Set_Option(name.encode(), ctypes.c_long(int(value))):
+        raise ValueError("SQYAMD_Set_Option(%r, %r) refused" % (name, value))
+
+
+def get_option(name):
+    return int(lib().SQYAMD_Get_Option(name.encode()))
+
+
+class option:
+    """with sqeazy_amd.option("block_parallel", 0): ...  -- the option for the duration of the block (process-wide)"""
+
+    def __init__(self, name, value):
+        self.name, self.value = name, value
+
+    def __enter__(self):
+        self.old = get_option(self.name)
+        set_option(self.name, self.value)
+        return self
+
+    def __exit__(self, *exc):
+        set_option(self.name, self.old)
+        return False
 
 
 def profile_enable(on=True):

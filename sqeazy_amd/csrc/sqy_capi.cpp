@@ -41,6 +41,49 @@ using sqy::StageKind;
         }                                                                                               \
     } while (0)
 
+// ---- run-time options ------------------------------------------------------------------------------
+// Measurement / test switches.  The environment is read ONCE, when the library is loaded (getenv in the middle of a call races with
+// setenv from other host threads); afterwards they change only through SQYAMD_Set_Option (atomics).  None of them changes a byte of
+// any result.
+long env_flag(const char* name) { const char* v = std::getenv(name); return v && *v && std::strcmp(v, "0") != 0 ? 1 : 0; }
+long env_number(const char* name, long dflt, long lo, long hi)
+{
+    const char* v = std::getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = nullptr;
+    const long long x = std::strtoll(v, &end, 10);
+    if (*end != '\0' || x < lo || x > hi) {
+        std::fprintf(stderr, "[sqeazy]\t %s=%s is not a number in [%ld, %ld]: ignored\n", name, v, lo, hi);
+        return dflt;
+    }
+    return (long)x;
+}
+constexpr long kWarmupMax = 1l << 30;
+struct Options {
+    std::atomic<long> transpose_chain;                  // the bit-plane transposes of calls in flight on LIBRARY-OWNED streams run one after the other
+    std::atomic<long> transpose_chain_caller_streams;   // .. on streams the callers bring as well (opt-in: couples those streams, see the bitswap1 stage)
+    std::atomic<long> block_parallel;                   // block-linked frames: block-parallel encode and decode (0: the one-wavefront walk)
+    std::atomic<long> block_parallel_warmup;            // bytes parsed in front of a block to guess its table
+    std::atomic<long> block_parallel_stats;             // print the blocks that failed the table check
+    std::atomic<long> tail_scan;                        // serial-layout decode: the walk over the tails as a scan
+    Options()
+        : transpose_chain(env_flag("SQY_NO_TRANSPOSE_CHAIN") ? 0 : 1), transpose_chain_caller_streams(env_flag("SQY_TRANSPOSE_CHAIN_CALLER_STREAMS")),
+          block_parallel(env_flag("SQY_NO_BLOCK_PARALLEL") ? 0 : 1), block_parallel_warmup(env_number("SQY_BLOCK_PARALLEL_WARMUP", 65536, 0, kWarmupMax)),
+          block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1) {}
+    std::atomic<long>* find(const char* name)
+    {
+        if (!name) return nullptr;
+        if (!std::strcmp(name, "transpose_chain")) return &transpose_chain;
+        if (!std::strcmp(name, "transpose_chain_caller_streams")) return &transpose_chain_caller_streams;
+        if (!std::strcmp(name, "block_parallel")) return &block_parallel;
+        if (!std::strcmp(name, "block_parallel_warmup")) return &block_parallel_warmup;
+        if (!std::strcmp(name, "block_parallel_stats")) return &block_parallel_stats;
+        if (!std::strcmp(name, "tail_scan")) return &tail_scan;
+        return nullptr;
+    }
+};
+Options g_opt;
+
 // ---- per-kernel timing -------------------------------------------------------------------------
 struct ProfEntry { std::string name; double ms = 0; long launches = 0; };
 struct PendingEvent { const char* name; hipEvent_t a, b; };
@@ -377,6 +420,14 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
         return static_cast<uint8_t*>(b.p);
     };
 
+    // the shape a 3-D stage sees: the volume's -- or, behind a sink that did not write one byte per voxel, {1, 1, bytes}
+    // (dynamic_pipeline.hpp:658-666: the tail chain's "sinked_shape")
+    auto stage_shape = [&](size_t si, uint64_t& Z, uint64_t& Y, uint64_t& X) {
+        const bool tail = pipe.sink_index >= 0 && (int)si > pipe.sink_index;
+        const bool flat = tail && cur_len * (uint64_t)cur_elem != len;
+        Z = flat ? 1 : dims[0]; Y = flat ? 1 : dims[1]; X = flat ? cur_len : dims[2];
+    };
+
     uint64_t payload_bytes = 0;
     bool payload_is_lz4 = false;
     const sqy::Lz4Params* lz4p = nullptr;
@@ -446,11 +497,16 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 // transpose of the call in front before it starts its own.  Two HBM-bound kernels side by side each run at half speed
                 // and end together; chained, the first call's parse starts a whole transpose earlier (bench, four calls in flight:
                 // +3 %; also chaining the duplicate search behind it: -12 %, measured and not kept).  Only a transpose launched within
-                // the last few milliseconds is waited for, so that a caller whose stream is stuck behind other work holds nobody up for
-                // long; SQY_NO_TRANSPOSE_CHAIN=1 in the environment switches the chain off.
-                static const bool tchain = std::getenv("SQY_NO_TRANSPOSE_CHAIN") == nullptr;
+                // the last few milliseconds is waited for.  The chain is an edge between streams: by default only streams this library
+                // owns (the host-pointer entry points, the Slabs workers) are chained -- a stream the CALLER brings may carry work this
+                // library knows nothing about (a backlog, a host function that waits for another of the caller's threads), and a hidden
+                // wait on it would couple calls that are documented as independent (round-4 advice).  A caller whose streams carry
+                // nothing but these calls opts in: SQYAMD_Set_Option("transpose_chain_caller_streams", 1) (bench.py does, and says so).
+                // "transpose_chain" = 0 (or SQY_NO_TRANSPOSE_CHAIN=1 when the library is loaded) switches the chain off altogether.
+                const bool owned = stream != nullptr && stream == cx.stream;
                 int devid = 0;
-                const bool chain = tchain && gap_chunk && hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < kMaxDev;
+                const bool chain = g_opt.transpose_chain.load() && (owned || g_opt.transpose_chain_caller_streams.load()) && gap_chunk &&
+                                   hipGetDevice(&devid) == hipSuccess && devid >= 0 && devid < kMaxDev;
                 std::unique_lock<std::mutex> tlock;
                 if (chain) {
                     if (!cx.t_done && hipEventCreateWithFlags(&cx.t_done, hipEventDisableTiming) != hipSuccess) return 1;
@@ -483,16 +539,20 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     return 1;
                 }
                 const uint64_t ts = (uint64_t)std::atoi(st.cfg["tile_size"].c_str());
-                if (!sqy::raster_geometry_defined(dims[0], dims[1], dims[2], ts, cur_elem)) {
+                // (round 5) as a tail filter the stream is the sink's `char` output: the volume's shape when that is one byte per voxel,
+                // else {1, 1, bytes} (dynamic_pipeline.hpp:658-666; sqeazy_pipelines.hpp:64-77 lists the stage for the tail chain)
+                uint64_t Z, Y, X;
+                stage_shape(si, Z, Y, X);
+                if (!sqy::raster_geometry_defined(Z, Y, X, ts, cur_elem)) {
                     std::fprintf(stderr, "[sqeazy]\t raster_reorder: the reference's result is undefined for shape %llux%llux%llu at tile_size=%llu "
                                          "(remainder in some dimensions only, or a tile wider than one 16-byte block); refused\n",
-                                 (unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2], (unsigned long long)ts);
+                                 (unsigned long long)Z, (unsigned long long)Y, (unsigned long long)X, (unsigned long long)ts);
                     return 1;
                 }
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
                 ProfScope ps("raster_reorder", stream, pend);
-                SQY_HIP(sqy::launch_raster_reorder(cur, out, dims[0], dims[1], dims[2], ts, cur_elem, false, stream));
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, Z, Y, X, ts, cur_elem, false, stream));
                 cur = out;
                 break;
             }
@@ -509,17 +569,19 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 }
                 auto t = st.cfg.find("tile_size");
                 const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 2;
-                if (!sqy::zcurve_geometry_defined(dims[0], dims[1], dims[2], ts)) {
+                uint64_t Z, Y, X;
+                stage_shape(si, Z, Y, X);                                  // (tail filter: the sink's char stream, see raster_reorder)
+                if (!sqy::zcurve_geometry_defined(Z, Y, X, ts)) {
                     std::fprintf(stderr, "[sqeazy]\t zcurve_reorder: the reference's result is undefined for shape %llux%llux%llu at tile_size=%llu "
                                          "(tile sizes other than 2..128 powers of two, or a tile that does not divide a power-of-two shape); refused\n",
-                                 (unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2], (unsigned long long)ts);
+                                 (unsigned long long)Z, (unsigned long long)Y, (unsigned long long)X, (unsigned long long)ts);
                     return 1;
                 }
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
                 ProfScope ps("zcurve_reorder", stream, pend);
                 // (inside a tile the reference's morton_at_ct<log2(tile)> code is row-major: the tiled raster kernel is the stage)
-                SQY_HIP(sqy::launch_raster_reorder(cur, out, dims[0], dims[1], dims[2], ts, cur_elem, false, stream));
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, Z, Y, X, ts, cur_elem, false, stream));
                 cur = out;
                 break;
             }
@@ -541,10 +603,14 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 }
                 auto t = st.cfg.find("tile_size");
                 const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 32;
-                if (!sqy::tile_shuffle_geometry_defined(dims[0], dims[1], dims[2], ts)) {
+                // (tail filter: tile_shuffle_scheme<char> on the sink's stream -- the tile sums add SIGNED bytes and the metric is a char)
+                const bool tail = pipe.sink_index >= 0 && (int)si > pipe.sink_index;
+                uint64_t Z, Y, X;
+                stage_shape(si, Z, Y, X);
+                if (!sqy::tile_shuffle_geometry_defined(Z, Y, X, ts)) {
                     std::fprintf(stderr, "[sqeazy]\t tile_shuffle: shape %llux%llux%llu is not a whole multiple of tile_size=%llu; the reference's remainder "
                                          "path (P^2 median over tiles read past their end, thread-timing dependent map) is not reproduced; refused\n",
-                                 (unsigned long long)dims[0], (unsigned long long)dims[1], (unsigned long long)dims[2], (unsigned long long)ts);
+                                 (unsigned long long)Z, (unsigned long long)Y, (unsigned long long)X, (unsigned long long)ts);
                     return 1;
                 }
                 const uint64_t per_tile = ts * ts * ts, ntiles = cur_len / per_tile, tile_bytes = per_tile * (uint64_t)cur_elem;
@@ -553,7 +619,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 if (!tiled) return 1;
                 {
                     ProfScope ps("tile_gather", stream, pend);
-                    SQY_HIP(sqy::launch_raster_reorder(cur, tiled, dims[0], dims[1], dims[2], ts, cur_elem, false, stream));
+                    SQY_HIP(sqy::launch_raster_reorder(cur, tiled, Z, Y, X, ts, cur_elem, false, stream));
                 }
                 if (ws->small.ensure(std::max<uint64_t>(ntiles * 16, 4096))) return 1;
                 float* d_sums = static_cast<float*>(ws->small.p);
@@ -562,13 +628,13 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     const uint64_t fm_bytes = sqy::frame_metric_scratch_bytes(ntiles, per_tile, cur_elem);
                     if (ws->lz4_scratch.ensure(std::max<uint64_t>(fm_bytes, 16))) return 1;
                     ProfScope ps("tile_metric", stream, pend);
-                    SQY_HIP(sqy::launch_frame_metric(tiled, ntiles, per_tile, cur_elem, d_sums, stream, ws->lz4_scratch.p, fm_bytes));
+                    SQY_HIP(sqy::launch_frame_metric(tiled, ntiles, per_tile, cur_elem, d_sums, stream, ws->lz4_scratch.p, fm_bytes, tail));
                 }
                 std::vector<float> sums(ntiles);
                 std::vector<uint64_t> map(ntiles);
                 SQY_HIP(hipMemcpyAsync(sums.data(), d_sums, ntiles * sizeof(float), hipMemcpyDeviceToHost, stream));
                 SQY_HIP(hipStreamSynchronize(stream));
-                sqy::tile_shuffle_order(sums.data(), ntiles, per_tile, cur_elem, map.data());
+                sqy::tile_shuffle_order(sums.data(), ntiles, per_tile, cur_elem, map.data(), tail);
                 SQY_HIP(hipMemcpyAsync(d_map, map.data(), ntiles * sizeof(uint64_t), hipMemcpyHostToDevice, stream));
                 uint8_t* out = next_buf(cur_len * cur_elem);
                 if (!out) return 1;
@@ -861,9 +927,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     // measurement / test knobs: SQY_NO_BLOCK_PARALLEL (the frame walk of rounds 2-3), SQY_BLOCK_PARALLEL_WARMUP = bytes
                     // of warm-up in front of a block (default and liblz4's reach: 64 KiB; less makes the guess fail more often --
                     // the result stays exact, the blocks that fail are parsed again)
-                    const bool spec_off = std::getenv("SQY_NO_BLOCK_PARALLEL") != nullptr;
-                    uint64_t warmup = 65536;
-                    if (const char* wv = std::getenv("SQY_BLOCK_PARALLEL_WARMUP")) warmup = std::strtoull(wv, nullptr, 10);
+                    const bool spec_off = g_opt.block_parallel.load() == 0;
+                    const uint64_t warmup = (uint64_t)g_opt.block_parallel_warmup.load();
                     const uint64_t list_bytes = nblocks * sizeof(uint32_t);
                     // (without room for the tables -- 32 KiB per block -- the walk, which needs none)
                     if (!spec_off && longest >= 3 && nframes < 1024 && !ws->spec.ensure(nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t) + 3 * list_bytes)) {
@@ -904,7 +969,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                 wfirst[nruns] = (uint32_t)k; wlast[nruns] = (uint32_t)e; ++nruns;
                                 k = e;
                             }
-                            if (std::getenv("SQY_BLOCK_PARALLEL_STATS")) {
+                            if (g_opt.block_parallel_stats.load()) {
                                 uint64_t nbad = 0;
                                 for (uint64_t r = 0; r < nruns; ++r) nbad += wlast[r] - wfirst[r] + 1;
                                 std::fprintf(stderr, "[sqeazy]\t lz4 block-parallel: round %llu, %llu of %llu blocks to parse again in %llu runs",
@@ -1229,6 +1294,13 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
         return static_cast<uint8_t*>(b.p);
     };
 
+    // the shape a 3-D stage saw on the encoder's side (h.shape.size() == 3 checked by the caller): the volume's, or {1, 1, bytes} behind
+    // a sink that did not write one byte per voxel (dynamic_pipeline.hpp:658-666)
+    auto stage_shape = [&](size_t si, uint64_t n_in, uint64_t& Z, uint64_t& Y, uint64_t& X) {
+        const bool flat = sink_index >= 0 && (int)si > sink_index && n_in != n;
+        Z = flat ? 1 : h.shape[0]; Y = flat ? 1 : h.shape[1]; X = flat ? n_in : h.shape[2];
+    };
+
     for (size_t si = pipe.stages.size(); si-- > 0;) {
         const Stage& st = pipe.stages[si];
         const int e_in = elem_before[si];                                       // element size on the ENCODER's input side of this stage
@@ -1287,7 +1359,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 // ONE block-linked frame (nthreads = 1 on the encoder's side): every block at once with the history as an unknown, the
                 // references resolved afterwards (sqy_kernels.hip: lz4_blocks_decode_sym_kernel).  A stream that is not a frame of
                 // full blocks, or is damaged, raises the flag: the one-wavefront walk below then decides, as in rounds 2-3.
-                if (nframes == 1 && !std::getenv("SQY_NO_BLOCK_PARALLEL") && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes) &&
+                if (nframes == 1 && g_opt.block_parallel.load() && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes) &&
                     !ws->spec.ensure(((total * sizeof(uint16_t) + 255) & ~(uint64_t)255) + sqy::lz4_linked_decode_scan_scratch_bytes(hc[1]))) {
                     // (no room for the references: the walk needs none)
                     hipError_t le;
@@ -1295,7 +1367,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                         ProfScope ps("lz4_linked_decode", stream, pend);
                         uint8_t* scan = static_cast<uint8_t*>(ws->spec.p) + ((total * sizeof(uint16_t) + 255) & ~(uint64_t)255);
                         le = sqy::launch_lz4_linked_decode_parallel(cur, blk, hc[1], out, static_cast<uint16_t*>(ws->spec.p), total, block_bytes,
-                                                                    counts + 4, stream, std::getenv("SQY_NO_TAIL_SCAN") ? nullptr : scan);
+                                                                    counts + 4, stream, g_opt.tail_scan.load() ? scan : nullptr);
                     }
                     if (le != hipSuccess) (void)hipGetLastError();                    // (e.g. no 128 KiB of LDS for the tails: the walk below)
                     SQY_HIP(hipMemcpyAsync(&bad, counts + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
@@ -1357,14 +1429,16 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (h.shape.size() != 3) return 1;
                 auto t = st.cfg.find("tile_size");
                 const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 0;
-                if (!sqy::raster_geometry_defined(h.shape[0], h.shape[1], h.shape[2], ts, e_in)) {
+                uint64_t Z, Y, X;
+                stage_shape(si, n_in, Z, Y, X);                              // (tail filter: the sink's char stream)
+                if (!sqy::raster_geometry_defined(Z, Y, X, ts, e_in)) {
                     std::fprintf(stderr, "[sqeazy]\t raster_reorder: tile_size %llu does not fit the shape\n", (unsigned long long)ts);
-                    return 1;
+                    return stage_error(si);
                 }
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 ProfScope ps("raster_reorder_decode", stream, pend);
-                SQY_HIP(sqy::launch_raster_reorder(cur, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, Z, Y, X, ts, e_in, true, stream));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }
@@ -1374,14 +1448,16 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (h.shape.size() != 3) return stage_error(si);
                 auto t = st.cfg.find("tile_size");
                 const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 2;
-                if (!sqy::zcurve_geometry_defined(h.shape[0], h.shape[1], h.shape[2], ts)) {
+                uint64_t Z, Y, X;
+                stage_shape(si, n_in, Z, Y, X);
+                if (!sqy::zcurve_geometry_defined(Z, Y, X, ts)) {
                     std::fprintf(stderr, "[sqeazy]\t zcurve_reorder: tile_size %llu does not fit the shape\n", (unsigned long long)ts);
                     return stage_error(si);
                 }
                 uint8_t* out = out_buf(si, stage_in_bytes);
                 if (!out) return 1;
                 ProfScope ps("zcurve_reorder_decode", stream, pend);
-                SQY_HIP(sqy::launch_raster_reorder(cur, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                SQY_HIP(sqy::launch_raster_reorder(cur, out, Z, Y, X, ts, e_in, true, stream));
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
             }
@@ -1401,12 +1477,14 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (h.shape.size() != 3) return stage_error(si);
                 auto t = st.cfg.find("tile_size");
                 const uint64_t ts = t != st.cfg.end() ? (uint64_t)std::atoi(t->second.c_str()) : 32;
-                if (!sqy::tile_shuffle_geometry_defined(h.shape[0], h.shape[1], h.shape[2], ts)) {
+                uint64_t Z, Y, X;
+                stage_shape(si, n_in, Z, Y, X);
+                if (!sqy::tile_shuffle_geometry_defined(Z, Y, X, ts)) {
                     std::fprintf(stderr, "[sqeazy]\t tile_shuffle: tile_size %llu does not divide the shape\n", (unsigned long long)ts);
                     return stage_error(si);
                 }
                 auto it = st.cfg.find("reorder_map");
-                const uint64_t per_tile = ts * ts * ts, ntiles = n / per_tile, tile_bytes = per_tile * (uint64_t)e_in;
+                const uint64_t per_tile = ts * ts * ts, ntiles = n_in / per_tile, tile_bytes = per_tile * (uint64_t)e_in;
                 if (it == st.cfg.end() || it->second.size() < 21) { std::fprintf(stderr, "[sqeazy]\t tile_shuffle: no reorder_map in the header\n"); return stage_error(si); }
                 const std::vector<unsigned char> mapb = sqy::base64_decode(it->second.substr(10, it->second.size() - 21));
                 if (mapb.size() != ntiles * 8) { std::fprintf(stderr, "[sqeazy]\t tile_shuffle: malformed reorder_map\n"); return stage_error(si); }
@@ -1432,7 +1510,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 if (!out) return 1;
                 {
                     ProfScope ps("tile_scatter", stream, pend);
-                    SQY_HIP(sqy::launch_raster_reorder(tb.p, out, h.shape[0], h.shape[1], h.shape[2], ts, e_in, true, stream));
+                    SQY_HIP(sqy::launch_raster_reorder(tb.p, out, Z, Y, X, ts, e_in, true, stream));
                 }
                 cur = out; cur_bytes = stage_in_bytes;
                 break;
@@ -1940,6 +2018,22 @@ const char* SQYAMD_Profile_Get(int i, double* total_ms, long* launches)
     if (total_ms) *total_ms = g_prof[i].ms;
     if (launches) *launches = g_prof[i].launches;
     return g_prof[i].name.c_str();
+}
+
+int SQYAMD_Set_Option(const char* name, long value)
+{
+    std::atomic<long>* o = g_opt.find(name);
+    if (!o) return 1;
+    if (o == &g_opt.block_parallel_warmup) { if (value < 0 || value > kWarmupMax) return 1; }
+    else if (value != 0 && value != 1) return 1;
+    o->store(value);
+    return 0;
+}
+
+long SQYAMD_Get_Option(const char* name)
+{
+    std::atomic<long>* o = g_opt.find(name);
+    return o ? o->load() : -1;
 }
 
 void SQYAMD_Release_Workspace(void)

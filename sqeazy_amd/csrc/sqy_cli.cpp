@@ -9,8 +9,10 @@
 //   sqy bench      [-p pipeline] [-r repetitions] [-c] [--noheader] [--comment text] stack.tif ...
 //
 // Differences, all forced by the hardware behind the library:
-//   * -n/--nthreads defaults to 1 like the reference (src/sqy.cpp:190): ONE block-linked LZ4 frame, walked by a single
-//     wavefront on the GPU -- bit-identical to the reference's default output, but slow; pass -n 0 for the chunked layout;
+//   * -n/--nthreads defaults to 1 like the reference (src/sqy.cpp:190): ONE block-linked LZ4 frame -- bit-identical to the
+//     reference's default output; its blocks are parsed block-parallel from verified table guesses (about a third of the chunked
+//     layout's rate on microscopy stacks; data whose guesses fail, e.g. the sequence-heavy plane of a quantised stack, is
+//     parsed in order and is slow: DESIGN.md section 3).  Pass -n 0 for the chunked layout (independent frames, the fast path);
 //   * outputs other than .sqy (the reference can wrap the blob into .tif or .h5) are not written;
 //   * TIFF input/output is the uncompressed 8/16-bit grayscale subset the reference itself writes (tiff_utils.hpp:
 //     286-310), read and written here without libtiff; .raw needs --shape and --dtype.

@@ -390,7 +390,7 @@ Pipeline Pipeline::from_string(const std::string& s, int elem_size)
         st.cfg = parse_minors(pr.second);
         if (st.kind == StageKind::lz4) st.lz4 = Lz4Params(pr.second);
         if (st.kind == StageKind::raster_reorder && elem_size > 0 && !st.cfg.count("tile_size"))
-            st.cfg["tile_size"] = std::to_string(16 / elem_size);                  // raster_reorder_scheme_impl.hpp:23
+            st.cfg["tile_size"] = std::to_string(16 / (p.sink_index >= 0 ? 1 : elem_size));   // raster_reorder_scheme_impl.hpp:23 (behind the sink: raster_reorder_scheme<char>)
         if (p.sink_index < 0) {
             if (known_head_filter(pr.first)) { p.stages.push_back(st); continue; }
             if (known_sink(pr.first)) { p.sink_index = (int)p.stages.size(); p.stages.push_back(st); }
@@ -409,7 +409,6 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
     if (p.stages.empty()) return fail("empty pipeline");
     for (size_t i = 0; i < p.stages.size(); ++i) {
         const Stage& st = p.stages[i];
-        const bool after_sink = p.sink_index >= 0 && (int)i > p.sink_index;
         switch (st.kind) {
             case StageKind::bitswap1: break;
             case StageKind::diff3x3x1:
@@ -421,12 +420,9 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
                     return fail("frame_shuffle: frame_chunk_size must be positive");
                 break;
             }
-            case StageKind::zcurve_reorder: {
-                if (after_sink) return fail("zcurve_reorder as a tail filter is not implemented on MI355X");
-                break;
-            }
+            case StageKind::zcurve_reorder:
+                break;                                                           // (head filter, or tail filter on the sink's char output: round 5)
             case StageKind::tile_shuffle: {
-                if (after_sink) return fail("tile_shuffle as a tail filter is not implemented on MI355X");
                 auto t = st.cfg.find("tile_size");
                 if (t != st.cfg.end() && std::atoi(t->second.c_str()) <= 0) return fail("tile_shuffle: tile_size must be positive");
                 break;
@@ -438,7 +434,6 @@ bool Pipeline::supported(const std::string& s, int elem_size, std::string* why)
                 break;
             }
             case StageKind::raster_reorder: {
-                if (after_sink) return fail("raster_reorder as a tail filter is not implemented on MI355X");
                 auto t = st.cfg.find("tile_size");
                 if (t != st.cfg.end() && std::atoi(t->second.c_str()) <= 0) return fail("raster_reorder: tile_size must be positive");
                 break;
@@ -781,18 +776,19 @@ bool tile_shuffle_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t 
     return ts > 0 && Z >= ts && Y >= ts && X >= ts && Z % ts == 0 && Y % ts == 0 && X % ts == 0;
 }
 
-void tile_shuffle_order(const float* sums, size_t ntiles, size_t per_tile, int elem_size, uint64_t* decode_map)
+void tile_shuffle_order(const float* sums, size_t ntiles, size_t per_tile, int elem_size, uint64_t* decode_map, bool signed_char)
 {
-    // tile_shuffle_utils.hpp:176-219: std::vector<in_value_t> metric; metric[i] = sum / n_elements_per_tile (float -> voxel type)
-    std::vector<uint32_t> metric(ntiles);
+    // tile_shuffle_utils.hpp:176-219: std::vector<in_value_t> metric; metric[i] = sum / n_elements_per_tile (float -> voxel type).
+    // signed_char: the tail filter form, tile_shuffle_scheme<char> -- the metric is a (signed) char and sorts as one
+    std::vector<int32_t> metric(ntiles);
     for (size_t i = 0; i < ntiles; ++i) {
         const float m = sums[i] / per_tile;
-        metric[i] = elem_size == 2 ? (uint32_t)(uint16_t)m : (uint32_t)(uint8_t)m;
+        metric[i] = signed_char ? (int32_t)(int8_t)m : elem_size == 2 ? (int32_t)(uint16_t)m : (int32_t)(uint8_t)m;
     }
-    std::vector<uint32_t> sorted_metric = metric;
+    std::vector<int32_t> sorted_metric = metric;
     std::sort(sorted_metric.begin(), sorted_metric.end());
     // std::find(metric, sorted[i]) for every i = the first tile with that metric
-    std::map<uint32_t, uint64_t> first;
+    std::map<int32_t, uint64_t> first;
     for (size_t i = ntiles; i-- > 0;) first[metric[i]] = i;
     for (size_t i = 0; i < ntiles; ++i) decode_map[i] = first[sorted_metric[i]];
 }

@@ -105,7 +105,7 @@ bool zcurve_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_s
 // tile_shuffle (encoders/tile_shuffle_utils.hpp:104-224, encode_full): only shapes that are whole multiples of the tile
 bool tile_shuffle_geometry_defined(uint64_t Z, uint64_t Y, uint64_t X, uint64_t tile_size);
 // metric = (T)(sequential float sum / voxels per tile), sorted ascending, slot i <- first tile whose metric equals sorted[i]
-void tile_shuffle_order(const float* sums, size_t ntiles, size_t per_tile, int elem_size, uint64_t* decode_map);
+void tile_shuffle_order(const float* sums, size_t ntiles, size_t per_tile, int elem_size, uint64_t* decode_map, bool signed_char = false);
 // bitshuffle: elements per block (bshuf_default_block_size for 0); 0 when the configured size is not a multiple of 8
 uint64_t bitshuffle_block_elems(int elem_size, uint64_t block_size);
 

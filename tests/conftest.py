@@ -24,3 +24,17 @@ def sqy():
     import sqeazy_amd
     sqeazy_amd.lib()
     return sqeazy_amd
+
+
+@pytest.fixture
+def options(sqy):
+    """options("block_parallel", 0): SQYAMD_Set_Option for the rest of the test; every option touched is put back afterwards
+    (the library reads its environment once, at load -- include/sqeazy_amd.h)"""
+    saved = {}
+
+    def set_(name, value):
+        saved.setdefault(name, sqy.get_option(name))
+        sqy.set_option(name, value)
+    yield set_
+    for name, value in saved.items():
+        sqy.set_option(name, value)

@@ -99,6 +99,25 @@ static void headers(std::mt19937& rng)
                     if (x.valid) { (void)x.elem_size(); (void)Pipeline::supported(x.pipename, x.elem_size() > 0 ? x.elem_size() : 1); }
                 }
             }
+    {
+        // The one escaping vector the reference holds (tests/test_header_tag_impl.cpp:87, "property_tag_cant_do_this"): what Boost's
+        // JSON writer made of a quantiser LUT of raw bytes 00 40 00 80 00 and of the '/' of the closing verbatim tag -- NUL as
+        // \u0000, '/' as \/, a byte >= 0x80 and '@' as they are.  The raw pipename goes in, the reference's 71 bytes must come out.
+        const std::string raw = std::string("quantiser(decode_lut_string=<verbatim>") + std::string("\0@\0\200\0", 5) + "</verbatim>)";
+        const std::string want("quantiser(decode_lut_string=<verbatim>\\u0000@\\u0000\200\\u0000<\\/verbatim>)", 71);
+        const std::string h = header_pack(2, false, {1, 2, 3}, raw, 100);
+        CHECK(h.find("\"pipename\": \"" + want + "\",\n") != std::string::npos);
+        HeaderInfo hi = header_unpack(h.data(), h.data() + h.size());
+        CHECK(hi.valid && hi.pipename == raw && hi.payload_bytes == 100);
+        // .. and the reader takes the writer's other form of the same text (an unescaped '/') as well
+        std::string h2 = h;
+        const size_t at = h2.find("<\\/verbatim>");
+        CHECK(at != std::string::npos);
+        h2.erase(at + 1, 1);
+        if (h2.size() % 2) h2.insert(0, 1, ' ');
+        HeaderInfo hj = header_unpack(h2.data(), h2.data() + h2.size());
+        CHECK(hj.valid && hj.pipename == raw);
+    }
     std::vector<char> noise(4096);
     for (int round = 0; round < 300; ++round) {
         for (char& c : noise) c = (char)(rng() & 0xff);

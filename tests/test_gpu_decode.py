@@ -373,7 +373,7 @@ def sqy_oracle_planes(vol):
 
 @pytest.mark.parametrize("cfg", ["", "blocksize_kb=64", "blocksize_kb=1024"])
 @pytest.mark.parametrize("name", [s[0] for s in _linked_streams(1 << 20, 0)])
-def test_serial_layout_decodes_block_parallel(sqy, oracle, monkeypatch, name, cfg):
+def test_serial_layout_decodes_block_parallel(sqy, oracle, options, name, cfg):
     n = 20 * (256 << 10) + 4567 if cfg != "blocksize_kb=1024" else 5 * (1 << 20) + 999
     data = dict(_linked_streams(n, 31))[name]
     vol = data.reshape(1, 1, -1)
@@ -385,12 +385,12 @@ def test_serial_layout_decodes_block_parallel(sqy, oracle, monkeypatch, name, cf
     names = set(sqy.profile_get().keys())
     assert rc == 0 and np.array_equal(back.reshape(-1), data), (name, cfg)
     assert "lz4_linked_decode" in names and "lz4_frames_decode" not in names, names   # the block-parallel path, no fall-back
-    monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")                                  # the one-wavefront walk agrees
+    options("block_parallel", 0)                                  # the one-wavefront walk agrees
     rc, back2 = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back2.reshape(-1), data)
 
 
-def test_serial_layout_damaged_streams_fall_back_to_the_walk(sqy, oracle, monkeypatch):
+def test_serial_layout_damaged_streams_fall_back_to_the_walk(sqy, oracle, options):
     """damage inside a block, a block that does not decode to a full block, a cut stream: the block-parallel decode raises its flag and the
     one-wavefront walk gives the verdict -- the same return code and bytes as with the block-parallel path switched off"""
     rng = np.random.default_rng(3)
@@ -404,9 +404,9 @@ def test_serial_layout_damaged_streams_fall_back_to_the_walk(sqy, oracle, monkey
         b = bytearray(blob); b[at:at + 40] = bytes([0xF7] * 40); cases.append(bytes(b))
     cases.append(blob[:len(blob) - 9])
     for bad in cases:
-        monkeypatch.delenv("SQY_NO_BLOCK_PARALLEL", raising=False)
+        options("block_parallel", 1)
         rc1, back1 = sqy.decode(bad)
-        monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")
+        options("block_parallel", 0)
         rc2, back2 = sqy.decode(bad)
         assert rc1 == rc2
         if rc1 == 0:
@@ -414,7 +414,7 @@ def test_serial_layout_damaged_streams_fall_back_to_the_walk(sqy, oracle, monkey
 
 
 @pytest.mark.parametrize("name", ["zeros", "period60001", "sparse", "rawmix", "relay", "planes", "runs"])
-def test_serial_layout_long_frames_resolve_their_tails_as_a_scan(sqy, oracle, monkeypatch, name):
+def test_serial_layout_long_frames_resolve_their_tails_as_a_scan(sqy, oracle, options, name):
     """frames of a few hundred blocks: the tails are not walked by one workgroup but composed per range of 64 blocks, chained, and walked by
     all ranges at once (lz4_linked_compose_tails_kernel ..); 64 KiB blocks so that a test-sized stream has 300 of them; the one walk
     (SQY_NO_TAIL_SCAN) and the one-wavefront decode (SQY_NO_BLOCK_PARALLEL) agree"""
@@ -438,7 +438,7 @@ def test_serial_layout_long_frames_resolve_their_tails_as_a_scan(sqy, oracle, mo
     names = set(sqy.profile_get().keys())
     assert rc == 0 and np.array_equal(back.reshape(-1), data), name
     assert "lz4_linked_decode" in names and "lz4_frames_decode" not in names, names
-    monkeypatch.setenv("SQY_NO_TAIL_SCAN", "1")
+    options("tail_scan", 0)
     rc, back2 = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back2.reshape(-1), data)
 
@@ -522,7 +522,7 @@ def _handmade_linked_frame(seed, nblocks, block=64 << 10):
 
 
 @pytest.mark.parametrize("seed,nblocks", [(1, 5), (2, 9), (3, 40), (4, 300), (5, 3)])
-def test_handmade_sequences_on_every_boundary(sqy, oracle, monkeypatch, seed, nblocks):
+def test_handmade_sequences_on_every_boundary(sqy, oracle, options, seed, nblocks):
     payload, want = _handmade_linked_frame(seed, nblocks)
     name = "lz4(accel=1,blocksize_kb=64,framestep_kb=256,n_chunks_of_input=0)"
     blob = oracle.header_pack(np.uint8, (1, 1, want.size), name, len(payload)) + payload
@@ -533,10 +533,10 @@ def test_handmade_sequences_on_every_boundary(sqy, oracle, monkeypatch, seed, nb
     names = set(sqy.profile_get().keys())
     assert rc == 0 and np.array_equal(back.reshape(-1), want), "block-parallel decode differs"
     assert "lz4_linked_decode" in names and "lz4_frames_decode" not in names, names
-    monkeypatch.setenv("SQY_NO_TAIL_SCAN", "1")
+    options("tail_scan", 0)
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back.reshape(-1), want), "one walk over the tails differs"
-    monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")
+    options("block_parallel", 0)
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back.reshape(-1), want), "one-wavefront decode differs"
 

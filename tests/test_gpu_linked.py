@@ -129,7 +129,7 @@ def _profile_names(sqy):
 
 @pytest.mark.parametrize("warmup", [None, "0", "1", "200000", "1000000"])
 @pytest.mark.parametrize("name", ["zeros", "random", "noise3", "sparse", "periodic", "farrep", "runs", "rawmix", "hist1", "hist3", "planes"])
-def test_block_parallel_serial_layout(sqy, oracle, monkeypatch, name, warmup):
+def test_block_parallel_serial_layout(sqy, oracle, options, name, warmup):
     n = 24 * (256 << 10) + 54321
     if name == "hist1":
         data = _histmatch(n, 1)
@@ -142,7 +142,7 @@ def test_block_parallel_serial_layout(sqy, oracle, monkeypatch, name, warmup):
     vol = data.reshape(1, 1, -1)
     want = oracle.pipeline_encode("lz4", vol, nthreads=1)
     if warmup is not None:
-        monkeypatch.setenv("SQY_BLOCK_PARALLEL_WARMUP", warmup)
+        options("block_parallel_warmup", int(warmup))
     sqy.profile_reset(); sqy.profile_enable(True)
     rc, blob = sqy.encode("lz4", vol, nthreads=1)
     sqy.profile_enable(False)
@@ -155,7 +155,7 @@ def test_block_parallel_serial_layout(sqy, oracle, monkeypatch, name, warmup):
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back.reshape(-1), data)
     # the frame walk of rounds 2-3 gives the same bytes
-    monkeypatch.setenv("SQY_NO_BLOCK_PARALLEL", "1")
+    options("block_parallel", 0)
     rc, blob2 = sqy.encode("lz4", vol, nthreads=1)
     assert rc == 0 and blob2 == want
 

@@ -29,6 +29,65 @@ def test_tail_filters_on_char(sqy, oracle, pipeline):
         assert rc == 0 and np.array_equal(back, oracle.pipeline_decode(want)), (pipeline, vol.shape)
 
 
+# ---- round 5: the reorder / shuffle stages behind the sink (sqeazy_pipelines.hpp:64-77 lists all of them for the tail chain) ----
+def _tile_vols():
+    rng = np.random.default_rng(22)
+    yield (rng.gamma(2.0, 300.0, (32, 32, 64)) + 50).astype(np.uint16)            # whole 16^3 / 32^3 tiles, bytes from 0 to 255 (negative as char)
+    yield synth.stack((32, 64, 96), np.uint16)
+    yield rng.integers(0, 65536, (16, 48, 32), dtype=np.uint16)
+    yield rng.integers(0, 65536, (19, 37, 53), dtype=np.uint16)                    # remainders in every dimension
+
+
+TAIL_REORDER = ["quantiser->raster_reorder->lz4", "quantiser->raster_reorder(tile_size=8)->bitswap1->lz4", "quantiser->zcurve_reorder->lz4",
+                "quantiser->zcurve_reorder(tile_size=8)->bitswap1->lz4", "quantiser->tile_shuffle(tile_size=16)->lz4", "quantiser->tile_shuffle(tile_size=16)",
+                "quantiser->tile_shuffle(tile_size=8)->zcurve_reorder(tile_size=4)->lz4", "quantiser->raster_reorder->diff3x3x1->lz4"]
+
+
+@pytest.mark.parametrize("pipeline", TAIL_REORDER)
+def test_reorder_stages_as_tail_filters_on_char(sqy, oracle, pipeline):
+    """raster_reorder / zcurve_reorder / tile_shuffle on the sink's `char` stream: pure reorders of bytes for the first two (default tile of
+    raster_reorder_scheme<char>: 16), signed tile sums and a `char` metric for tile_shuffle (tile_shuffle_utils.hpp:176-190 with
+    in_value_t = char).  Geometries the reference leaves undefined are refused by both sides alike."""
+    assert sqy.pipeline_possible(pipeline, np.uint16)
+    ran = 0
+    for vol in _tile_vols():
+        try:
+            want = oracle.pipeline_encode(pipeline, vol)
+        except ValueError:
+            assert sqy.encode(pipeline, vol, nthreads=2, extra_capacity=1 << 16)[0] == 1, (pipeline, vol.shape)      # refused alike
+            continue
+        rc, blob = sqy.encode(pipeline, vol, nthreads=2, extra_capacity=1 << 16)
+        assert rc == 0, (pipeline, vol.shape)
+        assert blob == want, (pipeline, vol.shape)
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, oracle.pipeline_decode(want)), (pipeline, vol.shape)
+        ran += 1
+    assert ran >= 2, pipeline
+
+
+def test_tail_filters_behind_pass_through(sqy, oracle):
+    """pass_through on 8-bit voxels writes one byte per voxel: the tail chain keeps the volume's shape; on 16-bit voxels it sees
+    {1, 1, bytes} (dynamic_pipeline.hpp:658-666) -- there frame_shuffle has ONE frame, and the tiled reorders find no geometry the
+    reference defines: refused, by the oracle and here."""
+    rng = np.random.default_rng(23)
+    v8 = rng.integers(0, 256, (16, 32, 48), dtype=np.uint8)
+    for pipeline in ("pass_through->frame_shuffle->lz4", "pass_through->raster_reorder->lz4", "pass_through->zcurve_reorder(tile_size=8)->lz4",
+                     "pass_through->tile_shuffle(tile_size=16)->lz4"):
+        assert sqy.pipeline_possible(pipeline, np.uint8)
+        want = oracle.pipeline_encode(pipeline, v8)
+        rc, blob = sqy.encode(pipeline, v8, nthreads=2, extra_capacity=1 << 16)
+        assert rc == 0 and blob == want, pipeline
+        rc, back = sqy.decode(blob)
+        # (tiles of equal metric share one source tile in the encoder -- tile_shuffle is not invertible then, like the reference's)
+        assert rc == 0 and np.array_equal(back, oracle.pipeline_decode(want)), pipeline
+        assert "tile_shuffle" in pipeline or np.array_equal(back, v8), pipeline
+    v16 = synth.stack((16, 32, 48), np.uint16)
+    for pipeline in ("pass_through->raster_reorder->lz4", "pass_through->zcurve_reorder->lz4", "pass_through->tile_shuffle(tile_size=16)->lz4"):
+        with pytest.raises(ValueError):
+            oracle.pipeline_encode(pipeline, v16)
+        assert sqy.encode(pipeline, v16, nthreads=2, extra_capacity=1 << 16)[0] == 1, pipeline
+
+
 def test_tail_diff_needs_the_volume_shape(sqy):
     """behind a sink that does not write one byte per voxel the tail chain sees {1, 1, bytes} (dynamic_pipeline.hpp:658-666): diff3x3x1
     reads out of bounds there in the reference; refused.  8-bit extents above 127 overflow its char coordinates: refused as well."""

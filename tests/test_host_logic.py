@@ -34,6 +34,21 @@ def test_version(sqy):
     assert b"gfx950" in sqy.lib().SQYAMD_Version()
 
 
+def test_run_time_options(sqy):
+    """SQYAMD_Set_Option / SQYAMD_Get_Option (include/sqeazy_amd.h): the switches the environment sets once at load; names and ranges checked"""
+    assert sqy.get_option("block_parallel") == 1 and sqy.get_option("tail_scan") == 1 and sqy.get_option("transpose_chain") == 1
+    assert sqy.get_option("transpose_chain_caller_streams") == 0          # coupling caller streams is opt-in (round-4 advice)
+    assert sqy.get_option("block_parallel_warmup") == 65536
+    assert sqy.get_option("no_such_option") == -1
+    L = sqy.lib()
+    assert L.SQYAMD_Set_Option(b"no_such_option", 1) == 1 and L.SQYAMD_Set_Option(None, 1) == 1
+    assert L.SQYAMD_Set_Option(b"block_parallel", 2) == 1 and L.SQYAMD_Set_Option(b"block_parallel_warmup", -1) == 1
+    assert L.SQYAMD_Set_Option(b"block_parallel_warmup", (1 << 30) + 1) == 1
+    with sqy.option("block_parallel_warmup", 200000):
+        assert sqy.get_option("block_parallel_warmup") == 200000
+    assert sqy.get_option("block_parallel_warmup") == 65536
+
+
 def test_pipeline_possible_matches_reference_rules(sqy, oracle):
     """tests/test_pipeline_interface.cpp:28-61 + the documented restriction to implemented stages"""
     for dt in (np.uint16, np.uint8):
@@ -47,12 +62,15 @@ def test_pipeline_possible_matches_reference_rules(sqy, oracle):
                  "raster_reorder->lz4", "raster_reorder(tile_size=4)->bitswap1->lz4", "tile_shuffle->lz4", "zcurve_reorder->lz4",
                  "zcurve_reorder(tile_size=8)->bitswap1->lz4", "bitshuffle->lz4", "bitshuffle(block_size=64)->lz4", "quantiser->bitshuffle->lz4",
                  "pass_through", "pass_through->lz4", "bitswap1->pass_through->bitswap1->lz4",
+                 # every tail filter of sqeazy_pipelines.hpp:64-77 but the video codecs (round 5: the reorder / shuffle stages too)
+                 "quantiser->tile_shuffle->lz4", "quantiser->raster_reorder->lz4", "quantiser->zcurve_reorder(tile_size=4)->bitswap1->lz4",
+                 "pass_through->raster_reorder->tile_shuffle(tile_size=8)->zcurve_reorder->frame_shuffle->diff3x3x1->bitshuffle->bitswap1->lz4",
                  "bitswap1(num_bits_per_plane=1)->lz4(accel=1,blocksize_kb=256,framestep_kb=256,n_chunks_of_input=0)"]
     for p in supported:
         assert oracle.can_be_built_from(p) and sqy.pipeline_possible(p), p
     # valid for the reference, not implemented here: answered false (documented deviation)
     for p in ["lz4(accel=9)", "lz4->bitswap1", "lz4->raster_reorder", "raster_reorder(tile_size=0)->lz4",
-              "bitshuffle(block_size=12)->lz4", "remove_background->lz4", "quantiser->tile_shuffle->lz4"]:
+              "bitshuffle(block_size=12)->lz4", "remove_background->lz4", "quantiser->tile_shuffle(tile_size=0)->lz4"]:
         assert oracle.can_be_built_from(p) and not sqy.pipeline_possible(p), p
     assert not sqy.pipeline_possible("quantiser->lz4", np.uint8)
     # malformed

@@ -1,5 +1,7 @@
 """CPU: the reference's own known-answer tests for the hot path, restated against the oracle.
 Each test cites the reference test it follows (paths relative to /root/reference/src/cpp/tests)."""
+import base64
+
 import numpy as np
 import pytest
 
@@ -408,6 +410,35 @@ def test_header_bytes_of_docs_overview(oracle):
         want_mine = b" " + want_mine
     assert mine == want_mine
     assert mine == oracle.header_pack(np.uint16, shape, "bitswap1(num_bits_per_plane=1)->" + lz4_name, nbytes)
+
+
+def test_header_escaping_vector_of_the_reference(oracle):
+    """tests/test_header_tag_impl.cpp:87 ("property_tag_cant_do_this") holds what Boost's JSON writer made of a pipename with raw LUT
+    bytes 00 40 00 80 00 inside a verbatim block: NUL as \\u0000, the '/' of the closing tag as \\/, '@' and the byte 0x80 as they
+    are -- 71 bytes.  The raw name goes through oracle.header_pack and must come out as exactly those bytes; the product's writer is
+    held to the same vector with real NUL bytes in tests/sanitize/host_fuzz.cpp (a C string cannot carry them through the C-ABI) and,
+    here, through SQYAMD_Header_Build for the part a C string can carry."""
+    import ctypes
+    import sqeazy_amd
+    want = b"quantiser(decode_lut_string=<verbatim>\\u0000@\\u0000\200\\u0000<\\/verbatim>)"
+    assert len(want) == 71                                           # the length the reference's test passes to std::string
+    raw = "quantiser(decode_lut_string=<verbatim>" + "\x00@\x00\x80\x00" + "</verbatim>)"
+    got = oracle.header_pack(np.uint16, (1, 2, 3), raw, 100)
+    assert b'"pipename": "' + want + b'",\n' in got
+    back = oracle.header_unpack(got)
+    assert back["pipename"] == raw and back["bytes"] == 100 and back["shape"] == (1, 2, 3)
+    # the product's writer through the C-ABI: '/' and a control character below 0x20 (0x01; NUL would end the C string), byte 0x80
+    L = sqeazy_amd.lib()
+    shp = (ctypes.c_long * 3)(1, 2, 3)
+    n = ctypes.c_long(0)
+    name = b"quantiser(decode_lut_string=<verbatim>" + base64.b64encode(bytes(range(256)) * 2) + b"</verbatim>)"
+    assert L.SQYAMD_Header_Build(name, 2, shp, 3, 100, None, ctypes.byref(n)) == 0
+    buf = ctypes.create_string_buffer(n.value)
+    assert L.SQYAMD_Header_Build(name, 2, shp, 3, 100, buf, ctypes.byref(n)) == 0
+    mine = buf.raw[:n.value]
+    assert b"<\\/verbatim>" in mine and b"</verbatim>" not in mine     # as written at :87
+    assert mine.count(b"\\/") == name.count(b"/")                     # every '/' of the base64 text as well
+    assert oracle.header_unpack(mine)["pipename"].encode("latin-1").startswith(name[:-1])
 
 
 def test_quantiser_weighters_reference_kats(oracle):

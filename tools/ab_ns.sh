@@ -1,4 +1,4 @@
 #!/bin/bash
-cp sqeazy_amd/lib/libsqeazy_amd.so /tmp/_installed.so
-for tag in "$@"; do cp tools/_ab/$tag.so sqeazy_amd/lib/libsqeazy_amd.so; python tools/ns_slab.py $tag 2>&1 | grep -v amdgpu.ids; done
-cp /tmp/_installed.so sqeazy_amd/lib/libsqeazy_amd.so
+# A/B of the north_star slab run: tools/ab_ns.sh base v1   (libraries ab_libs/<tag>.so)
+. tools/ab_common.sh
+for tag in "$@"; do ab_install $tag; python tools/ns_slab.py "$tag@$AB_SHA" 2>&1 | grep -v amdgpu.ids; done
