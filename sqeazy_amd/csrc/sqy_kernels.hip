@@ -119,6 +119,13 @@ __device__ __forceinline__ uint32_t sgpr(uint32_t v) { return __builtin_amdgcn_r
 __device__ __forceinline__ uint32_t lane_read(uint32_t v, uint32_t l) { return __builtin_amdgcn_readlane(v, l); }
 // (the builtin on a bool: __ballot() first turns the lane mask into 0 / 1 per lane and compares that again -- two vector
 // instructions and their latency per ballot on the parse's critical path)
+// v_writelane_b32: lane `l` of v takes the (uniform) value x.  (lane select through m0: two different SGPRs exceed the constant bus)
+__device__ __forceinline__ uint32_t lane_write(uint32_t v, uint32_t x, uint32_t l)
+{
+    uint32_t km;
+    asm("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(v), "=&s"(km) : "s"(x), "s"(l));
+    return v;
+}
 __device__ __forceinline__ uint64_t ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 __device__ __forceinline__ uint32_t ctz64(uint64_t m) { return (uint32_t)__builtin_ctzll(m); }
 
@@ -1325,178 +1332,171 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     if (ballot(near && !cin)) {
                         if (near && !cin) {                                             // candidates behind the ring: one round trip for all of them
                             c16 = glb_ld_u128(w.src + old);                             // old + 16 <= pos + 15 < matchlimit
-                            cb4 = old >= 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src) << (8u * (4u - old)));
+                            // (the stream begins at p_lo: 0, or inside the history window of a block-linked frame's first blocks)
+                            cb4 = old >= p_lo + 4u ? glb_ld_u32(w.src + old - 4u) : (glb_ld_u32(w.src + p_lo) << (8u * (4u - (old - p_lo))));
                         }
                     }
                     const uint32_t d = first_diff16(s16, c16);                          // 0..16 equal bytes forward
                     const uint32_t xb = b4 ^ cb4;
                     const uint32_t bkv = xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u;  // equal bytes in front, 4 = maybe more
-                    // what the walk needs of a lane in one word: forward bytes | bytes in front << 5 | literal limit << 8 | offset << 16.
+                    // what the walk needs of a lane in one word: forward bytes | bytes in front << 5 | literal limit << 8 | hit << 12 |
+                    // shares-a-bucket << 13 | offset << 16.
                     // The literal limit folds every reason to leave the dense batches into one compare per sequence: fewer than 15
                     // literals; fewer than 5 when the catch-up may run past the 4 bytes looked at; none at all (0: the match goes to
                     // the lean / generic paths) when it runs past the 16 bytes looked at or its candidate sits within 15 bytes of the
-                    // chunk start (the catch-up limit needs care there).
-                    const uint32_t maxlit1 = (d == 16u || old < 16u) ? 0u : (bkv == 4u ? 5u : 15u);
-                    const uint32_t info = d | (bkv << 5) | (maxlit1 << 8) | ((pos - old) << 16);
+                    // stream's start (the catch-up limit needs care there; a block-linked frame's history limits it likewise).
+                    auto verdict_word = [&](uint32_t fwd, uint32_t bk, uint32_t cand, uint32_t off) -> uint32_t {
+                        const bool edge = cand < p_lo + 16u || (LINKED && back_room(cand) < 4u);
+                        const uint32_t ml1 = (fwd == 16u || edge) ? 0u : (bk == 4u ? 5u : 15u);
+                        return fwd | (bk << 5) | (ml1 << 8) | (fwd >= 4u ? 1u << 12 : 0u) | (off << 16);
+                    };
+                    const uint32_t info = (verdict_word(d, bkv, old, pos - old) & (near ? ~0u : ~(1u << 12))) | (dup ? 1u << 13 : 0u);
                     const uint64_t M = ballot(near && d >= 4u);
                     const uint64_t D = ballot(dup);
                     SQY_STAMP(21);
-                    // ---- the walk: uniform, registers only.  Sequence after sequence: first event lane at or behind the cursor -> its verdict
-                    // word (`info`) -> cursor behind the match; lane k of q_fq / q_inf records sequence k.
-                    // Profiled in round 3: three quarters of a batch's time -- compiled from C++ a step was ~70 scalar instructions and
-                    // eight branches (~900 cycles at the rate a lone wave gets).  The common step -- an event lane that is a plain hit --
-                    // is a hand-written scalar loop of ~20 instructions and one taken branch; it hands back to the C++ below for
-                    // the lanes that share a bucket with an earlier lane of the batch (reason 1) and ends the batch on a literal
-                    // limit (reason 2).  Which probes lie INSIDE matches (they do not enter the table) is not tracked step by step:
-                    // it is derived from the recorded sequences, in parallel, where somebody needs it.
-                    uint32_t cur = 0, nseq = 0;                                         // lane units; the cursor is also the anchor of the next sequence
-                    uint32_t q_fq = 0, q_inf = 0;                                       // lane k: sequence k -- its probe lane and that lane's verdict word
+                    // ---- the walk.  Sequence after sequence: first event lane at or behind the cursor -> its verdict word -> cursor behind the
+                    // match.  Round 3 profiled it at three quarters of a batch's time and hand-wrote the common step -- an event lane that is
+                    // a plain hit -- as a scalar loop of ~20 instructions; round 5 takes the step apart: WHAT the parse does when its cursor
+                    // stands at lane i (which lane matches, with what verdict, where the cursor goes) depends, for a plain hit, on i alone, so
+                    // every lane works that out for its own i at once (a 64-bit shift of the event mask, one lane permute, a few compares:
+                    // tools/dense_walk_model.c), and what is left in a row is the chain 0 -> next(0) -> next(next(0)) ..: one lane read, a
+                    // bit set and a compare per sequence.  The sequences are recorded where they begin: lane c = the sequence whose anchor is
+                    // lane c (bit c of `chain`), no second numbering.  Lanes that share a bucket with an earlier lane of the batch (their true
+                    // candidate depends on which of those lanes have entered the table by then: 14 % of the steps on quantised data) stop
+                    // the chain; they are settled below from the chain so far and written into the cursor lane's record, and the chain goes on.
+                    uint32_t cur = 0;                                                   // lane units; the cursor is also the anchor of the next sequence
+                    uint64_t chain = 0;                                                 // bit c: a sequence starts (has its anchor) at lane c
                     bool keep_dense = true;
                     uint64_t evm = M | D;                                               // lanes the walk has to look at
-                    // probes inside the matches recorded so far: (fq, ipn) of every sequence but for ipn - 2 (LZ4_putPosition(ip - 2))
-                    auto inside_matches = [&]() -> uint64_t {
-                        const bool on = (uint32_t)lane < nseq;
-                        const uint32_t a1 = q_fq + 1u, e = q_fq + (q_inf & 31u);        // bits a1 .. e-1, minus bit e-2
-                        auto below = [](uint32_t x) -> uint64_t { return x >= 64u ? ~0ull : ((1ull << x) - 1ull); };
-                        uint64_t m = on ? (below(e) & ~below(a1)) : 0ull;
-                        if (on && e - 2u < 64u) m &= ~(1ull << (e - 2u));
-                        uint32_t lo = (uint32_t)m, hi = (uint32_t)(m >> 32);
-                        // OR over the first row of 16 lanes (nseq <= 16), result in lane 15
-                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x111, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x111, 0xf, 0xf, false);
-                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x112, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x112, 0xf, 0xf, false);
-                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x114, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x114, 0xf, 0xf, false);
-                        lo |= __builtin_amdgcn_update_dpp(0u, lo, 0x118, 0xf, 0xf, false); hi |= __builtin_amdgcn_update_dpp(0u, hi, 0x118, 0xf, 0xf, false);
-                        return ((uint64_t)lane_read(hi, 15) << 32) | lane_read(lo, 15);
+                    // per cursor lane: status | probe lane << 8 | next cursor << 16, and the verdict word of that probe lane
+                    constexpr uint32_t W_OK = 0u, W_NONE = 1u, W_LIMIT = 2u, W_MATE = 3u;
+                    uint32_t epk, einf;
+                    {
+                        const uint64_t x = evm >> (uint32_t)lane;
+                        const uint32_t eo = x ? (uint32_t)__builtin_ctzll(x) : 0u;
+                        const uint32_t e = (uint32_t)lane + eo;                        // first event lane at or behind me (me, when there is none)
+                        einf = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(e << 2), (int)info);
+                        const uint32_t st = !x ? W_NONE : ((einf >> 13) & 1u) ? W_MATE : (eo >= ((einf >> 8) & 15u)) ? W_LIMIT : W_OK;
+                        epk = st | (e << 8) | ((e + (einf & 31u)) << 16);
+                    }
+                    // is lane q in the table by now?  (q in front of the cursor: it belongs to the sequence of the last chain lane at or in
+                    // front of it -- a literal or the probe that matched: yes; strictly inside the match: no, but for its ip - 2)
+                    auto entered = [&](uint32_t q) -> bool {
+                        if (q >= cur) return true;                                      // the literals of the sequence under way: probes the parse passed
+                        const uint64_t cs = chain & ((2ull << q) - 1ull);              // (cur > 0: lane 0 is a chain lane)
+                        const uint32_t c = 63u - (uint32_t)__builtin_clzll(cs);
+                        const uint32_t wq = lane_read(epk, c);
+                        const uint32_t fqc = (wq >> 8) & 63u, nxc = wq >> 16;
+                        return q <= fqc || q + 2u == nxc;
                     };
                     for (;;) {
-                        uint32_t reason, fq, t0, t1, t2, keep_m0;
-                        uint64_t ev;
-                        // (uniform by construction; said explicitly, the compiler otherwise hands the mask over in vector registers)
-                        const uint64_t evm_s = ((uint64_t)sgpr((uint32_t)(evm >> 32)) << 32) | sgpr((uint32_t)evm);
+                        uint32_t st, t0;
                         SQY_STAMP(24);
-                        // The serial part of a step is only the chain cursor -> first event lane -> its forward bytes -> cursor: the loop
-                        // records the lane and its verdict word, what the sequence looks like (literals, catch-up, match code) is worked
-                        // out afterwards for all sequences at once, lane k = sequence k.
-                        // reason 0: batch over (cursor past the batch, 16 sequences, or no event lane left); 1: event lane fq shares its
-                        // bucket with an earlier lane; 2: literal limit of lane fq (info bits 8..11) reached
                         asm volatile(
-                            "s_mov_b32 %[km0], m0\n"
                             "1:\n\t"
-                            "s_mov_b32 %[rsn], 0\n\t"
-                            "s_cmp_ge_u32 %[cur], 64\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "s_cmp_ge_u32 %[nseq], 16\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "s_lshr_b64 %[ev], %[evm], %[cur]\n\t"
-                            "s_cmp_eq_u64 %[ev], 0\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "s_ff1_i32_b64 %[t0], %[ev]\n\t"
-                            "s_add_u32 %[fq], %[cur], %[t0]\n\t"
-                            "s_mov_b32 %[rsn], 1\n\t"
-                            "s_bitcmp1_b64 %[dm], %[fq]\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "v_readlane_b32 %[t0], %[info], %[fq]\n\t"
-                            "s_sub_u32 %[t1], %[fq], %[cur]\n\t"                      // literals
-                            "s_bfe_u32 %[t2], %[t0], 0x40008\n\t"                     // literal limit
-                            "s_mov_b32 %[rsn], 2\n\t"
-                            "s_cmp_ge_u32 %[t1], %[t2]\n\t"
-                            "s_cbranch_scc1 3f\n\t"
-                            "s_mov_b32 m0, %[nseq]\n\t"
-                            "s_and_b32 %[t1], %[t0], 31\n\t"                          // forward bytes
-                            "v_writelane_b32 %[qfq], %[fq], m0\n\t"
-                            "v_writelane_b32 %[qinf], %[t0], m0\n\t"
-                            "s_add_u32 %[cur], %[fq], %[t1]\n\t"                      // behind the match
-                            "s_add_u32 %[nseq], %[nseq], 1\n\t"
-                            "s_branch 1b\n"
-                            "3:\n\t"
-                            "s_mov_b32 m0, %[km0]"
-                            : [rsn] "=&s"(reason), [fq] "=&s"(fq), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2), [km0] "=&s"(keep_m0),
-                              [ev] "=&s"(ev), [cur] "+s"(cur), [nseq] "+s"(nseq), [qfq] "+v"(q_fq), [qinf] "+v"(q_inf)
-                            : [evm] "s"(evm_s), [dm] "s"(D), [info] "v"(info)
+                            "v_readlane_b32 %[t0], %[epk], %[cur]\n\t"
+                            "s_and_b32 %[st], %[t0], 0xff\n\t"
+                            "s_cmp_lg_u32 %[st], 0\n\t"
+                            "s_cbranch_scc1 2f\n\t"
+                            "s_bitset1_b64 %[ch], %[cur]\n\t"
+                            "s_lshr_b32 %[cur], %[t0], 16\n\t"
+                            "s_cmp_lt_u32 %[cur], 64\n\t"
+                            "s_cbranch_scc1 1b\n"
+                            "2:"
+                            : [t0] "=&s"(t0), [st] "=&s"(st), [cur] "+s"(cur), [ch] "+s"(chain)
+                            : [epk] "v"(epk)
                             : "scc");
                         SQY_STAMP(25);
-                        if (reason == 0u) break;
-                        if (reason == 2u) { keep_dense = false; SQY_REASON(11); break; }
-                        // ---- lane fq shares its bucket with an earlier lane of this batch ----
-                        SQY_REASON(13); SQY_REASON(14);
-                        bool is_hit = (M >> fq) & 1ull;
-                        uint32_t inf = lane_read(info, fq);
-                        {
-                            // If one of the earlier lanes has entered the table by now (a probe the parse passed over, or an ip - 2), the
-                            // LATEST such lane is this probe's true candidate.  Earlier lanes of the bucket, latest first; a lane has entered
-                            // the table unless it lies strictly inside a recorded match (and is not that match's ip - 2) -- asked of the
-                            // sequence lanes directly, the whole mask of such probes is not needed for one lane.
-                            const uint32_t hf = lane_read(h, fq);
-                            uint64_t mates = ballot(h == hf) & ((1ull << fq) - 1ull);
-                            const uint32_t s_ipn = q_fq + (q_inf & 31u);
-                            uint32_t qm = 64u;
-                            while (mates) {
-                                const uint32_t c = 63u - (uint32_t)__builtin_clzll(mates);
-                                mates &= ~(1ull << c);
-                                if (!ballot((uint32_t)lane < nseq && q_fq < c && c < s_ipn && c + 2u != s_ipn)) { qm = c; break; }
+                        if (st == W_OK || st == W_NONE) break;                          // cursor past the batch / no event lane left
+                        if (st == W_LIMIT) { keep_dense = false; SQY_REASON(11); break; }
+                        // ---- W_MATE: the first event lane at or behind the cursor shares its bucket with an earlier lane of this batch ----
+                        SQY_REASON(13);
+                        uint32_t fq = (t0 >> 8) & 63u;
+                        uint32_t inf = 0;
+                        bool found = false;
+                        for (;;) {
+                            inf = lane_read(info, fq);
+                            if ((inf >> 13) & 1u) {
+                                SQY_REASON(14);
+                                // If one of the earlier lanes of the bucket has entered the table by now (a probe the parse passed over, or an
+                                // ip - 2), the LATEST such lane is this probe's true candidate; else the table entry from before the batch is.
+                                const uint32_t hf = lane_read(h, fq);
+                                uint64_t mates = ballot(h == hf) & ((1ull << fq) - 1ull);
+                                uint32_t qm = 64u;
+                                while (mates) {
+                                    const uint32_t c = 63u - (uint32_t)__builtin_clzll(mates);
+                                    mates &= ~(1ull << c);
+                                    if (entered(c)) { qm = c; break; }
+                                }
+                                if (qm < 64u) {
+                                    // both sequences sit in registers: lane qm's 16 + 4 bytes go to every lane, each compares its own against
+                                    // them (one vector pass), lane fq's result counts
+                                    const uint4 cq = make_uint4(lane_read(s16.x, qm), lane_read(s16.y, qm), lane_read(s16.z, qm), lane_read(s16.w, qm));
+                                    const uint32_t dq = lane_read(first_diff16(s16, cq), fq);
+                                    const uint32_t xbq = lane_read(b4, fq) ^ lane_read(b4, qm);
+                                    const uint32_t bq = xbq ? ((uint32_t)__builtin_clz(xbq) >> 3) : 4u;
+                                    inf = verdict_word(dq, bq, P + qm, fq - qm);
+                                    SQY_REASON(10);
+                                }
                             }
-                            qm = sgpr(qm);
-                            if (qm < 64u) {
-                                // both sequences sit in registers: lane qm's 16 + 4 bytes go to every lane, each compares its own against
-                                // them (one vector pass instead of ten lane reads and a scalar compare chain), lane fq's result counts
-                                const uint4 cq = make_uint4(lane_read(s16.x, qm), lane_read(s16.y, qm), lane_read(s16.z, qm), lane_read(s16.w, qm));
-                                const uint32_t dq = lane_read(first_diff16(s16, cq), fq);
-                                const uint32_t xbq = lane_read(b4, fq) ^ lane_read(b4, qm);
-                                is_hit = dq >= 4u;
-                                const uint32_t bq = xbq ? ((uint32_t)__builtin_clz(xbq) >> 3) : 4u;
-                                const uint32_t ml1 = (dq == 16u || P + qm < 16u) ? 0u : (bq == 4u ? 5u : 15u);
-                                inf = dq | (bq << 5) | (ml1 << 8) | ((fq - qm) << 16);
-                                SQY_REASON(10);
-                            }
+                            if ((inf >> 12) & 1u) { found = true; break; }
+                            // (a same-bucket lane that is no match: one more probe passed) -- the next event lane behind it, same cursor
+                            const uint64_t rest = fq < 63u ? evm >> (fq + 1u) : 0ull;
+                            if (!rest) break;
+                            fq += 1u + (uint32_t)__builtin_ctzll(rest);
                         }
-                        if (!is_hit) { evm &= ~(1ull << fq); SQY_STAMP(26); continue; }  // (a same-bucket lane that is no match: one more probe passed)
+                        fq = sgpr(fq); inf = sgpr(inf);
+                        if (!found) break;                                               // no event lane left behind the cursor
                         if (fq - cur >= ((inf >> 8) & 15u)) { keep_dense = false; SQY_REASON(11); break; }
-                        {
-                            // (lane select through m0: two different SGPRs exceed the constant bus)
-                            uint32_t km;
-                            asm("s_mov_b32 %2, m0\n\ts_mov_b32 m0, %5\n\tv_writelane_b32 %0, %3, m0\n\tv_writelane_b32 %1, %4, m0\n\ts_mov_b32 m0, %2"
-                                : "+v"(q_fq), "+v"(q_inf), "=&s"(km) : "s"(fq), "s"(inf), "s"(nseq));
-                        }
-                        nseq += 1; cur = fq + (inf & 31u);                              // behind the match (may lie beyond the batch)
+                        // the cursor lane's record, settled: the chain reads it again and goes on
+                        epk = lane_write(epk, sgpr(W_OK | (fq << 8) | ((fq + (inf & 31u)) << 16)), sgpr(cur));
+                        einf = lane_write(einf, inf, sgpr(cur));
                         SQY_STAMP(26);
                     }
-                    const uint64_t nins = inside_matches();
-                    // the probes the parse passed over enter the table: everything in front of the cursor that is not inside a match
-                    const uint64_t ins = ~nins & (cur < 64u ? (1ull << cur) - 1ull : ~0ull);
+                    const uint32_t nseq = (uint32_t)__builtin_popcountll(chain);
                     SQY_REASON(8);
 #ifdef SQY_LZ4_DIAG
                     dreason[9] += nseq;
 #endif
                     SQY_STAMP(22);
                     if (nseq == 0) { dense_next = false; SQY_REASON(12); break; }        // (P - 2 is in the table: put2 stays empty)
-                    if ((ins >> lane) & 1ull) atomicMax(&table[h], mine);
-                    wave_lds_sync();
-                    // ---- write the sequences: lane k = sequence k ----
+                    // the probes the parse passed over enter the table: every lane in front of the cursor that is not strictly inside a match
+                    // (but for a match's ip - 2) -- each lane asks the record of the chain lane it belongs to
                     {
-                        const bool on = (uint32_t)lane < nseq;
-                        // sequence k from its probe lane and verdict word: the anchor is where the sequence in front of it ended (lane k - 1,
-                        // one DPP step; 0 for the first), the catch-up takes what the literals and the bytes known equal in front allow
-                        const uint32_t q_df = q_inf & 31u, q_bk = (q_inf >> 5) & 7u, q_off = q_inf >> 16;
-                        const uint32_t q_ipn = q_fq + q_df;
-                        const uint32_t q_anc = __builtin_amdgcn_update_dpp(0u, q_ipn, 0x111, 0xf, 0xf, false);   // row_shr:1
-                        const uint32_t q_lit0 = q_fq - q_anc;
+                        const uint64_t cs = chain & ((2ull << (uint32_t)lane) - 1ull);
+                        const uint32_t c = 63u - (uint32_t)__builtin_clzll(cs | 1ull);
+                        const uint32_t wq = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(c << 2), (int)epk);
+                        const uint32_t fqc = (wq >> 8) & 63u, nxc = wq >> 16;
+                        const bool ins = (uint32_t)lane < cur && ((uint32_t)lane <= fqc || (uint32_t)lane + 2u == nxc);
+                        if (ins) atomicMax(&table[h], mine);
+                    }
+                    wave_lds_sync();
+                    // ---- write the sequences: lane c of `chain` = the sequence whose anchor is lane c ----
+                    {
+                        const bool on = (chain >> (uint32_t)lane) & 1ull;
+                        // the catch-up takes what the literals and the bytes known equal in front allow
+                        const uint32_t q_fq = (epk >> 8) & 63u;
+                        const uint32_t q_df = einf & 31u, q_bk = (einf >> 5) & 7u, q_off = einf >> 16;
+                        const uint32_t q_lit0 = q_fq - (uint32_t)lane;
                         const uint32_t q_back = q_bk < q_lit0 ? q_bk : q_lit0;
                         const uint32_t q_lit = q_lit0 - q_back, q_mc = q_df - 4u + q_back;
                         const uint32_t ext = q_mc >= 15u ? 1u : 0u;                     // match code <= 15: at most one extension byte (0)
                         const uint32_t sb = on ? 1u + q_lit + 2u + ext : 0u;
-                        uint32_t inc = sb;                                              // inclusive prefix sum over the first 16 lanes (one DPP row)
+                        uint32_t inc = sb;                                              // inclusive prefix sum over the wave
                         inc += __builtin_amdgcn_update_dpp(0u, inc, 0x111, 0xf, 0xf, false);   // row_shr:1
                         inc += __builtin_amdgcn_update_dpp(0u, inc, 0x112, 0xf, 0xf, false);   // row_shr:2
                         inc += __builtin_amdgcn_update_dpp(0u, inc, 0x114, 0xf, 0xf, false);   // row_shr:4
                         inc += __builtin_amdgcn_update_dpp(0u, inc, 0x118, 0xf, 0xf, false);   // row_shr:8
-                        const uint32_t total = lane_read(inc, nseq - 1u);
+                        inc += __builtin_amdgcn_update_dpp(0u, inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
+                        inc += __builtin_amdgcn_update_dpp(0u, inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
+                        const uint32_t total = lane_read(inc, 63);
                         const uint32_t my_op = op + inc - sb;
                         // upstream's two limit checks per sequence (no literal-length extension below 15 literals)
                         const bool bad = on && (my_op + 1u + q_lit + (2 + 1 + LZ4_LASTLITERALS) > olimit ||
                                                 my_op + 1u + q_lit + 2u + (1 + LZ4_LASTLITERALS) + ext > olimit);
                         if (ballot(bad)) { failed = true; break; }
                         o.reserve(op, total);
-                        const uint4 l16 = w.lds128(P + q_anc);                          // the literals start at the sequence's anchor
+                        const uint4 l16 = s16;                                          // the literals start at the sequence's anchor: my own lane
                         // the sequence as five little-endian words: token, literals, offset, (extension byte 0), exact length sb;
                         // whole words leave as (unaligned) word stores, the 0..3 bytes behind them as byte stores
                         const uint32_t tok = (q_lit << 4) | q_mc;                       // (q_mc <= 15 is its own token nibble)
@@ -1685,6 +1685,18 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         // 32 in a row: a stream of short sequences, this chunk goes to the DENSE kernel
                         shorts = ml < 12u ? shorts + 1u : 0u;
                         if (shorts >= 32u && redo_list) { redo_dense = true; break; }
+                    } else if (LINKED) {
+                        // (round 5) the block-parallel parse's guesses (mode 1): a stream of short sequences -- the top plane of a quantised
+                        // stack, ~35 000 sequences per block -- is given up here, warm-up or not: its guess fails anyway (on such data nearly
+                        // every look-up finds a candidate, any difference between the guessed and the true table changes a match and with it
+                        // the positions that enter the table: tools/segment_convergence.c), and the run it belongs to is parsed again in order
+                        // by the kernel with the dense batches (mode 2).  The block's tables on record are made impossible below, so that it
+                        // and the block behind it fail the check.  (2048 in a row: the sparse planes of a diff3x3x1 residual have stretches
+                        // of short matches too, and are better off here.)
+                        if constexpr (LINKED) if (spec_mode == 1u) {
+                            shorts = ml < 12u ? shorts + 1u : 0u;
+                            if (shorts >= 2048u && !(blocks[b_last - 1u].flags & 1u)) { redo_dense = true; break; }
+                        }
                     }
                 }
                 if (finished || failed || redo_dense) break;
@@ -2070,14 +2082,24 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
     if (lane == 0) {
-        if (!DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
-        else if (!LINKED || bi >= b_out) csize[blk] = failed ? 0u : op;
+        if (!LINKED && !DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
+        else if (!LINKED || (bi >= b_out && !redo_dense)) csize[blk] = failed ? 0u : op;      // (LINKED && redo_dense: given up, see below)
     }
     if (LINKED) __syncthreads();
     if constexpr (LINKED) if (spec_mode && bi >= b_out) {
         uint32_t* __restrict__ tf = dd.tables + (uint64_t)bi * kLz4SpecTableWords + 4096u;
 #pragma unroll 4
         for (int i = 0; i < 64; ++i) tf[i * 64 + lane] = table[i * 64 + lane];
+    }
+    if constexpr (LINKED && !DENSE) if (redo_dense) {
+        // given up (mode 1, see the lean loop): a table entry with bit 31 set exists in no table -- the block this wavefront was to
+        // deliver neither passes the check nor lets the block behind it pass
+        if (lane == 0) {
+            uint32_t* __restrict__ t0 = dd.tables + (uint64_t)(b_last - 1u) * kLz4SpecTableWords;
+            __hip_atomic_store(&t0[0], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&t0[4096], 0xffffffffu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        break;
     }
   }
 #ifdef SQY_LZ4_DIAG
@@ -4909,6 +4931,14 @@ hipError_t launch_lz4_linked_spec(const uint8_t* in, const Lz4Block* blocks, con
     if (nwaves == 0) return hipSuccess;
     if (max_block == 0 || max_block > (4u << 20) || !spec.wave_first || !spec.wave_last || !spec.tables || (spec.mode != 1 && spec.mode != 2))
         return hipErrorInvalidValue;
+    // mode 2 (runs of blocks whose guess failed, parsed again in order): the kernel with the dense batches -- it is the lean kernel
+    // until it meets two short matches in a row, and 2.4 x faster per block on streams of short sequences, where a run can be
+    // hundreds of blocks long (round 5; 50 KiB of LDS per wavefront, which a handful of runs do not mind)
+    if (acceleration <= 1 && spec.mode == 2) {
+        hipLaunchKernelGGL((lz4_chunks_kernel<true, true>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, spec SQY_DIAG_NULL);
+        return hipGetLastError();
+    }
     if (acceleration > 1)
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
                            (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, spec SQY_DIAG_NULL);

@@ -90,6 +90,38 @@ def test_config5_slab_2048x2048x256_u16_quantiser_bitswap1_lz4(sqy, oracle):
     assert err.max() <= int((hi - lo).max())
 
 
+@pytest.mark.parametrize("pipeline", ["diff3x3x1->bitswap1->lz4", "quantiser->bitswap1->lz4"])
+def test_serial_layout_of_the_c3_and_c5_slabs(sqy, oracle, pipeline):
+    """nthreads = 1 -- what the HDF5 filter (sqy_h5_filter.c) and the sqy tool pass by default, and every unchanged caller of the
+    reference -- at slab size on the other two BASELINE pipelines: ONE block-linked frame (lz4_utils.hpp:99-173, lz4.hpp:227-234),
+    the blob byte for byte the oracle's, and the decode of it.  These are the streams on which the block-parallel parse's table
+    guesses fail: a few dozen short runs on the diff3x3x1 planes, the whole sequence-heavy top plane of the quantised stack as ONE
+    run of 511 blocks, which is parsed in order by the kernel with the dense batches (seconds, not milliseconds: DESIGN.md 3)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    shape = (256, 2048, 2048)
+    vol = synth.stack_torch(shape, np.uint16, dev)
+    cap = sqy.max_compressed_length(pipeline, shape, np.uint16)
+    out = torch.empty(cap, dtype=torch.uint8, device=dev)
+    rc, n = sqy.encode_device(pipeline, vol.data_ptr(), shape, np.uint16, out.data_ptr(), cap, nthreads=1)
+    assert rc == 0
+    host_vol = vol.cpu().numpy()
+    blob = out[:n].cpu().numpy().tobytes()
+    del vol, out
+    torch.cuda.empty_cache()
+    want = oracle.pipeline_encode(pipeline, host_vol, nthreads=1)
+    assert len(blob) == len(want) and blob == want, "HIP blob (serial layout) differs from the oracle blob"
+    h = oracle.header_unpack(blob)
+    body = np.frombuffer(blob, np.uint8)[h["size"]:]
+    assert body[:7].tobytes() == bytes([0x04, 0x22, 0x4D, 0x18, 0x40, 0x50, 0x77]) and body[-4:].tobytes() == b"\0\0\0\0"     # one frame
+    rc, back = sqy.decode(blob, nthreads=1)
+    assert rc == 0
+    if "quantiser" in pipeline:
+        assert np.array_equal(back, oracle.pipeline_decode(blob))
+    else:
+        assert np.array_equal(back, host_vol)
+
+
 def test_config1_256cubed_u16_host_abi(sqy, oracle):
     """configs[0] (the reference's CPU-runnable case) through the HOST-pointer ABI, nthreads = all cores"""
     vol = synth.stack((256, 256, 256))
