@@ -109,6 +109,7 @@ static uint32_t verdict(const uint8_t* src, uint32_t pos, uint32_t cand)
 
 static long g_batches, g_seqs, g_plain, g_dupsteps, g_dup_mate, g_slow, g_fast_dup, g_passed_dup, g_chain_steps, g_scalar_steps, g_end_lit;
 static long g_case[8], g_rank[8], g_groups, g_duplanes;
+static long g_x_dup, g_x_self2, g_x_table, g_x_slow, g_x_lit_self1, g_x_lit_self2, g_x_lit_other, g_x_lit_front;
 
 int main(int argc, char** argv)
 {
@@ -167,6 +168,42 @@ int main(int argc, char** argv)
                     cur = e;
                 }
                 w1.nseq = nseq; w1.cur = cur;
+            }
+            /* ---- statistics for the "event at the cursor" rule: lane i is an event lane, shares its bucket with earlier lanes; the cursor stands
+               at i itself (no literals).  i-1 and i-3 lie inside the match that just ended, i-2 is its ip-2: if i-2 is a mate it is the
+               candidate (the verdict against pos-2 comes out of the lane's own bytes); if the bucket's FIRST lane is i-3 or later and i-2 is
+               no mate, no mate has entered the table: the table entry is the candidate.  Else: history decides. ---- */
+            {
+                uint64_t evm = M | D; int cur = 0, nseq = 0; uint64_t inside = 0;
+                for (;;) {
+                    if (cur >= 64 || nseq >= 16) break;
+                    uint64_t ev = evm >> cur; if (!ev) break;
+                    int fq = cur + __builtin_ctzll(ev);
+                    uint32_t inf = infoT[fq]; int is_hit = (M >> fq) & 1;
+                    if ((D >> fq) & 1) {
+                        g_x_dup++;
+                        int first = __builtin_ctzll(mates[fq]);
+                        if (fq == cur && cur >= 2) {
+                            if ((mates[fq] >> (cur - 2)) & 1) g_x_self2++;
+                            else if (first >= cur - 3) g_x_table++;
+                            else g_x_slow++;
+                        } else if (fq == cur) g_x_slow++;      /* cur < 2: cannot happen for a dup lane but for lane 1 */
+                        else {
+                            /* event behind the cursor (literals in between): nearest mate at or behind the cursor? */
+                            int m1 = 63 - __builtin_clzll(mates[fq]);
+                            if (m1 >= cur) { if (m1 == fq - 1) g_x_lit_self1++; else if (m1 == fq - 2) g_x_lit_self2++; else g_x_lit_other++; }
+                            else g_x_lit_front++;
+                        }
+                        uint64_t m = mates[fq] & ~inside;
+                        if (m) { int qm = 63 - __builtin_clzll(m); inf = verdict(src, P + fq, P + qm); is_hit = (inf & 31) >= 4; }
+                        if (!is_hit) { evm &= ~(1ull << fq); continue; }
+                    }
+                    if ((uint32_t)(fq - cur) >= ((inf >> 8) & 15)) break;
+                    nseq++;
+                    int e = fq + (inf & 31);
+                    for (int c = fq + 1; c < e && c < 64; ++c) if (c != e - 2) inside |= 1ull << c;
+                    cur = e;
+                }
             }
             /* ---- (2) round 5: per-cursor answers, then the chain ---- */
             walk_t w2; memset(&w2, 0, sizeof w2); w2.keep = 1;
@@ -269,6 +306,9 @@ int main(int argc, char** argv)
     printf("round-4 walk: plain steps %ld, same-bucket steps %ld (%.1f %%), of those with a mate in the table %ld\n", g_plain, g_dupsteps, 100.0 * g_dupsteps / (g_plain + g_dupsteps + 1e-9), g_dup_mate);
     printf("  buckets with two or more lanes per batch %.2f, lanes with an earlier mate per batch %.2f; same-bucket steps by the rank of the mate that was the candidate: nearest %ld, 2nd %ld, 3rd %ld, 4th %ld, 5th %ld, further %ld\n",
            (double)g_groups / g_batches, (double)g_duplanes / g_batches, g_rank[1], g_rank[2], g_rank[3], g_rank[4], g_rank[5], g_rank[6]);
+    printf("same-bucket event lanes %ld: AT the cursor -> candidate is lane-2 (own bytes) %ld, -> the table entry (bucket starts at lane-3 or later) %ld, history decides %ld; "
+           "BEHIND the cursor -> nearest mate is lane-1 %ld, lane-2 %ld, another lane of the literal run %ld, a lane in front of the cursor %ld\n",
+           g_x_dup, g_x_self2, g_x_table, g_x_slow, g_x_lit_self1, g_x_lit_self2, g_x_lit_other, g_x_lit_front);
     printf("round-5 walk: chain steps %ld, SLOW sequences %ld (%.2f per batch)\n", g_chain_steps, g_slow, g_batches ? (double)g_slow / g_batches : 0);
     printf("  SLOW events by what the candidate turned out to be: table %ld, nearest mate %ld, 2nd %ld, 3rd %ld, 4th %ld, 5th %ld, further %ld; plain lanes met on the way %ld\n",
            g_case[0], g_case[1], g_case[2], g_case[3], g_case[4], g_case[5], g_case[6], g_case[7]);

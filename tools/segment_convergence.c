@@ -90,7 +90,7 @@ int main(int argc, char** argv)
     seq_t* S = malloc(sizeof(seq_t) * chunk);
     int32_t* at = malloc(sizeof(int32_t) * (chunk + 1));
     static uint32_t table[4096];
-    long n_seg = 0, n_conv = 0, n_nosync = 0;
+    long n_seg = 0, n_conv = 0, n_nosync = 0, n_hand = 0, n_hand_ok = 0, n_hand_table = 0, n_hand_anchor = 0;
     double sum_sync = 0, sum_bad = 0, sum_seqs = 0, sum_runs = 0;
     for (long c0 = 0; c0 + chunk <= total; c0 += chunk) {
         const uint8_t* src = buf + c0;
@@ -130,6 +130,25 @@ int main(int argc, char** argv)
                 if (found > 0) printf("   tables equivalent at shared anchor #%d (+%u); %d buckets differ at the first\n", found, where - s, ndiff0);
                 else printf("   tables never equivalent in %d shared anchors; %d buckets differ at the first\n", tries, ndiff0);
             }
+            {   /* the hand-over as a kernel would do it without looking for a SHARED anchor: the wavefront in front stops at ITS first anchor at
+                   or behind the border, the one behind starts counting at ITS first anchor at or behind the border -- the same anchor? */
+                size_t a = 0; while (a < nt && T[a].anchor < s) ++a;
+                size_t b = 0; while (b < nsp && S[b].anchor < s) ++b;
+                n_hand++;
+                if (a < nt && b < nsp && T[a].anchor == S[b].anchor) {
+                    static uint32_t ta[4096], tb[4096];
+                    const uint32_t A = T[a].anchor;
+                    memset(ta, 0, sizeof ta); memset(tb, 0, sizeof tb);
+                    parse(src, chunk, 0, ta, NULL, 0, A);
+                    parse(src, chunk, st, tb, NULL, 0, A);
+                    int nd = 0;
+                    for (int h = 0; h < 4096; ++h) {
+                        int ra = ta[h] + 65535u >= A && ta[h] != 0, rb = tb[h] + 65535u >= A && tb[h] != 0;
+                        if (ra != rb || (ra && ta[h] != tb[h])) nd++;
+                    }
+                    if (!nd) n_hand_ok++; else n_hand_table++;
+                } else n_hand_anchor++;
+            }
             long bad = 0, seqs = 0, runs = 0, inrun = 0;
             uint32_t lastbad = 0;
             for (; i < nsp && S[i].anchor < e; ++i) {
@@ -147,5 +166,7 @@ int main(int argc, char** argv)
     }
     printf("== %ld segments, %ld converge outright, %ld never share an anchor; mean sync +%.0f B; %.2f %% of the sequences differ, %.1f runs per segment\n",
            n_seg, n_conv, n_nosync, n_seg ? sum_sync / n_seg : 0, sum_seqs ? 100.0 * sum_bad / sum_seqs : 0, n_seg ? sum_runs / n_seg : 0);
+    printf("== hand-over at each parse's OWN first anchor at or behind the border: %ld borders, %ld equal anchor + equivalent tables, %ld equal anchor but tables differ, %ld different anchors\n",
+           n_hand, n_hand_ok, n_hand_table, n_hand_anchor);
     return 0;
 }
