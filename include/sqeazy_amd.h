@@ -193,12 +193,7 @@ SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
  *   "block_parallel_warmup"           65536 [SQY_BLOCK_PARALLEL_WARMUP=<bytes>, 0 .. 2^30]  stream parsed in front of a block to guess its table
  *   "block_parallel_stats"            0 [SQY_BLOCK_PARALLEL_STATS=1]  print the blocks whose guess failed
  *   "tail_scan"                       1 [SQY_NO_TAIL_SCAN=1 -> 0]  serial-layout decode: the walk over the block tails as a scan
- *   "chunk_split"                     1 [SQY_CHUNK_SPLIT=0..3]  frames in place: sparse, sequence-heavy 256 KiB chunks are parsed by four wavefronts at
- *                                     once (64 KiB segments behind 64 KiB warm-ups, every hand-over verified, anything that fails parsed again in
- *                                     one piece -- the bytes never change).  0 never; 1 when the call has the device to itself (a call then is as long
- *                                     as its slowest chunk and the wave slots idle; with other calls in flight the slots are what is short); 2 always;
- *                                     3 always and every chunk (the tests' way into the verify and fall-back paths)
- * Set: 0 = done, 1 = unknown name or value out of range (0 / 1 but for the warm-up bytes and chunk_split).  Get: the value, -1 for an unknown name. */
+ * Set: 0 = done, 1 = unknown name or value out of range.  Get: the value, -1 for an unknown name. */
 SQY_FUNCTION_PREFIX int SQYAMD_Set_Option(const char* name, long value);
 SQY_FUNCTION_PREFIX long SQYAMD_Get_Option(const char* name);
 

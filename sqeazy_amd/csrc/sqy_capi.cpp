@@ -66,16 +66,10 @@ struct Options {
     std::atomic<long> block_parallel_warmup;            // bytes parsed in front of a block to guess its table
     std::atomic<long> block_parallel_stats;             // print the blocks that failed the table check
     std::atomic<long> tail_scan;                        // serial-layout decode: the walk over the tails as a scan
-    std::atomic<long> chunk_split;                      // sequence-heavy chunks parsed by several wavefronts: 0 never, 1 when this call has the device
-                                                        // to itself (the default), 2 always, 3 always and EVERY chunk (tests: the fall-back paths)
-    std::atomic<long> chunk_split_segments;             // .. how many (2, 4 or 8 per 256 KiB chunk)
-    std::atomic<long> chunk_split_slots;                // .. at most this many chunks per call (more qualify: nobody is split)
     Options()
         : transpose_chain(env_flag("SQY_NO_TRANSPOSE_CHAIN") ? 0 : 1), transpose_chain_caller_streams(env_flag("SQY_TRANSPOSE_CHAIN_CALLER_STREAMS")),
           block_parallel(env_flag("SQY_NO_BLOCK_PARALLEL") ? 0 : 1), block_parallel_warmup(env_number("SQY_BLOCK_PARALLEL_WARMUP", 65536, 0, kWarmupMax)),
-          block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1),
-          chunk_split(env_number("SQY_CHUNK_SPLIT", 1, 0, 3)), chunk_split_segments(env_number("SQY_CHUNK_SPLIT_SEGMENTS", 4, 2, 8)),
-          chunk_split_slots(env_number("SQY_CHUNK_SPLIT_SLOTS", 768, 1, 4096)) {}
+          block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1) {}
     std::atomic<long>* find(const char* name)
     {
         if (!name) return nullptr;
@@ -85,9 +79,6 @@ struct Options {
         if (!std::strcmp(name, "block_parallel_warmup")) return &block_parallel_warmup;
         if (!std::strcmp(name, "block_parallel_stats")) return &block_parallel_stats;
         if (!std::strcmp(name, "tail_scan")) return &tail_scan;
-        if (!std::strcmp(name, "chunk_split")) return &chunk_split;
-        if (!std::strcmp(name, "chunk_split_segments")) return &chunk_split_segments;
-        if (!std::strcmp(name, "chunk_split_slots")) return &chunk_split_slots;
         return nullptr;
     }
 };
@@ -192,12 +183,11 @@ struct Workspace {
     DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan, dedupe;
     DevBuf spec;              // block-linked frames parsed block-parallel: per block the table it started from and the one it left, the walk lists
     DevBuf diff_side;         // diff3x3x1 in front of a 16-bit bitswap1: the columns the stage can touch (outside the ping/pong rotation)
-    DevBuf seg;               // chunks parsed by several wavefronts (Lz4SegArgs): slots, marks, the entry / exit tables
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
     void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
-        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release(); spec.release(); seg.release();
+        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release(); spec.release();
     }
 };
 
@@ -340,16 +330,6 @@ struct ContextLease {
     ContextLease(const ContextLease&) = delete;
     ContextLease& operator=(const ContextLease&) = delete;
 };
-
-// calls in flight on the current device (this one included)
-int busy_contexts()
-{
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return 0;
-    std::lock_guard<std::mutex> lock(g_pool_mu);
-    for (auto& c : g_pool[dev]) n += c->busy ? 1 : 0;
-    return n;
-}
 
 // Every exit of an encode / decode -- the early error returns included -- leaves the stream idle before the context goes
 // back to the pool: kernels and async copies still in flight would otherwise read host vectors that are being destroyed
@@ -848,29 +828,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         // frames in place (acceleration 1): only the key table is built here, the decision per chunk (byte compare, hole fill)
                         // is the first thing the chunk's parse wavefront does (lz4_chunk_dedupe)
                         fused_dedupe = lz4_inplace && lz4_accel == 1;
-                        // Round 5: with the device to itself -- one call at a time, what the sqy tool, the HDF5 filter and a BridJ caller do -- a call
-                        // is as long as its transpose plus its slowest chunk, and most wave slots idle while that chunk is parsed: the sparse,
-                        // sequence-heavy chunks (nominated by the key kernel) are then parsed by several wavefronts at once, 64 KiB segments
-                        // behind 64 KiB warm-ups, verified (sqy_kernels.h: Lz4SegArgs).  Twice the parse work for those chunks: not with
-                        // other calls in flight, where the wave slots are what the step is short of.
-                        const long split_opt = g_opt.chunk_split.load();
-                        sqy::Lz4SegArgs seg_args;
-                        const uint32_t nseg = (uint32_t)g_opt.chunk_split_segments.load();
-                        if (fused_dedupe && lz4_holes && split_opt && (split_opt >= 2 || busy_contexts() <= 1) && lz4_chunk % (65536u * nseg) == 0 &&
-                            lz4_chunk <= (512u << 10) && !lz4_frame_map) {
-                            const uint32_t max_slots = (uint32_t)std::min<uint64_t>((uint64_t)g_opt.chunk_split_slots.load(), lz4_nchunks);
-                            if (!ws->seg.ensure(sqy::lz4_seg_work_bytes(lz4_nchunks, nseg, max_slots))) {
-                                sqy::lz4_seg_layout(ws->seg.p, lz4_nchunks, nseg, max_slots, &seg_args);
-                                seg_args.seg_bytes = (uint32_t)(lz4_chunk / nseg);
-                                // liblz4's reach plus room for the guess to fall in step with the true parse: what the two entered differently
-                                // before that is out of reach (dead in both tables) by the time the segment begins
-                                seg_args.warm = 65536 + 16384;
-                                seg_args.piece_bytes = (uint32_t)(lz4_stride / nseg) & ~15u;
-                            }
-                        }
                         SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride, lz4_holes,
-                                                       dedupe_cleared, fused_dedupe ? &lz4_dedupe_args : nullptr, seg_args.nseg ? &seg_args : nullptr,
-                                                       split_opt == 3));
+                                                       dedupe_cleared, fused_dedupe ? &lz4_dedupe_args : nullptr));
                         lz4_dup_of = d_dup;
                     }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
@@ -881,22 +840,6 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                                        static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, stream, lz4_frame_map, lz4_frame_bytes, d_redo,
                                                        fused_dedupe ? nullptr : lz4_dup_of, lz4_in_stride, lz4_accel, dedupe_cleared,
                                                        fused_dedupe ? &lz4_dedupe_args : nullptr));
-                    }
-                    if (fused_dedupe && lz4_dedupe_args.seg.nseg) {
-                        // the chunks parsed in segments: accepted and made one piece, or onto the dense list (parsed again below)
-                        ProfScope ps("lz4_seg_verify", stream, pend);
-                        SQY_HIP(sqy::launch_lz4_seg_verify(lz4_dedupe_args.seg, lz4_total, (uint32_t)lz4_chunk, static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride,
-                                                           static_cast<uint32_t*>(ws->csize.p), d_redo, lz4_dup_of, stream));
-                        if (g_opt.block_parallel_stats.load()) {
-                            uint32_t cnt[8] = {0}, nredo = 0;
-                            SQY_HIP(hipMemcpyAsync(cnt, lz4_dedupe_args.seg.slot_count, 32, hipMemcpyDeviceToHost, stream));
-                            SQY_HIP(hipMemcpyAsync(&nredo, d_redo, 4, hipMemcpyDeviceToHost, stream));
-                            SQY_HIP(hipStreamSynchronize(stream));
-                            std::fprintf(stderr, "[sqeazy]\t lz4 chunk split: %u of %llu chunks nominated (%s), %u chunks on the dense list behind the check "
-                                                 "(turned down: %u a wavefront failed, %u anchors differ, %u did not end at the chunk's end, %u too close to the capacity, %u tables differ)\n",
-                                         cnt[0], (unsigned long long)lz4_nchunks, cnt[0] > lz4_dedupe_args.seg.max_slots ? "too many: nobody is split" : "split", nredo,
-                                         cnt[1], cnt[2], cnt[3], cnt[4], cnt[5]);
-                        }
                     }
                     auto dense_pass = [&](uint32_t n_redo) -> int {
                         ProfScope ps("lz4_chunks_dense", stream, pend);
@@ -2082,9 +2025,6 @@ int SQYAMD_Set_Option(const char* name, long value)
     std::atomic<long>* o = g_opt.find(name);
     if (!o) return 1;
     if (o == &g_opt.block_parallel_warmup) { if (value < 0 || value > kWarmupMax) return 1; }
-    else if (o == &g_opt.chunk_split) { if (value < 0 || value > 3) return 1; }
-    else if (o == &g_opt.chunk_split_segments) { if (value != 2 && value != 4 && value != 8) return 1; }
-    else if (o == &g_opt.chunk_split_slots) { if (value < 1 || value > 4096) return 1; }
     else if (value != 0 && value != 1) return 1;
     o->store(value);
     return 0;

@@ -9,31 +9,7 @@ namespace sqy {
 
 // the duplicate search's tables, handed to launch_lz4_chunks when the decision per chunk is made by the chunk's own parse wavefront
 // (launch_lz4_dedupe(.., fused) fills it in); chunk_key == nullptr: not in use
-// Round 5: a sequence-heavy chunk parsed by SEVERAL wavefronts at once (frames in place, one call at a time: "latency mode").
-// The chunk is cut into nseg segments of seg_bytes; wavefront s starts from an empty table `warm` bytes in front of its segment
-// (wavefront 0 and 1 at the chunk's start: theirs is the true parse), and its output counts from its first anchor at or behind the
-// segment's start (the ENTRY mark: anchor + table on record) to its first anchor at or behind the next segment's start (the EXIT mark).
-// lz4_seg_verify_kernel accepts a chunk when every exit mark equals the next wavefront's entry mark -- same anchor, tables equal on
-// every entry still within liblz4's reach -- which, by induction from wavefront 0, makes the concatenated pieces liblz4's parse;
-// anything else (and output within 64 bytes of the capacity, where a limit check of the one-piece parse could have fired) sends the
-// chunk to the dense kernel, which parses it again in one piece.  Where that holds: tools/segment_convergence.c (the sparse planes of a
-// microscopy stack: always; a diff3x3x1 residual: sometimes; low-entropy noise: never) -- the key kernel only nominates chunks
-// with some, but not only, all-zero 1 KiB pieces, and nobody is split when more than max_slots chunks qualify.
-struct Lz4SegArgs {
-    uint32_t nseg = 0;                   // 0: off; else 2, 4 or 8
-    uint32_t nseg_log2 = 0;
-    uint32_t seg_bytes = 0;
-    uint32_t warm = 65536;
-    uint32_t piece_bytes = 0;            // room of one wavefront's output inside the chunk's scratch slot (stride / nseg, a multiple of 16)
-    uint32_t max_slots = 0;
-    uint32_t* slot_of = nullptr;         // [nchunks] split slot of a chunk, ~0u: none              (lz4_dedupe_key_kernel)
-    uint32_t* slot_count = nullptr;      // [1] chunks that qualified (> max_slots: nobody is split)
-    uint32_t* chunk_of = nullptr;        // [max_slots]
-    uint32_t* tables = nullptr;          // [max_slots][nseg][2][4096]: entry / exit table of every wavefront
-    uint32_t* marks = nullptr;           // [max_slots][nseg][4]: entry anchor, exit anchor, bytes, flags (1 = failed)
-};
 struct Lz4DedupeArgs {
-    Lz4SegArgs seg;
     const uint64_t* chunk_key = nullptr;
     const uint64_t* tab_key = nullptr;
     const uint32_t* tab_val = nullptr;
@@ -62,14 +38,7 @@ uint64_t lz4_dedupe_work_bytes(uint64_t nchunks);
 // in (writes into `in`) for every chunk anybody will read -- the bit planes above the data's range are neither written nor read
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
                              uint32_t* dup_of, hipStream_t stream, uint64_t in_stride = 0, uint64_t* holes_map = nullptr,
-                             bool table_is_clear = false, Lz4DedupeArgs* fused = nullptr, const Lz4SegArgs* seg = nullptr, bool seg_all = false);
-// bytes of Lz4SegArgs' arrays for nchunks chunks (slot_of, slot_count, chunk_of, marks, tables -- in that order, 256-byte aligned)
-uint64_t lz4_seg_work_bytes(uint64_t nchunks, uint32_t nseg, uint32_t max_slots);
-void lz4_seg_layout(void* work, uint64_t nchunks, uint32_t nseg, uint32_t max_slots, Lz4SegArgs* out);
-// behind launch_lz4_chunks(.., dedupe with seg.nseg != 0): checks the marks of every split chunk, makes the pieces of the accepted ones
-// one contiguous block (csize[k] = its bytes) and appends the others to the dense list `redo`
-hipError_t launch_lz4_seg_verify(const Lz4SegArgs& seg, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride, uint32_t* csize,
-                                 uint32_t* redo, const uint32_t* dup_of, hipStream_t stream);
+                             bool table_is_clear = false, Lz4DedupeArgs* fused = nullptr);
 // the search's table emptied and *zero_word = 0 by one small kernel (a call launches it in front of its bit-plane transpose)
 hipError_t launch_lz4_dedupe_clear(void* work, uint64_t nchunks, uint32_t* zero_word, hipStream_t stream);
 uint64_t lz4_holes_map_bytes(uint64_t nchunks, uint32_t chunk);

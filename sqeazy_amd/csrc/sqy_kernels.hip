@@ -277,8 +277,7 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
 __global__ __launch_bounds__(64)
 void lz4_dedupe_key_kernel(const uint32_t* __restrict__ piece_hash, uint32_t pieces_per_chunk, uint64_t nchunks_full,
                            uint64_t* __restrict__ chunk_key, uint64_t* __restrict__ tab_key, uint32_t* __restrict__ tab_val, uint32_t tab_mask,
-                           uint64_t* __restrict__ holes_map, uint32_t pieces_last, Lz4SegArgs seg, uint8_t* __restrict__ body0, uint64_t in_stride,
-                           uint32_t seg_all)
+                           uint64_t* __restrict__ holes_map, uint32_t pieces_last)
 {
     const uint64_t k = blockIdx.x;
     const int lane = threadIdx.x;
@@ -287,7 +286,6 @@ void lz4_dedupe_key_kernel(const uint32_t* __restrict__ piece_hash, uint32_t pie
     const uint32_t np = k < nchunks_full ? pieces_per_chunk : pieces_last;
     uint64_t* hm = holes_map ? holes_map + k * (1u + (pieces_per_chunk + 63u) / 64u) : nullptr;
     uint32_t h1 = 0, h2 = 0, any = 0, nzero = 0;
-    uint64_t zms[8] = {0, 0, 0, 0, 0, 0, 0, 0};                  // (the zero masks once more, for the hole fill below: chunks of up to 512 pieces)
     for (uint32_t base = 0; base < np; base += 64) {
         const uint32_t i = base + (uint32_t)lane;
         uint4 q = make_uint4(1u, 0u, 0u, 0u);
@@ -301,38 +299,9 @@ void lz4_dedupe_key_kernel(const uint32_t* __restrict__ piece_hash, uint32_t pie
             const uint64_t zm = ballot((q.x | q.y | q.z | q.w) == 0u);
             nzero += (uint32_t)__builtin_popcountll(zm);
             if (lane == 0) hm[1u + base / 64u] = zm;
-            if (base < 512u) zms[base / 64u] = zm;
         }
     }
     if (hm && lane == 0) hm[0] = nzero;
-    if (seg.nseg) {
-        // Round 5 (Lz4SegArgs): a full chunk with some, but not only, all-zero pieces -- the sparse planes of a microscopy stack, where a
-        // parse started mid-chunk converges -- is nominated for the parse by several wavefronts; its holes are filled in right here, so
-        // that every one of those wavefronts finds the whole chunk in memory (this kernel is over before the parse begins).
-        // (seg_all: every full chunk that is not all zero, whatever it holds -- the tests' way to reach the verify / fall-back paths)
-        const bool want = hm && k < nchunks_full && np <= 512u && nzero < np && (seg_all || (nzero >= np / 16u && nzero <= np - np / 16u));
-        uint32_t slot = ~0u;
-        if (want) {
-            if (lane == 0) slot = atomicAdd(seg.slot_count, 1u);
-            slot = sgpr(slot);
-            if (slot < seg.max_slots) {
-                if (lane == 0) seg.chunk_of[slot] = (uint32_t)k;
-                uint8_t* body = body0 + k * in_stride;
-#pragma unroll
-                for (uint32_t wi = 0; wi < 8u; ++wi) {
-                    uint64_t m = zms[wi];
-                    while (m) {
-                        const uint32_t pc = wi * 64u + ctz64(m);
-                        m &= m - 1;
-                        const v4u zero = {0, 0, 0, 0};
-                        *reinterpret_cast<v4u_any*>(body + (uint64_t)pc * 1024u + (uint32_t)lane * 16u) = zero;
-                    }
-                }
-            } else
-                slot = ~0u;
-        }
-        if (lane == 0) seg.slot_of[k] = slot;
-    }
     if (k >= nchunks_full) return;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { h1 += __shfl_xor(h1, d); h2 += __shfl_xor(h2, d); }
@@ -795,7 +764,7 @@ struct Lz4WindowT {
             const uint32_t lds_dst = (uint32_t)(uintptr_t)win + (b & (LZ4_WIN - 1));   // wave-uniform; the copy adds lane * 16
             uint32_t keep;
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src + a), "s"(sgpr(lds_dst)) : "memory");
+                         : "=&s"(keep) : "v"(src + a), "s"(lds_dst) : "memory");
         }
         nif += 1;
     }
@@ -1094,18 +1063,13 @@ __device__ __forceinline__ uint32_t lz4_linked_tag_shift(uint32_t max_block)
     return 31u - (32u - (uint32_t)__builtin_clz(pmax - 1));
 }
 
-// SEG = true (round 5; chunked layout, first pass, frames in place): Lz4SegArgs -- max_slots * nseg blocks for the wavefronts of the
-// split chunks in front of one block per chunk.
-template <bool LINKED, bool DENSE, bool ACCEL = false, bool SEG = false>
+template <bool LINKED, bool DENSE, bool ACCEL = false>
 __global__ __launch_bounds__(64)
 void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t chunk, uint64_t in_stride,
                        uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
                        const uint64_t* __restrict__ fmap, uint64_t fbytes,
                        const Lz4Block* __restrict__ blocks, const uint32_t* __restrict__ frame_first, uint32_t max_block,
-                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel, typename Lz4ExtraArgs<LINKED>::type dd,
-                       // (SEG; a parameter of its own: `dd` is handed to a noinline function by reference and lives in scratch memory from then on --
-                       // its fields come back as per-lane loads, and everything computed from them counts as divergent)
-                       const Lz4SegArgs sg SQY_DIAG_ARG)
+                       uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of, uint32_t accel, typename Lz4ExtraArgs<LINKED>::type dd SQY_DIAG_ARG)
 {
 #ifdef SQY_LZ4_DIAG
     unsigned long long dacc = 0, dt0 = 0, dcnt = 0, dreason[16] = {0};
@@ -1117,30 +1081,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __shared__ __attribute__((aligned(16))) uint8_t ring[LZ4_WIN + LZ4_MIRROR];
     __shared__ __attribute__((aligned(16))) uint8_t stage[LZ4_OB];
     const int lane = threadIdx.x;
-    // (SEG) which chunk, which segment of it, and whether the chunk is parsed in segments at all
-    // (The parse loop is at the scalar-register limit: of all this only `seg_mark` lives across it; slot, segment and marks are looked
-    // up again where an entry / exit mark or the end needs them.)
-    // Grid (SEG): blocks [0, max_slots * nseg) are the wavefronts of the split chunks -- block b = (slot b / nseg, segment b % nseg), in
-    // front so that they get their wave slots first: they are what the launch waits for --, the blocks behind them the chunks in order
-    // (the ones that are split return at once).  nseg is a power of two.
-    uint32_t kchunk = blockIdx.x;
-    auto seg_split_role = [&]() -> bool { return SEG && blockIdx.x < sg.max_slots * sg.nseg; };
-    auto seg_slot_of = [&]() -> uint32_t { return seg_split_role() ? blockIdx.x >> sg.nseg_log2 : ~0u; };
-    auto seg_index = [&]() -> uint32_t { return seg_split_role() ? blockIdx.x & (sg.nseg - 1u) : 0u; };
-    if constexpr (SEG) {
-        const uint32_t cnt = sgpr(*sg.slot_count);
-        if (seg_split_role()) {
-            if (cnt > sg.max_slots || seg_slot_of() >= cnt) return;
-            kchunk = sgpr(sg.chunk_of[seg_slot_of()]);
-        } else {
-            kchunk = blockIdx.x - sg.max_slots * sg.nseg;
-            if (cnt <= sg.max_slots && sgpr(sg.slot_of[kchunk]) != ~0u) return;
-        }
-    }
-    const uint32_t seg_i = seg_index();
-    if (!LINKED && !DENSE && dup_of && dup_of[kchunk] != kchunk) return;     // byte-identical to an earlier chunk (lz4_dedupe_*): its frame is that chunk's
-    if constexpr (!LINKED && !DENSE && !ACCEL) if (dd.chunk_key && seg_i == 0) {   // the same decision, made here (round 4); a split chunk's holes: the key kernel
-        if (lz4_chunk_dedupe(in, chunk, in_stride, total, kchunk, dd, threadIdx.x)) return;
+    if (!LINKED && !DENSE && dup_of && dup_of[blockIdx.x] != blockIdx.x) return;     // byte-identical to an earlier chunk (lz4_dedupe_*): its frame is that chunk's
+    if constexpr (!LINKED && !DENSE && !ACCEL) if (dd.chunk_key) {                     // the same decision, made here (round 4)
+        if (lz4_chunk_dedupe(in, chunk, in_stride, total, blockIdx.x, dd, threadIdx.x)) return;
         // The holes filled above are read back below by this same wavefront (loads and LDS-DMA): its stores have to have left the
         // wave (vmcnt) -- nothing more: nobody has read those addresses since the kernel began, so no cache holds an older copy.
         // (An agent-scope release here writes back the whole XCD's L2 once per chunk, next to other calls' transposes filling it:
@@ -1162,7 +1105,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             b_out = b_first;
         }
     } else {
-        b_first = DENSE ? redo_list[1 + blockIdx.x] : kchunk;
+        b_first = DENSE ? redo_list[1 + blockIdx.x] : blockIdx.x;
         b_last = b_first + 1;
     }
     uint32_t n_prev = 0;
@@ -1209,27 +1152,11 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         const int64_t r = (int64_t)mt - (mt >= p0 ? low_in : low_dict);
         return r < 0 ? 0u : (r > 0x7fffffff ? 0x7fffffffu : (uint32_t)r);
     };
-    // (SEG) a split chunk's wavefront s: its piece of the chunk's scratch slot, where its parse begins (`warm` bytes in front of its
-    // segment, from an empty table: a guess that lz4_seg_verify_kernel checks), the anchors at which its output starts / stops counting
-    uint32_t seg_start = p0, seg_cap = 0;
-    // the next mark, bit 0 = past the entry mark (marks are multiples of 64 KiB).  ~0: none; 3: stopped at the exit mark
-    uint32_t seg_mark = 0xffffffffu;
-    auto seg_exit_of = [&]() -> uint32_t {
-        uint32_t e = 0xffffffffu;
-        if constexpr (SEG) if (seg_index() + 1u < sg.nseg) e = (seg_index() + 1u) * sg.seg_bytes;
-        return e;
-    };
-    if constexpr (SEG) if (seg_slot_of() != ~0u) {
-        const uint32_t entry = seg_i * sg.seg_bytes;
-        seg_start = entry > sg.warm ? entry - sg.warm : 0u;
-        seg_cap = sg.piece_bytes;
-        seg_mark = seg_i == 0 ? (seg_exit_of() | 1u) : entry;
-    }
-    uint8_t* __restrict__ dst = scratch + blk * stride + (SEG ? (uint64_t)seg_i * seg_cap : 0ull);
+    uint8_t* __restrict__ dst = scratch + blk * stride;
 
     Lz4Window w;
-    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = pend; w.whi = seg_start; w.wlo = seg_start; w.nif = 0; w.lane16 = (uint32_t)lane * 16u;
-    w.pmin = seg_start;
+    w.src = (glb_u8*)src; w.win = (lds_u8*)ring; w.n = pend; w.whi = p0; w.wlo = p0; w.nif = 0; w.lane16 = (uint32_t)lane * 16u;
+    w.pmin = p0;
     w.issue();
     Lz4Out o;
     o.dst = (SQY_GLB uint8_t*)dst; o.ob = (lds_u8*)stage; o.base = 0; o.lane = lane;
@@ -1268,10 +1195,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __syncthreads();
     n_prev = n;
 
-    // capacity n-1 (LZ4F_makeBlock); offsets into dst.  (A split chunk's wavefront: its piece of the slot, less the margin the verify
-    // kernel asks of the sum -- whether a limit check of the one-piece parse could have fired is decided there.)
-    const uint32_t olimit = (SEG && seg_cap) ? (seg_cap - 64u < n - 1u ? seg_cap - 64u : n - 1u) : n - 1;
-    uint32_t op = 0, anchor = seg_start;
+    const uint32_t olimit = n - 1;       // capacity n-1 (LZ4F_makeBlock); offsets into dst
+    uint32_t op = 0, anchor = p0;
     bool failed = false;
     bool redo_dense = false;             // first pass: this chunk is left to the DENSE kernel
 
@@ -1284,13 +1209,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             if (lane == 0) table[lz4_hash5(s0)] = (p0 << tsh) | tag_of((uint32_t)s0);
             wave_lds_sync();
         }
-        if (SEG && seg_start > p0) {
-            // the guess starts like a chunk does: LZ4_putPosition on its first byte, the search from the byte behind it
-            const uint64_t s0 = glb_ld_u64((glb_u8*)src + seg_start);
-            if (lane == 0) table[lz4_hash5(s0)] = (seg_start << tsh) | tag_of((uint32_t)s0);
-            wave_lds_sync();
-        }
-        uint32_t P = seg_start + 1, U = 1;      // first probe of the block: search from ip = first byte + 1
+        uint32_t P = p0 + 1, U = 1;      // first probe of the block: search from ip = first byte + 1
         uint32_t put2 = 0xffffffffu;     // position whose hash has to enter the table before the next batch (ip - 2)
 
         // A sequence found by the lean path is written out one iteration LATER, between the issue of the next batch's
@@ -1343,22 +1262,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
         for (;;) {
             SQY_STAMP(0);
-            if constexpr (SEG) if (U == 0 && anchor >= (seg_mark & ~1u)) {
-                // right behind a match (anchor == P, its ip - 2 still to enter the table: the same state in every parse that ends a
-                // match here) at or behind a mark
-                if (pend) { emit_pending(); if (failed) break; }
-                if (!(seg_mark & 1u)) {
-                    // ENTRY: from here on the output counts; anchor and table go on record (what the wavefront in front must have left)
-                    const uint64_t rec = blockIdx.x;                        // = slot * nseg + segment
-                    uint32_t* __restrict__ tf = sg.tables + rec * 8192u;
-#pragma unroll 4
-                    for (int i = 0; i < 64; ++i) tf[i * 64 + lane] = table[i * 64 + lane];
-                    if (lane == 0) sg.marks[rec * 4u] = anchor;
-                    op = 0; o.base = 0;
-                    seg_mark = seg_exit_of() | 1u;
-                }
-                if (anchor >= (seg_mark & ~1u)) { seg_mark = 3u; break; }     // EXIT: the wavefront behind takes over from this very state
-            }
             // Skip-accelerated probing (no match for a while: incompressible data) strides over the ring: at a step of 16 bytes a
             // batch of 64 probes spans a KiB, later several -- most probes lie behind the resident range and are read from global
             // memory anyway, and refilling the ring up to P + AHEAD would cost an HBM round trip per batch for bytes nobody reads.
@@ -1774,7 +1677,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                     P = ipn;
                     SQY_STAMP(9);
                     w.ensure(P);
-                    if constexpr (SEG) if (ipn >= (seg_mark & ~1u)) { redo = true; break; }   // a mark: the round starts again (loop top)
                     if (DENSE) {
                         // two matches of less than 16 bytes in a row: back to the dense batches
                         shorts = ml < 12u ? shorts + 1u : 0u;
@@ -2157,9 +2059,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         if (pend && !failed) emit_pending();
     }
 
-    const bool seg_left = SEG && seg_mark == 3u;
-    if constexpr (SEG) if (seg_left && !failed) o.flush(op);   // stopped at the exit mark: no last literals, the wavefront behind goes on from here
-    if (!failed && !redo_dense && !seg_left) {
+    if (!failed && !redo_dense) {
         o.flush(op);
         const uint32_t lastRun = pend - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
@@ -2182,23 +2082,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
     if (lane == 0) {
-        bool marked = false;
-        if constexpr (SEG) if (seg_cap) {
-            // (entry anchor: written at the entry mark,) exit anchor, bytes, failed (lz4_seg_verify_kernel; a dense stream, a piece that
-            // outgrew its room, a wavefront that never reached its entry mark: the chunk is parsed again in one piece)
-            uint32_t* __restrict__ mk = sg.marks + (uint64_t)blockIdx.x * 4u;
-            if (seg_index() == 0) mk[0] = 0u;
-            mk[1] = seg_left ? anchor : pend; mk[2] = op; mk[3] = (failed || redo_dense || !(seg_mark & 1u)) ? 1u : 0u;
-            marked = true;
-        }
-        if (marked) { }
-        else if (!LINKED && !DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
+        if (!LINKED && !DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
         else if (!LINKED || (bi >= b_out && !redo_dense)) csize[blk] = failed ? 0u : op;      // (LINKED && redo_dense: given up, see below)
-    }
-    if constexpr (SEG) if (seg_left) {
-        uint32_t* __restrict__ tf = sg.tables + (uint64_t)blockIdx.x * 8192u + 4096u;
-#pragma unroll 4
-        for (int i = 0; i < 64; ++i) tf[i * 64 + lane] = table[i * 64 + lane];
     }
     if (LINKED) __syncthreads();
     if constexpr (LINKED) if (spec_mode && bi >= b_out) {
@@ -4872,28 +4757,9 @@ hipError_t launch_lz4_dedupe_clear(void* work, uint64_t nchunks, uint32_t* zero_
     return hipGetLastError();
 }
 
-uint64_t lz4_seg_work_bytes(uint64_t nchunks, uint32_t nseg, uint32_t max_slots)
-{
-    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
-    return up(nchunks * 4) + up(32) + up((uint64_t)max_slots * 4) + up((uint64_t)max_slots * nseg * 16) + (uint64_t)max_slots * nseg * 2 * 4096 * 4 + 256;
-}
-
-void lz4_seg_layout(void* work, uint64_t nchunks, uint32_t nseg, uint32_t max_slots, Lz4SegArgs* out)
-{
-    auto up = [](uint64_t x) { return (x + 255) & ~(uint64_t)255; };
-    uint8_t* p = reinterpret_cast<uint8_t*>((reinterpret_cast<uintptr_t>(work) + 255) & ~(uintptr_t)255);
-    out->nseg = nseg; out->max_slots = max_slots;
-    out->nseg_log2 = nseg == 8 ? 3u : nseg == 4 ? 2u : 1u;
-    out->slot_of = reinterpret_cast<uint32_t*>(p); p += up(nchunks * 4);
-    out->slot_count = reinterpret_cast<uint32_t*>(p); p += up(32);
-    out->chunk_of = reinterpret_cast<uint32_t*>(p); p += up((uint64_t)max_slots * 4);
-    out->marks = reinterpret_cast<uint32_t*>(p); p += up((uint64_t)max_slots * nseg * 16);
-    out->tables = reinterpret_cast<uint32_t*>(p);
-}
-
 hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, const uint32_t* piece_hash, void* work,
                              uint32_t* dup_of, hipStream_t stream, uint64_t in_stride, uint64_t* holes_map, bool table_is_clear,
-                             Lz4DedupeArgs* fused, const Lz4SegArgs* seg, bool seg_all)
+                             Lz4DedupeArgs* fused)
 {
     const uint64_t nchunks = (total + chunk - 1) / chunk, nfull = total / chunk;
     if (nchunks == 0) return hipSuccess;
@@ -4913,17 +4779,10 @@ hipError_t launch_lz4_dedupe(const uint8_t* in, uint64_t total, uint32_t chunk, 
     }
     if (holes_map && total % 1024u != 0) return hipErrorInvalidValue;
     const uint64_t nkey = holes_map ? nchunks : nfull;
-    const bool seg_on = seg && seg->nseg && holes_map && fused;
-    if (seg_on) {
-        e = hipMemsetAsync(seg->slot_count, 0, 8 * sizeof(uint32_t), stream);
-        if (e != hipSuccess) return e;
-    }
     if (nkey)
         hipLaunchKernelGGL(lz4_dedupe_key_kernel, dim3((unsigned)nkey), dim3(64), 0, stream, piece_hash, chunk / 1024u, nfull, chunk_key, tab_key,
-                           tab_val, tab - 1u, holes_map, (uint32_t)((total - nfull * chunk) >> 10), seg_on ? *seg : Lz4SegArgs{},
-                           const_cast<uint8_t*>(in), in_stride, seg_all ? 1u : 0u);
+                           tab_val, tab - 1u, holes_map, (uint32_t)((total - nfull * chunk) >> 10));
     if (fused) {
-        if (seg_on) fused->seg = *seg;
         // the decision per chunk is left to the chunk's parse wavefront (lz4_chunk_dedupe): only the key table is built here
         fused->chunk_key = chunk_key; fused->tab_key = tab_key; fused->tab_val = tab_val; fused->tab_mask = tab - 1u; fused->dup_of = dup_of;
         fused->piece_hash = piece_hash; fused->holes_map = holes_map; fused->nchunks_full = nfull;
@@ -5020,94 +4879,6 @@ hipError_t launch_diff3x3x1(const void* in, void* out, uint64_t Z, uint64_t Y, u
 #define SQY_DIAG_NULL
 #endif
 
-// Round 5 (Lz4SegArgs): one workgroup per split slot.  A chunk parsed in segments is accepted when no wavefront failed, every exit
-// mark is the next wavefront's entry mark -- the same anchor, and tables equal on every entry a probe at or behind that anchor can still
-// reach (an entry more than 65535 bytes in front of the anchor is dead in both) --, the last wavefront ran to the chunk's end and the
-// sum of the pieces stays 64 bytes clear of the capacity n - 1 (every limit check of the one-piece parse looks at most a few bytes
-// past the end of its sequence: none of them can have fired).  Then, by induction from wavefront 0 -- whose parse is the true one up
-// to its exit mark, where wavefront 1 stood in the same state -- the pieces in order ARE liblz4's output: they are moved together at
-// the slot's start (piece s never ends behind the start of piece s + 1's source) and csize[k] is their sum.  Anything else: the
-// chunk goes on the dense list and is parsed again in one piece.
-__global__ __launch_bounds__(256)
-void lz4_seg_verify_kernel(Lz4SegArgs seg, uint64_t total, uint32_t chunk, uint8_t* __restrict__ scratch, uint64_t stride, uint32_t* __restrict__ csize,
-                           uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ dup_of)
-{
-    const uint32_t slot = blockIdx.x;
-    const uint32_t count = *seg.slot_count;
-    if (count > seg.max_slots || slot >= count) return;
-    const uint32_t k = seg.chunk_of[slot];
-    if (dup_of && dup_of[k] != k) return;                       // byte-identical to an earlier chunk: its frame is that chunk's
-    __shared__ uint32_t s_bad;
-    __shared__ uint8_t s_buf[4096];
-    if (threadIdx.x == 0) s_bad = 0;
-    __syncthreads();
-    const uint32_t n = chunk;                                    // (only full chunks are nominated)
-    const uint32_t pos_bits = 32u - (uint32_t)__builtin_clz(n - 1u);
-    const uint32_t tsh = 31u - pos_bits;
-    const uint32_t* __restrict__ mk = seg.marks + (uint64_t)slot * seg.nseg * 4u;
-    uint32_t sum = 0, bad = 0;
-    // (slot_count[1..5]: why chunks were turned down -- a wavefront failed, anchors differ, did not end at the chunk's end, too close to the
-    // capacity, tables differ; read by the host's statistics switch only)
-    for (uint32_t s_ = 0; s_ < seg.nseg; ++s_) {
-        bad |= mk[s_ * 4u + 3u];
-        sum += mk[s_ * 4u + 2u];
-        if (s_ && mk[s_ * 4u] != mk[(s_ - 1u) * 4u + 1u]) bad |= 2u;
-    }
-    if (mk[0] != 0u || mk[(seg.nseg - 1u) * 4u + 1u] != n) bad |= 4u;
-    if (sum + 64u > n - 1u) bad |= 8u;
-    if (bad && threadIdx.x == 0)
-        for (uint32_t r = 0; r < 4u; ++r) if ((bad >> r) & 1u) atomicAdd(&seg.slot_count[1u + r], 1u);
-    if (!bad) {
-        for (uint32_t s_ = 1; s_ < seg.nseg; ++s_) {
-            const uint32_t A = mk[s_ * 4u];
-            const uint32_t* __restrict__ left = seg.tables + ((uint64_t)slot * seg.nseg + (s_ - 1u)) * 8192u + 4096u;   // what wavefront s - 1 left
-            const uint32_t* __restrict__ used = seg.tables + ((uint64_t)slot * seg.nseg + s_) * 8192u;                  // what wavefront s stood on
-            uint32_t d = 0;
-            for (uint32_t i = threadIdx.x; i < 4096u; i += 256u) {
-                uint32_t a = left[i], b = used[i];
-                if ((a >> tsh) + LZ4_MAXD < A) a = 0;             // out of reach for every probe from the anchor on
-                if ((b >> tsh) + LZ4_MAXD < A) b = 0;
-                d |= a ^ b;
-            }
-            if (d) s_bad = 1;                                    // (benign race: every writer writes 1)
-        }
-    }
-    __syncthreads();
-    if (s_bad && !bad && threadIdx.x == 0) atomicAdd(&seg.slot_count[5], 1u);
-    bad |= s_bad;
-    if (bad) {
-        if (threadIdx.x == 0) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = k;
-        return;
-    }
-    // the pieces, moved together: blocks of 4 KiB in order, every block read before it is written (a piece's destination never reaches
-    // past the part of its own source that is already read, and never into a later piece's source)
-    uint8_t* __restrict__ slot0 = scratch + (uint64_t)k * stride;
-    const uint32_t cap = seg.piece_bytes;
-    uint32_t at = mk[2];
-    for (uint32_t s_ = 1; s_ < seg.nseg; ++s_) {
-        const uint32_t len = mk[s_ * 4u + 2u];
-        const uint8_t* __restrict__ from = slot0 + (uint64_t)s_ * cap;
-        for (uint32_t o0 = 0; o0 < len; o0 += 4096u) {
-            const uint32_t m = len - o0 < 4096u ? len - o0 : 4096u;
-            for (uint32_t i = threadIdx.x; i < m; i += 256u) s_buf[i] = from[o0 + i];
-            __syncthreads();
-            for (uint32_t i = threadIdx.x; i < m; i += 256u) slot0[at + o0 + i] = s_buf[i];
-            __syncthreads();
-        }
-        at += len;
-    }
-    if (threadIdx.x == 0) csize[k] = sum;
-}
-
-hipError_t launch_lz4_seg_verify(const Lz4SegArgs& seg, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride, uint32_t* csize,
-                                 uint32_t* redo, const uint32_t* dup_of, hipStream_t stream)
-{
-    if (!seg.nseg || !seg.max_slots) return hipSuccess;
-    if (!redo || !seg.marks || !seg.tables) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(lz4_seg_verify_kernel, dim3(seg.max_slots), dim3(256), 0, stream, seg, total, chunk, scratch, stride, csize, redo, dup_of);
-    return hipGetLastError();
-}
-
 hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, uint8_t* scratch, uint64_t stride,
                              uint32_t* csize, uint64_t nchunks, hipStream_t stream, const uint64_t* frame_map, uint64_t frame_bytes,
                              uint32_t* redo, const uint32_t* dup_of, uint64_t in_stride, uint32_t acceleration, bool redo_is_zero,
@@ -5122,14 +4893,10 @@ hipError_t launch_lz4_chunks(const uint8_t* in, uint64_t total, uint32_t chunk, 
     }
     if (acceleration > 1)    // (no dense second pass: the list stays empty)
         hipLaunchKernelGGL((lz4_chunks_kernel<false, false, true>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, dup_of, acceleration, Lz4DedupeArgs{}, Lz4SegArgs{} SQY_DIAG_NULL);
-    else if (dedupe && dedupe->seg.nseg && dedupe->chunk_key && redo && !frame_map)
-        // several wavefronts per nominated chunk (Lz4SegArgs): nseg times the grid, most of it returns at once
-        hipLaunchKernelGGL((lz4_chunks_kernel<false, false, false, true>), dim3((unsigned)(nchunks + (uint64_t)dedupe->seg.max_slots * dedupe->seg.nseg)), dim3(64), 0, stream, in, total, chunk, in_stride,
-                           scratch, stride, csize, frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of, 1u, *dedupe, dedupe->seg SQY_DIAG_NULL);
+                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, (uint32_t*)nullptr, dup_of, acceleration, Lz4DedupeArgs{} SQY_DIAG_NULL);
     else
         hipLaunchKernelGGL((lz4_chunks_kernel<false, false>), dim3((unsigned)nchunks), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of, 1u, dedupe ? *dedupe : Lz4DedupeArgs{}, Lz4SegArgs{} SQY_DIAG_NULL);
+                           frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, dup_of, 1u, dedupe ? *dedupe : Lz4DedupeArgs{} SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -5140,7 +4907,7 @@ hipError_t launch_lz4_chunks_dense(const uint8_t* in, uint64_t total, uint32_t c
     if (redo_count == 0) return hipSuccess;
     if (in_stride == 0) in_stride = chunk;
     hipLaunchKernelGGL((lz4_chunks_kernel<false, true>), dim3(redo_count), dim3(64), 0, stream, in, total, chunk, in_stride, scratch, stride, csize,
-                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr, 1u, Lz4DedupeArgs{}, Lz4SegArgs{} SQY_DIAG_NULL);
+                       frame_map, frame_bytes, (const Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, redo, (const uint32_t*)nullptr, 1u, Lz4DedupeArgs{} SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -5151,10 +4918,10 @@ hipError_t launch_lz4_linked(const uint8_t* in, const Lz4Block* blocks, const ui
     if (max_block == 0 || max_block > (4u << 20)) return hipErrorInvalidValue;
     if (acceleration > 1)
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, Lz4SpecArgs{}, Lz4SegArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, Lz4SpecArgs{} SQY_DIAG_NULL);
     else
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nframes), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, Lz4SpecArgs{}, Lz4SegArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, frame_first, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, Lz4SpecArgs{} SQY_DIAG_NULL);
     return hipGetLastError();
 }
 
@@ -5169,15 +4936,15 @@ hipError_t launch_lz4_linked_spec(const uint8_t* in, const Lz4Block* blocks, con
     // hundreds of blocks long (round 5; 50 KiB of LDS per wavefront, which a handful of runs do not mind)
     if (acceleration <= 1 && spec.mode == 2) {
         hipLaunchKernelGGL((lz4_chunks_kernel<true, true>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, spec, Lz4SegArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, spec SQY_DIAG_NULL);
         return hipGetLastError();
     }
     if (acceleration > 1)
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false, true>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, spec, Lz4SegArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, acceleration, spec SQY_DIAG_NULL);
     else
         hipLaunchKernelGGL((lz4_chunks_kernel<true, false>), dim3((unsigned)nwaves), dim3(64), 0, stream, in, (uint64_t)0, 0u, (uint64_t)0, scratch, stride, csize,
-                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, spec, Lz4SegArgs{} SQY_DIAG_NULL);
+                           (const uint64_t*)nullptr, (uint64_t)0, blocks, (const uint32_t*)nullptr, max_block, (uint32_t*)nullptr, (const uint32_t*)nullptr, 1u, spec SQY_DIAG_NULL);
     return hipGetLastError();
 }
 

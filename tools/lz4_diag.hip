@@ -27,10 +27,10 @@ int main(int argc, char** argv)
         CK(hipEventRecord(e0, 0));
         CK(hipMemset(dredo, 0, 4));
         hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, false>), dim3((unsigned)nch), dim3(64), 0, 0, din, (uint64_t)n, chunk, (uint64_t)chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
-                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, (const uint32_t*)nullptr, 1u, sqy::Lz4DedupeArgs{}, sqy::Lz4SegArgs{}, ddg);
+                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, (const uint32_t*)nullptr, 1u, sqy::Lz4DedupeArgs{}, ddg);
         uint32_t nredo = 0; CK(hipMemcpy(&nredo, dredo, 4, hipMemcpyDeviceToHost));
         if (nredo) hipLaunchKernelGGL((sqy::lz4_chunks_kernel<false, true>), dim3(nredo), dim3(64), 0, 0, din, (uint64_t)n, chunk, (uint64_t)chunk, dscr, (uint64_t)chunk, dcs, (const uint64_t*)nullptr, (uint64_t)0,
-                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, (const uint32_t*)nullptr, 1u, sqy::Lz4DedupeArgs{}, sqy::Lz4SegArgs{}, ddg);
+                           (const sqy::Lz4Block*)nullptr, (const uint32_t*)nullptr, 0u, dredo, (const uint32_t*)nullptr, 1u, sqy::Lz4DedupeArgs{}, ddg);
         CK(hipEventRecord(e1, 0));
         CK(hipDeviceSynchronize());
         float ms = 0; CK(hipEventElapsedTime(&ms, e0, e1));
