@@ -162,13 +162,14 @@ void prof_collect(std::vector<PendingEvent>& pending)
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    int ensure(size_t bytes)
+    // quiet: an OPTIONAL buffer (the caller has a path that needs none and says which) -- no message from here
+    int ensure(size_t bytes, bool quiet = false)
     {
         if (bytes <= cap) return 0;
         if (p) { hipFree(p); p = nullptr; cap = 0; }
         const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
         if (hipMalloc(&p, want) != hipSuccess) {
-            std::fprintf(stderr, "[sqeazy]\t unable to allocate %zu bytes of HBM workspace\n", want);
+            if (!quiet) std::fprintf(stderr, "[sqeazy]\t unable to allocate %zu bytes of HBM workspace\n", want);
             (void)hipGetLastError();          // (not left behind for the launch checks of a caller that carries on without this buffer)
             p = nullptr;
             return 1;
@@ -931,7 +932,17 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                     const uint64_t warmup = (uint64_t)g_opt.block_parallel_warmup.load();
                     const uint64_t list_bytes = nblocks * sizeof(uint32_t);
                     // (without room for the tables -- 32 KiB per block -- the walk, which needs none)
-                    if (!spec_off && longest >= 3 && nframes < 1024 && !ws->spec.ensure(nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t) + 3 * list_bytes)) {
+                    const bool spec_wanted = !spec_off && longest >= 3 && nframes < 1024;
+                    const bool spec_room = spec_wanted && !ws->spec.ensure(nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t) + 3 * list_bytes, true);
+                    if (spec_wanted && !spec_room) {
+                        // (round-4 advice) said once, not per call: the result is the same, the rate is not
+                        static std::atomic<bool> told{false};
+                        if (!told.exchange(true))
+                            std::fprintf(stderr, "[sqeazy]\t lz4: no HBM for the block-parallel parse's tables (%llu MiB): block-linked frames are walked by one "
+                                                 "wavefront each (same bytes, hundreds of times slower on long frames)\n",
+                                         (unsigned long long)((nblocks * sqy::kLz4SpecTableWords * sizeof(uint32_t)) >> 20));
+                    }
+                    if (spec_room) {
                         std::vector<uint32_t> wfirst(nblocks), wlast(nblocks), ok(nblocks);
                         for (uint64_t f = 0; f < nframes; ++f)
                             for (uint32_t k = plan.frame_first[f]; k < plan.frame_first[f + 1]; ++k) {
@@ -1359,8 +1370,16 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 // ONE block-linked frame (nthreads = 1 on the encoder's side): every block at once with the history as an unknown, the
                 // references resolved afterwards (sqy_kernels.hip: lz4_blocks_decode_sym_kernel).  A stream that is not a frame of
                 // full blocks, or is damaged, raises the flag: the one-wavefront walk below then decides, as in rounds 2-3.
-                if (nframes == 1 && g_opt.block_parallel.load() && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes) &&
-                    !ws->spec.ensure(((total * sizeof(uint16_t) + 255) & ~(uint64_t)255) + sqy::lz4_linked_decode_scan_scratch_bytes(hc[1]))) {
+                const bool par_wanted = nframes == 1 && g_opt.block_parallel.load() && sqy::lz4_linked_decode_parallel_possible(hc[1], total, block_bytes);
+                const bool par_room = par_wanted && !ws->spec.ensure(((total * sizeof(uint16_t) + 255) & ~(uint64_t)255) + sqy::lz4_linked_decode_scan_scratch_bytes(hc[1]), true);
+                if (par_wanted && !par_room) {
+                    // (round-4 advice) the references need 2 bytes per decoded byte; without them the walk below decodes the frame -- said once
+                    static std::atomic<bool> told{false};
+                    if (!told.exchange(true))
+                        std::fprintf(stderr, "[sqeazy]\t lz4: no HBM for the block-parallel decode's references (%llu MiB): the block-linked frame is decoded "
+                                             "by one wavefront (same bytes, hundreds of times slower)\n", (unsigned long long)((total * sizeof(uint16_t)) >> 20));
+                }
+                if (par_room) {
                     // (no room for the references: the walk needs none)
                     hipError_t le;
                     {
