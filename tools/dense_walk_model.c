@@ -17,6 +17,15 @@
 #include <stdlib.h>
 #include <string.h>
 
+#ifndef W
+#define W 64            /* positions per batch: 64 (one per lane) or 128 (two per lane, -DW=128) */
+#endif
+typedef unsigned __int128 mask_t;
+static inline int ctzm(mask_t m) { return (uint64_t)m ? __builtin_ctzll((uint64_t)m) : 64 + __builtin_ctzll((uint64_t)(m >> 64)); }
+static inline int topm(mask_t m) { return (uint64_t)(m >> 64) ? 127 - __builtin_clzll((uint64_t)(m >> 64)) : 63 - __builtin_clzll((uint64_t)m); }
+static inline int popm(mask_t m) { return __builtin_popcountll((uint64_t)m) + __builtin_popcountll((uint64_t)(m >> 64)); }
+#define ONE ((mask_t)1)
+
 typedef struct { uint32_t anchor, mstart, off, mlen; } seq_t;
 static inline uint64_t rd64(const uint8_t* p) { uint64_t v; memcpy(&v, p, 8); return v; }
 static inline uint32_t rd32(const uint8_t* p) { uint32_t v; memcpy(&v, p, 4); return v; }
@@ -96,7 +105,7 @@ static int step_scalar(st_t* s, int first_of_chunk)
     return 1;
 }
 
-typedef struct { int nseq, cur, keep; int fq[16]; uint32_t inf[16]; } walk_t;
+typedef struct { int nseq, cur, keep; int fq[W / 4]; uint32_t inf[W / 4]; } walk_t;
 /* verdict word of lane `lane` against candidate position cand: forward bytes (0..16) | equal bytes in front (0..4) << 5 | literal limit << 8 | offset << 16 */
 static uint32_t verdict(const uint8_t* src, uint32_t pos, uint32_t cand)
 {
@@ -127,44 +136,44 @@ int main(int argc, char** argv)
         step_scalar(s, 1);
         while (!s->done) {
             const uint32_t P = s->P;
-            if (!(P >= 4 && P + 112 <= matchlimit)) { g_scalar_steps++; step_scalar(s, 0); continue; }
+            if (!(P >= 4 && P + W + 48 <= matchlimit)) { g_scalar_steps++; step_scalar(s, 0); continue; }
             /* ---- the vector part: every lane judges its own table candidate ---- */
             if (s->put2) { s->table[h5(src + P - 2)] = P - 2; s->put2 = 0; }
-            uint32_t h[64], infoT[64]; uint64_t M = 0, D = 0;
-            uint64_t mates[64];
-            for (int l = 0; l < 64; ++l) {
+            uint32_t h[W], infoT[W]; mask_t M = 0, D = 0;
+            mask_t mates[W];
+            for (int l = 0; l < W; ++l) {
                 h[l] = h5(src + P + l);
                 mates[l] = 0;
-                for (int k = 0; k < l; ++k) if (h[k] == h[l]) mates[l] |= 1ull << k;
-                if (mates[l]) D |= 1ull << l;
+                for (int k = 0; k < l; ++k) if (h[k] == h[l]) mates[l] |= ONE << k;
+                if (mates[l]) D |= ONE << l;
                 uint32_t old = s->table[h[l]];
                 int near = (P + l - old) <= 65535 && rd32(src + old) == rd32(src + P + l);
                 infoT[l] = verdict(src, P + l, old);
-                if (near && (infoT[l] & 31) >= 4) M |= 1ull << l;
+                if (near && (infoT[l] & 31) >= 4) M |= ONE << l;
             }
-            { uint64_t todo = D; while (todo) { int c = __builtin_ctzll(todo); uint64_t g = 0; for (int k = 0; k < 64; ++k) if (h[k] == h[c]) g |= 1ull << k; todo &= ~g; g_groups++; }
-              g_duplanes += __builtin_popcountll(D); }
+            { mask_t todo = D; while (todo) { int c = ctzm(todo); mask_t g = 0; for (int k = 0; k < W; ++k) if (h[k] == h[c]) g |= ONE << k; todo &= ~g; g_groups++; }
+              g_duplanes += popm(D); }
             /* ---- (1) the walk of round 4 ---- */
             walk_t w1; memset(&w1, 0, sizeof w1); w1.keep = 1;
             {
-                uint64_t evm = M | D; int cur = 0, nseq = 0; uint64_t inside = 0;   /* inside: lanes strictly inside recorded matches, minus ip-2 */
+                mask_t evm = M | D; int cur = 0, nseq = 0; mask_t inside = 0;   /* inside: lanes strictly inside recorded matches, minus ip-2 */
                 for (;;) {
-                    if (cur >= 64 || nseq >= 16) break;
-                    uint64_t ev = evm >> cur; if (!ev) break;
-                    int fq = cur + __builtin_ctzll(ev);
-                    uint32_t inf = infoT[fq]; int is_hit = (M >> fq) & 1;
-                    if ((D >> fq) & 1) {
+                    if (cur >= W || nseq >= W / 4) break;
+                    mask_t ev = evm >> cur; if (!ev) break;
+                    int fq = cur + ctzm(ev);
+                    uint32_t inf = infoT[fq]; int is_hit = (int)((M >> fq) & 1);
+                    if ((int)((D >> fq) & 1)) {
                         g_dupsteps++;
-                        uint64_t m = mates[fq] & ~inside;
-                        if (m) { int qm = 63 - __builtin_clzll(m); inf = verdict(src, P + fq, P + qm); is_hit = (inf & 31) >= 4; g_dup_mate++;
-                                 { int rank = __builtin_popcountll(mates[fq] >> qm); g_rank[rank < 6 ? rank : 6]++; }
+                        mask_t m = mates[fq] & ~inside;
+                        if (m) { int qm = topm(m); inf = verdict(src, P + fq, P + qm); is_hit = (inf & 31) >= 4; g_dup_mate++;
+                                 { int rank = popm(mates[fq] >> qm); g_rank[rank < 6 ? rank : 6]++; }
                                  /* the kernel's P + qm < 16 rule is part of verdict() (cand < 16) */ }
-                        if (!is_hit) { evm &= ~(1ull << fq); continue; }
+                        if (!is_hit) { evm &= ~(ONE << fq); continue; }
                     } else g_plain++;
                     if ((uint32_t)(fq - cur) >= ((inf >> 8) & 15)) { w1.keep = 0; break; }
                     w1.fq[nseq] = fq; w1.inf[nseq] = inf; nseq++;
                     int e = fq + (inf & 31);
-                    for (int c = fq + 1; c < e && c < 64; ++c) if (c != e - 2) inside |= 1ull << c;
+                    for (int c = fq + 1; c < e && c < W; ++c) if (c != e - 2) inside |= ONE << c;
                     cur = e;
                 }
                 w1.nseq = nseq; w1.cur = cur;
@@ -174,34 +183,34 @@ int main(int argc, char** argv)
                candidate (the verdict against pos-2 comes out of the lane's own bytes); if the bucket's FIRST lane is i-3 or later and i-2 is
                no mate, no mate has entered the table: the table entry is the candidate.  Else: history decides. ---- */
             {
-                uint64_t evm = M | D; int cur = 0, nseq = 0; uint64_t inside = 0;
+                mask_t evm = M | D; int cur = 0, nseq = 0; mask_t inside = 0;
                 for (;;) {
-                    if (cur >= 64 || nseq >= 16) break;
-                    uint64_t ev = evm >> cur; if (!ev) break;
-                    int fq = cur + __builtin_ctzll(ev);
-                    uint32_t inf = infoT[fq]; int is_hit = (M >> fq) & 1;
-                    if ((D >> fq) & 1) {
+                    if (cur >= W || nseq >= W / 4) break;
+                    mask_t ev = evm >> cur; if (!ev) break;
+                    int fq = cur + ctzm(ev);
+                    uint32_t inf = infoT[fq]; int is_hit = (int)((M >> fq) & 1);
+                    if ((int)((D >> fq) & 1)) {
                         g_x_dup++;
-                        int first = __builtin_ctzll(mates[fq]);
+                        int first = ctzm(mates[fq]);
                         if (fq == cur && cur >= 2) {
-                            if ((mates[fq] >> (cur - 2)) & 1) g_x_self2++;
+                            if ((int)((mates[fq] >> (cur - 2)) & 1)) g_x_self2++;
                             else if (first >= cur - 3) g_x_table++;
                             else g_x_slow++;
                         } else if (fq == cur) g_x_slow++;      /* cur < 2: cannot happen for a dup lane but for lane 1 */
                         else {
                             /* event behind the cursor (literals in between): nearest mate at or behind the cursor? */
-                            int m1 = 63 - __builtin_clzll(mates[fq]);
+                            int m1 = topm(mates[fq]);
                             if (m1 >= cur) { if (m1 == fq - 1) g_x_lit_self1++; else if (m1 == fq - 2) g_x_lit_self2++; else g_x_lit_other++; }
                             else g_x_lit_front++;
                         }
-                        uint64_t m = mates[fq] & ~inside;
-                        if (m) { int qm = 63 - __builtin_clzll(m); inf = verdict(src, P + fq, P + qm); is_hit = (inf & 31) >= 4; }
-                        if (!is_hit) { evm &= ~(1ull << fq); continue; }
+                        mask_t m = mates[fq] & ~inside;
+                        if (m) { int qm = topm(m); inf = verdict(src, P + fq, P + qm); is_hit = (inf & 31) >= 4; }
+                        if (!is_hit) { evm &= ~(ONE << fq); continue; }
                     }
                     if ((uint32_t)(fq - cur) >= ((inf >> 8) & 15)) break;
                     nseq++;
                     int e = fq + (inf & 31);
-                    for (int c = fq + 1; c < e && c < 64; ++c) if (c != e - 2) inside |= 1ull << c;
+                    for (int c = fq + 1; c < e && c < W; ++c) if (c != e - 2) inside |= ONE << c;
                     cur = e;
                 }
             }
@@ -210,20 +219,20 @@ int main(int argc, char** argv)
             {
                 /* status per cursor lane i: 0 = a sequence (fq, inf, E), 1 = no event lane left (batch over), 2 = literal limit (batch ends, leave the
                    dense batches), 3 = SLOW (depends on lanes more than 3 in front of the cursor) */
-                int st[64], Efq[64], Enext[64]; uint32_t Einf[64];
-                for (int i = 0; i < 64; ++i) {
-                    uint64_t evm = M | D; int e_from = i; st[i] = 1; Efq[i] = 0; Einf[i] = 0; Enext[i] = 64;
+                int st[W], Efq[W], Enext[W]; uint32_t Einf[W];
+                for (int i = 0; i < W; ++i) {
+                    mask_t evm = M | D; int e_from = i; st[i] = 1; Efq[i] = 0; Einf[i] = 0; Enext[i] = W;
                     for (int tries = 0; ; ++tries) {
-                        uint64_t ev = e_from < 64 ? evm >> e_from : 0; if (!ev) { st[i] = 1; break; }
-                        int e = e_from + __builtin_ctzll(ev);
-                        uint32_t inf = infoT[e]; int is_hit = (M >> e) & 1;
-                        if ((D >> e) & 1) {
+                        mask_t ev = e_from < W ? evm >> e_from : 0; if (!ev) { st[i] = 1; break; }
+                        int e = e_from + ctzm(ev);
+                        uint32_t inf = infoT[e]; int is_hit = (int)((M >> e) & 1);
+                        if ((int)((D >> e) & 1)) {
                             /* nearest mates first: a mate at or behind the cursor has entered the table; i-2 has (ip-2); i-1, i-3 have not (inside the
                                match that ended at i: it is at least 4 long); anything further in front of the cursor: history decides -> SLOW.
                                The batch's first cursor (i == 0) has no lanes in front of it. */
-                            uint64_t m = mates[e]; int cand = -1, slow = 0;
+                            mask_t m = mates[e]; int cand = -1, slow = 0;
                             while (m) {
-                                int q = 63 - __builtin_clzll(m); m &= ~(1ull << q);
+                                int q = topm(m); m &= ~(ONE << q);
                                 if (q >= i || q == i - 2) { cand = q; break; }
                                 if (q == i - 1 || q == i - 3) continue;
                                 slow = 1; break;
@@ -238,9 +247,9 @@ int main(int argc, char** argv)
                     }
                 }
                 /* the chain */
-                int cur = 0, nseq = 0; uint64_t inside = 0, evm = M | D;
+                int cur = 0, nseq = 0; mask_t inside = 0, evm = M | D;
                 for (;;) {
-                    if (cur >= 64 || nseq >= 16) break;
+                    if (cur >= W || nseq >= W / 4) break;
                     int status = st[cur];
                     if (status == 1) break;
                     if (status == 2) { w2.keep = 0; break; }
@@ -250,17 +259,17 @@ int main(int argc, char** argv)
                         /* SLOW: this one sequence by the step of (1) (needs `inside`, kept up to date below) */
                         g_slow++;
                         int found = 0; fq = 0; inf = 0;
-                        uint64_t evs = evm;
+                        mask_t evs = evm;
                         for (;;) {
-                            uint64_t ev = evs >> cur; if (!ev) break;
-                            int e = cur + __builtin_ctzll(ev);
-                            uint32_t x = infoT[e]; int is_hit = (M >> e) & 1;
-                            if ((D >> e) & 1) { uint64_t m = mates[e] & ~inside;
-                                                if (m) { int qm = 63 - __builtin_clzll(m); x = verdict(src, P + e, P + qm); is_hit = (x & 31) >= 4;
-                                                         int rank = __builtin_popcountll(mates[e] >> qm); g_case[rank < 6 ? rank : 6]++; }
+                            mask_t ev = evs >> cur; if (!ev) break;
+                            int e = cur + ctzm(ev);
+                            uint32_t x = infoT[e]; int is_hit = (int)((M >> e) & 1);
+                            if ((int)((int)((D >> e) & 1))) { mask_t m = mates[e] & ~inside;
+                                                if (m) { int qm = topm(m); x = verdict(src, P + e, P + qm); is_hit = (x & 31) >= 4;
+                                                         int rank = popm(mates[e] >> qm); g_case[rank < 6 ? rank : 6]++; }
                                                 else g_case[0]++; }
                             else g_case[7]++;
-                            if (!is_hit) { evs &= ~(1ull << e); continue; }
+                            if (!is_hit) { evs &= ~(ONE << e); continue; }
                             fq = e; inf = x; found = 1; break;
                         }
                         if (!found) break;
@@ -268,7 +277,7 @@ int main(int argc, char** argv)
                     }
                     w2.fq[nseq] = fq; w2.inf[nseq] = inf; nseq++;
                     int e = fq + (inf & 31);
-                    for (int c = fq + 1; c < e && c < 64; ++c) if (c != e - 2) inside |= 1ull << c;
+                    for (int c = fq + 1; c < e && c < W; ++c) if (c != e - 2) inside |= ONE << c;
                     cur = e;
                 }
                 w2.nseq = nseq; w2.cur = cur;
@@ -281,16 +290,16 @@ int main(int argc, char** argv)
             if (w1.nseq == 0) { g_scalar_steps++; step_scalar(s, 0); continue; }
             g_seqs += w1.nseq;
             /* the sequences, the table, the cursor */
-            uint64_t inside = 0; int anc = 0;
+            mask_t inside = 0; int anc = 0;
             for (int k = 0; k < w1.nseq; ++k) {
                 int fq = w1.fq[k]; uint32_t inf = w1.inf[k]; int d = inf & 31, bk = (inf >> 5) & 7, lit0 = fq - anc;
                 int back = bk < lit0 ? bk : lit0;
                 s->out[s->ns].anchor = P + anc; s->out[s->ns].mstart = P + fq - back; s->out[s->ns].off = inf >> 16; s->out[s->ns].mlen = d + back; s->ns++;
                 int e = fq + d;
-                for (int c = fq + 1; c < e && c < 64; ++c) if (c != e - 2) inside |= 1ull << c;
+                for (int c = fq + 1; c < e && c < W; ++c) if (c != e - 2) inside |= ONE << c;
                 anc = e;
             }
-            for (int l = 0; l < 64 && l < w1.cur; ++l) if (!((inside >> l) & 1)) { uint32_t pos = P + l; if (s->table[h[l]] < pos) s->table[h[l]] = pos; }
+            for (int l = 0; l < W && l < w1.cur; ++l) if (!(int)((inside >> l) & 1)) { uint32_t pos = P + l; if (s->table[h[l]] < pos) s->table[h[l]] = pos; }
             s->P = P + w1.cur; s->put2 = 1;
             if (!w1.keep) { g_end_lit++; g_scalar_steps++; step_scalar(s, 0); }
         }
