@@ -13,7 +13,10 @@ rng = np.random.default_rng(seed)
 PIPES16 = ["bitswap1->lz4", "lz4", "diff3x3x1->bitswap1->lz4", "diff3x3x1->lz4", "frame_shuffle->lz4", "raster_reorder->lz4",
            "quantiser->bitswap1->lz4", "quantiser->lz4", "zcurve_reorder->lz4", "bitshuffle->lz4", "tile_shuffle(tile_size=4)->lz4",
            "lz4(blocksize_kb=64)", "bitswap1->lz4(blocksize_kb=64,framestep_kb=256)", "bitswap1->lz4(n_chunks_of_input=3)",
-           "diff3x3x1->bitshuffle->lz4", "pass_through->bitswap1->lz4", "bitswap1"]
+           "diff3x3x1->bitshuffle->lz4", "pass_through->bitswap1->lz4", "bitswap1",
+           # round 5: the reorder / shuffle stages behind the sink (tail filters on char)
+           "quantiser->raster_reorder->lz4", "quantiser->zcurve_reorder(tile_size=4)->bitswap1->lz4", "quantiser->tile_shuffle(tile_size=8)->lz4",
+           "quantiser->frame_shuffle->lz4", "quantiser->diff3x3x1->lz4"]
 PIPES8 = ["bitswap1->lz4", "lz4", "frame_shuffle->lz4", "raster_reorder->lz4", "zcurve_reorder->lz4", "bitshuffle->lz4",
           "lz4(blocksize_kb=64)", "diff3x3x1->lz4"]
 
