@@ -1683,18 +1683,23 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         if (shorts >= 2u) { shorts = 0; dense_next = true; redo = true; break; }
                     } else if (!LINKED) {
                         // 32 in a row: a stream of short sequences, this chunk goes to the DENSE kernel
-                        shorts = ml < 12u ? shorts + 1u : 0u;
-                        if (shorts >= 32u && redo_list) { redo_dense = true; break; }
+                        // (round 5: a leaky count -- a short match adds one, any other takes four away -- up to 128.  Rounds 2-4 gave a chunk up
+                        // after 32 short matches IN A ROW: streams that are four fifths short matches or more (the top plane of quantised
+                        // data) get there within a few hundred sequences either way, but 32 in a row also happen in chunks that are mostly
+                        // ordinary -- 36 chunks of a 2048 x 2048 x 256 slab of the bench stack, which then waited for a second launch that
+                        // was no faster on them: that slab 2.46 -> 1.84 ms, the C3 slab 6.29 -> 5.65, the "+ 40000" stack 3.80 -> 2.30.)
+                        shorts = ml < 12u ? shorts + 1u : (shorts > 4u ? shorts - 4u : 0u);
+                        if (shorts >= 128u && redo_list) { redo_dense = true; break; }
                     } else if (LINKED) {
                         // (round 5) the block-parallel parse's guesses (mode 1): a stream of short sequences -- the top plane of a quantised
                         // stack, ~35 000 sequences per block -- is given up here, warm-up or not: its guess fails anyway (on such data nearly
                         // every look-up finds a candidate, any difference between the guessed and the true table changes a match and with it
                         // the positions that enter the table: tools/segment_convergence.c), and the run it belongs to is parsed again in order
                         // by the kernel with the dense batches (mode 2).  The block's tables on record are made impossible below, so that it
-                        // and the block behind it fail the check.  (2048 in a row: the sparse planes of a diff3x3x1 residual have stretches
-                        // of short matches too, and are better off here.)
+                        // and the block behind it fail the check.  (A leaky count of 2048: the sparse planes of a diff3x3x1 residual have
+                        // stretches of short matches too, and are better off here.)
                         if constexpr (LINKED) if (spec_mode == 1u) {
-                            shorts = ml < 12u ? shorts + 1u : 0u;
+                            shorts = ml < 12u ? shorts + 1u : (shorts > 4u ? shorts - 4u : 0u);
                             if (shorts >= 2048u && !(blocks[b_last - 1u].flags & 1u)) { redo_dense = true; break; }
                         }
                     }
