@@ -453,7 +453,10 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     uint64_t* lz4_holes = nullptr;               // frames in place: which 1 KiB pieces of the plane stream the transpose left unwritten (all zero)
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
+    size_t skip_stage = ~(size_t)0;             // a stage that the stage in front of it has already done (quantiser + bitswap1 in one pass)
     for (size_t si = 0; si < pipe.stages.size(); ++si) {
+        if (si == skip_stage) continue;
+
         Stage& st = pipe.stages[si];
         switch (st.kind) {
             case StageKind::bitswap1: {
@@ -782,7 +785,14 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 SQY_HIP(hipMemcpyAsync(d_lut, lut_encode.data(), 65536, hipMemcpyHostToDevice, stream));
                 uint8_t* out = next_buf(cur_len);
                 if (!out) return 1;
-                {
+                // (round 5) bitswap1 right behind the sink: look-up and 8-bit bit-plane transpose in one pass, the stage behind is done too
+                const bool fuse_bitswap = si + 1 < pipe.stages.size() && pipe.stages[si + 1].kind == StageKind::bitswap1 &&
+                                          (reinterpret_cast<uintptr_t>(cur) & 15) == 0;
+                if (fuse_bitswap) {
+                    ProfScope ps("quantiser_bitswap1_u8", stream, pend);
+                    SQY_HIP(sqy::launch_quantiser_apply_bitswap1_u8(reinterpret_cast<const uint16_t*>(cur), out, cur_len, d_lut, stream));
+                    skip_stage = si + 1;
+                } else {
                     ProfScope ps("quantiser_apply", stream, pend);
                     SQY_HIP(sqy::launch_quantiser_apply_u16(reinterpret_cast<const uint16_t*>(cur), out, cur_len, d_lut, stream));
                 }

@@ -146,6 +146,9 @@ hipError_t launch_lz4_frame_gather(const uint8_t* in, uint64_t total, uint32_t c
 // quantiser: 65536-bin histogram of u16 voxels (histo is zeroed by the launcher), and out[i] = lut[in[i]]
 hipError_t launch_histogram_u16(const uint16_t* in, uint64_t len, uint32_t* histo, hipStream_t stream);
 hipError_t launch_quantiser_apply_u16(const uint16_t* in, uint8_t* out, uint64_t len, const uint8_t* lut, hipStream_t stream);
+// .. with the 8-bit bit-plane transpose of the sink's bytes in the same pass (quantiser->bitswap1; `in` 16-byte aligned): out = the 8
+// plane segments of len / 8 bytes, MSB plane first, + the len % 8 tail
+hipError_t launch_quantiser_apply_bitswap1_u8(const uint16_t* in, uint8_t* out, uint64_t len, const uint8_t* lut, hipStream_t stream);
 
 // raster_reorder (encoders/raster_reorder_utils.hpp): tiles of tile_size^3 (remainder tiles at the high ends) appended in
 // (z,y,x) tile order, row-major inside; decode = the inverse permutation

@@ -2486,6 +2486,53 @@ void quantiser_apply_u16_kernel(const uint16_t* __restrict__ in, uint8_t* __rest
     }
 }
 
+// (round 5) quantiser with an 8-bit bitswap1 right behind it (quantiser->bitswap1->..: the BASELINE pipeline): the look-up and the
+// bit-plane transpose of the sink's bytes in one pass -- out is the 8 plane segments of seg = len / 8 bytes, MSB plane first, byte w of
+// plane b holds voxels 8w .. 8w+7 with voxel 8w + j at bit 7 - j (bitswap_scheme_impl.hpp:97-145 on `char`), the len % 8 tail bytes
+// copied behind them.  One thread per 8 voxels: 16 bytes in, one byte into each plane (coalesced across the threads); the pass that
+// wrote the sink's bytes and the pass that read them again (1 + 1 bytes per voxel of HBM traffic) are gone.
+__global__ __launch_bounds__(256)
+void quantiser_apply_bitswap1_u8_kernel(const uint16_t* __restrict__ in, uint8_t* __restrict__ out, uint64_t len,
+                                        const uint8_t* __restrict__ lut /* 65536 */)
+{
+    extern __shared__ uint8_t slut[];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 65536 / 16; i += 256)
+        reinterpret_cast<uint4*>(slut)[i] = reinterpret_cast<const uint4*>(lut)[i];
+    __syncthreads();
+    const uint64_t seg = len / 8;
+    const uint4* src = reinterpret_cast<const uint4*>(in);
+    const uint64_t step = (uint64_t)gridDim.x * 256;
+    for (uint64_t v0 = (uint64_t)blockIdx.x * 256 + tid; v0 < seg; v0 += 4 * step) {           // four loads in flight per thread
+        uint4 xs[4];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) if (v0 + j * step < seg) xs[j] = src[v0 + j * step];
+#pragma unroll
+        for (uint32_t j = 0; j < 4; ++j) {
+            const uint64_t w = v0 + j * step;
+            if (w >= seg) continue;
+            const uint4 x = xs[j];
+            // byte j of t = the quantised voxel 8w + j
+            uint64_t t = (uint64_t)slut[x.x & 0xffffu] | ((uint64_t)slut[x.x >> 16] << 8) | ((uint64_t)slut[x.y & 0xffffu] << 16) |
+                         ((uint64_t)slut[x.y >> 16] << 24) | ((uint64_t)slut[x.z & 0xffffu] << 32) | ((uint64_t)slut[x.z >> 16] << 40) |
+                         ((uint64_t)slut[x.w & 0xffffu] << 48) | ((uint64_t)slut[x.w >> 16] << 56);
+            // 8x8 bit transpose (bitswap1_u8_generic): afterwards byte b of t holds bit b of every voxel, voxel j at bit j
+            uint64_t y;
+            y = (t ^ (t >> 7)) & 0x00AA00AA00AA00AAull; t = t ^ y ^ (y << 7);
+            y = (t ^ (t >> 14)) & 0x0000CCCC0000CCCCull; t = t ^ y ^ (y << 14);
+            y = (t ^ (t >> 28)) & 0x00000000F0F0F0F0ull; t = t ^ y ^ (y << 28);
+#pragma unroll
+            for (int b = 0; b < 8; ++b) {
+                const uint32_t byte = (uint32_t)(t >> (8 * b)) & 0xffu;
+                out[(uint64_t)(7 - b) * seg + w] = (uint8_t)(__brev(byte) >> 24);
+            }
+        }
+    }
+    if (blockIdx.x == 0) {
+        for (uint64_t i = seg * 8 + tid; i < len; i += 256) out[i] = slut[in[i]];
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // frame_shuffle (encoders/frame_shuffle_utils.hpp:91-172).
 // metric[z] = (float sum of frame z accumulated SEQUENTIALLY in binary32) / (Y*X): the additions round once
@@ -4808,6 +4855,18 @@ uint64_t lz4_dedupe_work_bytes(uint64_t nchunks)
     uint64_t tab = 64;
     while (tab < 2 * nchunks) tab <<= 1;
     return nchunks * 8 + tab * 8 + tab * 4 + 64;
+}
+
+hipError_t launch_quantiser_apply_bitswap1_u8(const uint16_t* in, uint8_t* out, uint64_t len, const uint8_t* lut, hipStream_t stream)
+{
+    if (len == 0) return hipSuccess;
+    if (reinterpret_cast<uintptr_t>(in) & 15) return hipErrorInvalidValue;
+    uint64_t blocks = (len / 8 + 256 * 16 - 1) / (256 * 16);
+    const uint64_t cap = (uint64_t)num_cus() * 2;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    hipLaunchKernelGGL(quantiser_apply_bitswap1_u8_kernel, dim3((unsigned)blocks), dim3(256), 65536, stream, in, out, len, lut);
+    return hipGetLastError();
 }
 
 hipError_t launch_bitswap1_u8(const uint8_t* in, uint8_t* out, uint64_t len, hipStream_t stream)
