@@ -3084,6 +3084,37 @@ __global__ void lz4_frame_probe_kernel(const uint8_t* __restrict__ in, uint64_t 
     *hint = multi;
 }
 
+// a window that holds the magic's first two bytes somewhere: the sixteen start positions one by one (a call: it is rare)
+__device__ __noinline__ void frame_cand_record(uint64_t n, FrameSlot* __restrict__ table, uint32_t mask, FrameCand* __restrict__ list, uint32_t cap,
+                                               uint32_t* __restrict__ ncand, uint64_t base, uint32_t w0, uint32_t w1, uint32_t w2, uint32_t w3,
+                                               uint32_t w4, uint32_t w5, uint32_t w6, uint32_t w7, uint32_t w8, uint32_t kmax)
+{
+    const uint32_t w[9] = {w0, w1, w2, w3, w4, w5, w6, w7, w8};
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        if ((uint32_t)k >= kmax) continue;                             // (only the window in front of the first aligned vector stops early)
+        // little-endian window of 12 bytes starting at base + k: dwords d0 (bytes 0..3), d1 (4..7), d2 (8..11)
+        const int i = 1 + (k >> 2), sh = k & 3;
+        const uint32_t d0 = __builtin_amdgcn_alignbyte(w[i + 1], w[i], sh);
+        if (d0 != 0x184D2204u) continue;
+        const uint32_t d1 = __builtin_amdgcn_alignbyte(w[i + 2], w[i + 1], sh);
+        const uint32_t d2 = __builtin_amdgcn_alignbyte(w[i + 3], w[i + 2], sh);
+        const uint32_t flg = d1 & 0xffu;
+        const uint64_t pos = base + (uint64_t)k;
+        if ((flg >> 6) != 1 || (flg & 0x0D) || pos + 11 > n) continue;
+        const uint32_t pz = __builtin_amdgcn_alignbyte(w[i], w[i - 1], sh);       // the four bytes in front
+        const uint32_t idx = atomicAdd(ncand, 1u);
+        if (idx >= cap) continue;                                        // the rank kernel sees ncand > cap and gives up
+        FrameCand c;
+        c.pos = pos; c.field = (d1 >> 24) | (d2 << 8); c.flags = ((pos >= 4 && pz == 0u) ? 1u : 0u) | (flg << 8);
+        list[idx] = c;
+        uint32_t s_ = cand_slot(pos, mask);
+        for (uint32_t probe = 0; probe <= mask; ++probe, s_ = (s_ + 1) & mask) {
+            if (atomicCAS(&table[s_].key, 0ull, (unsigned long long)(pos + 1)) == 0ull) { table[s_].idx = idx; break; }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256)
 void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, FrameSlot* __restrict__ table, uint32_t mask,
                                  FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand, const uint32_t* __restrict__ hint)
@@ -3106,40 +3137,23 @@ void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, Fra
             pair |= ((x - 0x01010101u) & ~x) & ((y - 0x01010101u) & ~y);
         }
         if (!(pair & 0x80808080u)) return;
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            if ((uint32_t)k >= kmax) break;                                // (only the window in front of the first aligned vector stops early)
-            // little-endian window of 12 bytes starting at base + k: dwords d0 (bytes 0..3), d1 (4..7), d2 (8..11)
-            const int i = 1 + (k >> 2), sh = 8 * (k & 3);
-            const uint32_t d0 = sh ? (w[i] >> sh) | (w[i + 1] << (32 - sh)) : w[i];
-            if (d0 != 0x184D2204u) continue;
-            const uint32_t d1 = sh ? (w[i + 1] >> sh) | (w[i + 2] << (32 - sh)) : w[i + 1];
-            const uint32_t d2 = sh ? (w[i + 2] >> sh) | (w[i + 3] << (32 - sh)) : w[i + 2];
-            const uint32_t flg = d1 & 0xffu;
-            const uint64_t pos = base + (uint64_t)k;
-            if ((flg >> 6) != 1 || (flg & 0x0D) || pos + 11 > n) continue;
-            const uint32_t pz = sh ? (w[i - 1] >> sh) | (w[i] << (32 - sh)) : w[i - 1];   // the four bytes in front
-            const uint32_t idx = atomicAdd(ncand, 1u);
-            if (idx >= cap) continue;                                    // the rank kernel sees ncand > cap and gives up
-            FrameCand c;
-            c.pos = pos; c.field = (d1 >> 24) | (d2 << 8); c.flags = ((pos >= 4 && pz == 0u) ? 1u : 0u) | (flg << 8);
-            list[idx] = c;
-            uint32_t s_ = cand_slot(pos, mask);
-            for (uint32_t probe = 0; probe <= mask; ++probe, s_ = (s_ + 1) & mask) {
-                if (atomicCAS(&table[s_].key, 0ull, (unsigned long long)(pos + 1)) == 0ull) { table[s_].idx = idx; break; }
-            }
-        }
+        // (rare, and out of line: unrolled in place, once for each of a step's windows, the sixteen compares cost the kernel 145 registers)
+        frame_cand_record(n, table, mask, list, cap, ncand, base, w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7], w[8], kmax);
     };
-    // Round 4: every lane loads ONE aligned 16-byte vector per window; the 12 bytes behind it are the first dwords of the next lane's
-    // vector and the 4 bytes in front of it the last dword of the lane before (ds_bpermute, no memory) -- only a wave's first and last
-    // lane fetch those themselves.  (Before: 36 bytes loaded per 16 inspected, at the payload's arbitrary alignment: 2.6 TB/s.)
+    // Round 4: aligned 16-byte vectors; what a window needs from outside its vector comes out of registers, not memory.  Round 5: a
+    // wavefront takes 4 KiB, every lane the 64 bytes [64 * lane, 64 * lane + 64) of it as four vectors (the access pattern of
+    // frame_block_sums_kernel, which reads at 5.6 TB/s where the grid-stride loop of single vectors stayed at 3): three of a lane's four
+    // windows find their neighbours in the lane's own registers, the first takes one dword from the lane before and the last three from
+    // the lane behind (ds_bpermute), a wave's first and last lane fetch those themselves -- with the wave's own loads, all in flight at once.
     // Start positions [0, A) in front of the first aligned vector and the ragged end go through the byte-wise window.
     const uint64_t A = (16u - (reinterpret_cast<uintptr_t>(in) & 15u)) & 15u;
     const uint64_t nal = n > A + 32 ? (n - A - 16) / 16 : 0;            // aligned vectors whose window [base - 4, base + 28) lies inside the stream (base >= 4 checked below)
     auto slow_window = [&](uint64_t base, uint32_t kmax) {
         uint32_t w[9];
+#pragma unroll
         for (int i = 0; i < 9; ++i) {
             uint32_t v = 0;
+#pragma unroll
             for (int k = 0; k < 4; ++k) {
                 const int64_t p = (int64_t)base - 4 + 4 * i + k;
                 const uint32_t byte = (p >= 0 && (uint64_t)p < n) ? in[p] : 0xFFu;
@@ -3150,43 +3164,64 @@ void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, Fra
         inspect(base, w, kmax);
     };
     const uint32_t lane = threadIdx.x & 63u;
-    for (uint64_t t0 = (uint64_t)blockIdx.x * 256 + threadIdx.x; t0 - lane < nal; t0 += 4 * stride) {      // (whole waves stay together: bpermute)
-        uint4 a[4];
-        uint32_t nx[4][3], pv[4];
-        bool on[4];
+    const uint64_t gthread = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    {
+        // a wavefront's pieces: 256 vectors in a row each, the grid's wavefronts take them in turn, the NEXT piece's loads are in flight
+        // while this one is looked at (a wavefront that loads 64 bytes per lane once and then computes keeps the memory system busy for
+        // half its life: 3 TB/s; what bounds a read-only scan is the bytes in flight)
+        // (every load unconditional, at a clamped address: a load under a condition with a default value behind it makes the compiler
+        // wait for it on the spot)
+        struct Piece { uint4 a[4]; uint4 edge; };
+        const uint64_t npieces = (nal + 255) / 256, nwaves = (uint64_t)gridDim.x * 4;
+        const uint4* __restrict__ vec = reinterpret_cast<const uint4*>(in + A);
+        auto issue = [&](uint64_t pc, Piece& q) {
+            const uint64_t t0 = pc * 256 + (uint64_t)lane * 4;           // this lane's first vector
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t t = t0 + (uint64_t)u * stride;
-            on[u] = t < nal;
-            a[u] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, 0xffffffffu);
-            if (t <= nal) a[u] = *reinterpret_cast<const uint4*>(in + A + t * 16);      // (vector nal exists too: its first dwords are the lane before's tail)
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint64_t t = t0 + (uint64_t)u * stride;
-            const uint64_t base = A + t * 16;
+            for (int j = 0; j < 4; ++j) q.a[j] = vec[t0 + j < nal ? t0 + j : nal];       // (vector nal exists too: its first dwords are the tail of the window before)
+            // the vector behind the wave's last (lane 63) and the one in front of its first (lane 0: its last dword)
+            const uint64_t te = lane == 63u ? (t0 + 4 < nal ? t0 + 4 : nal) : (t0 ? t0 - 1 : 0);
+            if (lane == 63u || lane == 0u) q.edge = vec[te];
+        };
+        auto look = [&](uint64_t pc, const Piece& q) {
+            const uint64_t t0 = pc * 256 + (uint64_t)lane * 4;
             const int up = (int)(((lane + 1u) & 63u) * 4u), dn = (int)(((lane + 63u) & 63u) * 4u);
-            nx[u][0] = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)a[u].x);
-            nx[u][1] = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)a[u].y);
-            nx[u][2] = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)a[u].z);
-            pv[u] = (uint32_t)__builtin_amdgcn_ds_bpermute(dn, (int)a[u].w);
-            if (on[u] && lane == 63u) {                                   // the wave's last vector: what follows it belongs to another wave
-                nx[u][0] = ld_u32(in + base + 16); nx[u][1] = ld_u32(in + base + 20); nx[u][2] = ld_u32(in + base + 24);
-            }
-            if (on[u] && lane == 0u) pv[u] = base >= 4 ? ld_u32(in + base - 4) : 0xffffffffu;
-        }
+            uint32_t nx0 = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)q.a[0].x);
+            uint32_t nx1 = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)q.a[0].y);
+            uint32_t nx2 = (uint32_t)__builtin_amdgcn_ds_bpermute(up, (int)q.a[0].z);
+            uint32_t pv = (uint32_t)__builtin_amdgcn_ds_bpermute(dn, (int)q.a[3].w);
+            if (lane == 63u) { nx0 = q.edge.x; nx1 = q.edge.y; nx2 = q.edge.z; }
+            if (lane == 0u) pv = t0 ? q.edge.w : (A >= 4 ? ld_u32(in + A - 4) : 0xffffffffu);   // (A < 4: the window goes the byte-wise way below)
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!on[u]) continue;
-            const uint64_t base = A + (t0 + (uint64_t)u * stride) * 16;
-            if (base < 4) { slow_window(base, 16u); continue; }           // (a payload that starts within 4 bytes of an aligned address)
-            const uint32_t w[9] = {pv[u], a[u].x, a[u].y, a[u].z, a[u].w, nx[u][0], nx[u][1], nx[u][2], 0u};
-            inspect(base, w, 16u);
+            for (int j = 0; j < 4; ++j) {
+                if (t0 + j >= nal) continue;
+                const uint64_t base = A + (t0 + j) * 16;
+                if (base < 4) { slow_window(base, 16u); continue; }       // (a payload that starts within 4 bytes of an aligned address)
+                const uint32_t w[9] = {j ? q.a[(j + 3) & 3].w : pv, q.a[j].x, q.a[j].y, q.a[j].z, q.a[j].w,
+                                       j < 3 ? q.a[(j + 1) & 3].x : nx0, j < 3 ? q.a[(j + 1) & 3].y : nx1, j < 3 ? q.a[(j + 1) & 3].z : nx2, 0u};
+                inspect(base, w, 16u);
+            }
+        };
+        uint64_t pc = (gthread - lane) >> 6;                              // (whole waves stay together: bpermute)
+        if (pc < npieces) {
+            Piece p0, p1;
+            const uint64_t last = npieces - 1;
+            issue(pc, p0);
+            for (;;) {
+                const uint64_t pn = pc + nwaves;
+                issue(pn < last ? pn : last, p1);                         // (behind the end: the last piece once more, not looked at)
+                look(pc, p0);
+                if (pn >= npieces) break;
+                const uint64_t pm = pn + nwaves;
+                issue(pm < last ? pm : last, p0);
+                look(pn, p1);
+                if (pm >= npieces) break;
+                pc = pm;
+            }
         }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0 && A) slow_window(0, (uint32_t)(A < n ? A : n));          // start positions [0, A)
     // the ragged end: start positions from the first vector not taken above
-    for (uint64_t base = A + nal * 16 + ((uint64_t)blockIdx.x * 256 + threadIdx.x) * 16; base < n; base += stride * 16) slow_window(base, 16u);
+    for (uint64_t base = A + nal * 16 + gthread * 16; base < n; base += stride * 16) slow_window(base, 16u);
 }
 
 // one workgroup of 1024 threads; work arrays succ[2][N+2], dist[2][N+2], mark[N+2]: in LDS as 16-bit indices when the candidates fit
@@ -3228,12 +3263,12 @@ __device__ __forceinline__ void frame_rank_body(const uint8_t* __restrict__ in, 
         dist[0][i] = (IT)(i < N ? 1u : 0u);
         mark[i] = 0;
     }
-    __threadfence();
+    if (sizeof(IT) == 4) __threadfence();                              // (work arrays in global memory; the 16-bit ones live in LDS)
     __syncthreads();
     const uint32_t head = *head_s;
     if (head >= N) { give_up(); return; }
     if (tid == 0) mark[head] = 1;
-    __threadfence();
+    if (sizeof(IT) == 4) __threadfence();                              // (work arrays in global memory; the 16-bit ones live in LDS)
     __syncthreads();
     int cur = 0;
     for (uint32_t span = 1; span < M; span <<= 1) {
@@ -3244,7 +3279,7 @@ __device__ __forceinline__ void frame_rank_body(const uint8_t* __restrict__ in, 
             dist[cur ^ 1][i] = (IT)((uint32_t)dist[cur][i] + (uint32_t)dist[cur][sc]);
             succ[cur ^ 1][i] = succ[cur][sc];
         }
-        __threadfence();
+        if (sizeof(IT) == 4) __threadfence();
         __syncthreads();
         cur ^= 1;
     }
@@ -3373,11 +3408,21 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
 // streams with thousands of compressed frames (throughput-bound); a match that reaches further back than the ring reads its
 // source from the output buffer, where those bytes have long been flushed (one global round trip for such a match).
 
+// Round 5: `remap` != nullptr -- the stage in front of `lz4` on the encoder's side was frame_shuffle, and every LZ4 chunk lies inside ONE of
+// its frames of remap_bytes: the frames are decoded straight to where the shuffle's inverse would move them (frame i of the sorted
+// stream is frame remap[i] of the volume, frame_shuffle_utils.hpp:337-344), one pass over the decoded bytes less.
+__device__ __forceinline__ uint64_t lz4_decode_frame_out(uint64_t o, const uint64_t* __restrict__ remap, uint64_t remap_bytes)
+{
+    if (!remap) return o;
+    const uint64_t fi = o / remap_bytes;
+    return remap[fi] * remap_bytes + (o - fi * remap_bytes);
+}
+
 template <uint32_t DEC_RING>
 __global__ __launch_bounds__(64)
 void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
                               uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes,
-                              uint32_t* __restrict__ errflag)
+                              uint32_t* __restrict__ errflag, const uint64_t* __restrict__ remap, uint64_t remap_bytes)
 {
     // stage of compressed bytes: 4 KiB, or 3 KiB beside the small ring (ring + stage + marks < 20 KiB: 8 waves per CU, not 7)
     constexpr uint32_t DEC_IN = DEC_RING < 65536u ? 3072u : 4096u;
@@ -3388,7 +3433,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
     const int lane = threadIdx.x;
     const uint32_t f = blockIdx.x;
     const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
-    const uint64_t frame_out = (uint64_t)f * frame_stride;      // frame f decodes to [f*chunk, ...)
+    const uint64_t frame_out = lz4_decode_frame_out((uint64_t)f * frame_stride, remap, remap_bytes);   // frame f decodes to [f*chunk, ...)
     uint32_t pos = 0;                                          // decoded bytes of this frame so far
     uint32_t flushed = 0;                                      // bytes of this frame already written to global memory
     bool bad = false;
@@ -3556,14 +3601,27 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                 const bool okl = flit < 15u && (fml < 15u || ext < 255u);
                 const uint32_t mlen = fml < 15u ? fml + 4u : 19u + ext;           // <= 273
                 const uint32_t nxt = (uint32_t)lane + 3u + flit + (fml == 15u ? 1u : 0u);
-                const uint64_t okmask = ballot(okl);
+                // the walk along the "next start" links: a lane read, a bit set and a compare per sequence (round 5; the compiler's loop
+                // took fifteen scalar instructions and three branches per step -- a fifth of a batch's time on streams of short sequences).
+                // step = where the next sequence starts, 0 = this one does not fit the mould or ends behind the 64 bytes: the walk stops
+                const uint32_t step = (okl && nxt <= 64u) ? nxt : 0u;
                 uint64_t starts = 0;
                 uint32_t cur = 0;
-                while (cur < 64u && ((okmask >> cur) & 1ull)) {
-                    const uint32_t nx = lane_read(nxt, cur);
-                    if (nx > 64u) break;                                           // (a sequence in the batch ends inside the 64 bytes)
-                    starts |= 1ull << cur;
-                    cur = nx;
+                {
+                    uint32_t t0;
+                    asm volatile(
+                        "1:\n\t"
+                        "v_readlane_b32 %[t0], %[step], %[cur]\n\t"
+                        "s_cmp_eq_u32 %[t0], 0\n\t"
+                        "s_cbranch_scc1 2f\n\t"
+                        "s_bitset1_b64 %[st], %[cur]\n\t"
+                        "s_mov_b32 %[cur], %[t0]\n\t"
+                        "s_cmp_lt_u32 %[cur], 64\n\t"
+                        "s_cbranch_scc1 1b\n"
+                        "2:"
+                        : [t0] "=&s"(t0), [cur] "+s"(cur), [st] "+s"(starts)
+                        : [step] "v"(step)
+                        : "scc");
                 }
                 if (starts) {
                     const bool is_start = (starts >> lane) & 1ull;
@@ -3867,7 +3925,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
     // else one chunk (the last frame the remainder) -- short frames must not leave the destination half-written
     {
         const uint64_t room = frame_out < out_bytes ? out_bytes - frame_out : 0;
-        const uint64_t expect = (gridDim.x == 1 || room < frame_stride) ? room : frame_stride;
+        const uint64_t expect = remap ? frame_stride : (gridDim.x == 1 || room < frame_stride) ? room : frame_stride;   // (remap: whole chunks only)
         if ((uint64_t)pos != expect) bad = true;
     }
     if (bad && lane == 0) atomicExch(errflag, 1u);
@@ -3878,7 +3936,8 @@ constexpr uint32_t DEC_COPY_SLICE = 32768;
 
 __global__ __launch_bounds__(256)
 void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
-                                   uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint32_t slices_per_frame)
+                                   uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint32_t slices_per_frame,
+                                   const uint64_t* __restrict__ remap, uint64_t remap_bytes)
 {
     const uint32_t f = blockIdx.x / slices_per_frame, slice = blockIdx.x % slices_per_frame;
     const uint32_t b0 = frame_first[f];
@@ -3886,7 +3945,7 @@ void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* 
     const uint4 e = blk[b0];
     if (!(e.z >> 31)) return;
     const uint32_t sz = e.z & 0x7fffffffu;
-    const uint64_t o = (uint64_t)f * frame_stride;
+    const uint64_t o = lz4_decode_frame_out((uint64_t)f * frame_stride, remap, remap_bytes);
     if (o + sz > out_bytes) return;                              // the decode kernel reports it
     const uint32_t begin = slice * DEC_COPY_SLICE;
     if (begin >= sz) return;
@@ -5277,8 +5336,8 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
     e = hipMemsetAsync(ncand, 0, 4, stream);
     if (e != hipSuccess) return e;
     const uint64_t nvec = (n + 15) / 16;
-    uint64_t blocks = (nvec + 255) / 256;
-    const uint64_t gcap = (uint64_t)num_cus() * 16;
+    uint64_t blocks = (nvec + 1023) / 1024;                               // a thread takes four vectors at a time, a wavefront 4 KiB
+    const uint64_t gcap = (uint64_t)num_cus() * 4;                        // (16 wavefronts per CU, all resident, each with its next piece in flight: 128 KiB per CU)
     if (blocks > gcap) blocks = gcap;
     if (blocks == 0) blocks = 1;
     uint32_t* hint = counts + 5;                                          // (counts: [0..3] the index, [4] the decoders' flag, [5] this)
@@ -5306,9 +5365,13 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
 constexpr uint32_t SQY_RING8_MIN = 2560;
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
-                                    uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join)
+                                    uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join,
+                                    const uint64_t* remap, uint64_t remap_bytes)
 {
     if (nframes == 0) return hipSuccess;
+    // (remap: frame f goes to remap[f * stride / remap_bytes] * remap_bytes + the rest -- whole chunks inside whole shuffle frames only)
+    if (remap && (remap_bytes == 0 || frame_stride == 0 || remap_bytes % frame_stride != 0 || out_bytes % remap_bytes != 0 ||
+                  (uint64_t)nframes * frame_stride != out_bytes)) return hipErrorInvalidValue;
     // the stored frames are copied (HBM-bound) while the compressed ones are decoded (latency-bound, HBM idle): disjoint
     // outputs, both only read the stream -- on a second stream when the caller has one to spare.  The decode kernel is
     // launched first: its few long-running waves should get their slots before the copy's many short workgroups fill the CUs.
@@ -5326,18 +5389,18 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     // per CU win although more matches reach behind the ring -- the C3 slab's 3584 frames 3.37 -> 2.65 ms (a 4 KiB ring: no better)
     if (ncompressed > SQY_RING8_MIN && nframes > SQY_RING8_MIN)
         hipLaunchKernelGGL(lz4_frames_decode_kernel<8192>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
-                           out_bytes, frame_stride, block_bytes, errflag);
+                           out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);
     else if (ncompressed > 768u && nframes > 768u)
         hipLaunchKernelGGL(lz4_frames_decode_kernel<16384>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
-                           out_bytes, frame_stride, block_bytes, errflag);
+                           out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);
     else
         hipLaunchKernelGGL(lz4_frames_decode_kernel<65536>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
-                           out_bytes, frame_stride, block_bytes, errflag);
+                           out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);
     {   // stored blocks of single-block frames (a block never exceeds block_bytes)
         const uint32_t slices = (uint32_t)((block_bytes + DEC_COPY_SLICE - 1) / DEC_COPY_SLICE);
         if (slices == 0 || (uint64_t)nframes * slices > 0x7fffffffull) return hipErrorInvalidValue;
         hipLaunchKernelGGL(lz4_stored_frames_copy_kernel, dim3(nframes * slices), dim3(256), 0, cs, in, (const uint4*)blk, frame_first,
-                           out, out_bytes, frame_stride, slices);
+                           out, out_bytes, frame_stride, slices, remap, remap_bytes);
     }
     if (side) {
         hipError_t e = hipEventRecord(join, copy_stream);

@@ -333,6 +333,67 @@ def test_frame_shuffle_decode_with_equal_metrics(sqy, oracle):
     assert np.array_equal(back, vol)
 
 
+# ---- frame_shuffle's inverse folded into the LZ4 decode (round 5) ----------------------------------------------------------------
+# When every LZ4 chunk lies inside ONE frame of the shuffle the frames are decoded straight to their places (sqy_kernels.hip:
+# lz4_decode_frame_out); any other geometry takes the two stages one after the other.  Frames of 1, 2, 4 chunks, a chunk of several
+# frames and frames no chunk size divides (the fall-back), compressible, stored and mixed frames, maps that name a frame twice.
+@pytest.mark.parametrize("dtype,shape,cfg", [(np.uint8, (12, 512, 512), ""), (np.uint8, (9, 1024, 512), ""), (np.uint16, (7, 512, 256), ""),
+                                             (np.uint16, (6, 1024, 512), ""), (np.uint8, (40, 128, 128), ""), (np.uint8, (11, 300, 301), ""),
+                                             (np.uint8, (16, 256, 256), "(framestep_kb=64)"), (np.uint16, (5, 512, 512), "(framestep_kb=128)"),
+                                             (np.uint8, (6, 512, 512), "(framestep_kb=512)"), (np.uint8, (7, 512, 512), "(n_chunks_of_input=7)")])
+@pytest.mark.parametrize("kind", ["stack", "noise", "mixed", "sparse", "equal"])
+def test_frame_shuffle_inverse_folded_into_lz4(sqy, oracle, dtype, shape, cfg, kind):
+    rng = np.random.default_rng(shape[0] * 7 + shape[2])
+    hi = 256 if dtype == np.uint8 else 65536
+    if kind == "stack":
+        vol = synth.stack(shape, dtype)
+    elif kind == "noise":
+        vol = rng.integers(0, hi, shape).astype(dtype)
+    elif kind == "mixed":
+        vol = synth.stack(shape, dtype)
+        vol[1::3] = rng.integers(0, hi, vol[1::3].shape).astype(dtype)
+    elif kind == "sparse":                                  # compressed frames (the others are mostly stored)
+        vol = ((rng.random(shape) < 0.01) * rng.integers(1, hi, shape)).astype(dtype)
+        vol[::4] = (np.arange(vol[::4].size) % 251).reshape(vol[::4].shape).astype(dtype)
+    else:                                                   # frames with equal metrics: the map names one of them for all
+        vol = rng.integers(0, hi, shape).astype(dtype)
+        vol[2] = vol[0]
+        vol[3:5] = 0
+        vol[shape[0] - 1] = 0
+    pipeline = "frame_shuffle->lz4" + cfg
+    blob = oracle.pipeline_encode(pipeline, vol, nthreads=2)
+    want = oracle.pipeline_decode(blob)
+    rc, _ = sqy.decode(oracle.pipeline_encode(pipeline, np.full(shape, hi - 1, dtype), nthreads=2))      # (dirty the workspace)
+    assert rc == 0
+    rc, back = sqy.decode(blob)
+    assert rc == 0
+    assert np.array_equal(back, want), (shape, cfg, kind)
+    if kind != "equal":
+        assert np.array_equal(back, vol)
+    rc, mine = sqy.encode(pipeline, vol, nthreads=2, extra_capacity=16 * shape[0] + 4096)
+    assert rc == 0 and mine == blob
+
+
+def test_frame_shuffle_inverse_folded_bad_map_is_refused(sqy, oracle):
+    """a reorder_map in the header that names a frame outside the volume: refused before anything is written through it"""
+    import base64, re
+    vol = np.random.default_rng(3).integers(0, 256, (8, 512, 512), dtype=np.uint8)
+    blob = oracle.pipeline_encode("frame_shuffle->lz4", vol, nthreads=2)
+    m = re.search(rb"<verbatim>([A-Za-z0-9+/=]+)<\\/verbatim>", blob)
+    assert m, "reorder_map not found in the header"
+    raw = bytearray(base64.b64decode(m.group(1)))
+    assert len(raw) == 8 * 8
+    for slot in (0, 3, 7):
+        r2 = bytearray(raw)
+        r2[8 * slot:8 * slot + 8] = (8).to_bytes(8, "little")            # frame 8 of 8
+        enc = base64.b64encode(bytes(r2))
+        assert len(enc) == len(m.group(1))                                # (the header keeps its length)
+        rc, _ = sqy.decode(blob[:m.start(1)] + enc + blob[m.end(1):])
+        assert rc != 0, slot
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+
+
 # ---- ONE block-linked frame decoded block-parallel (round 4) ---------------------------------------------------------------------
 # The serial layout's frame was decoded by one wavefront in rounds 2-3.  Now every block is decoded at once with the history in front of
 # it as an unknown (a 16-bit reference per byte), the last 64 KiB of every block are resolved in order, everything else at once
