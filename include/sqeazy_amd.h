@@ -193,6 +193,7 @@ SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
  *   "block_parallel_warmup"           65536 [SQY_BLOCK_PARALLEL_WARMUP=<bytes>, 0 .. 2^30]  stream parsed in front of a block to guess its table
  *   "block_parallel_stats"            0 [SQY_BLOCK_PARALLEL_STATS=1]  print the blocks whose guess failed
  *   "tail_scan"                       1 [SQY_NO_TAIL_SCAN=1 -> 0]  serial-layout decode: the walk over the block tails as a scan
+ *   "decode_two_waves"                1 [SQY_NO_DECODE_TWO_WAVES=1 -> 0]  chunked-layout decode: two wavefronts per frame (0: one)
  * Set: 0 = done, 1 = unknown name or value out of range.  Get: the value, -1 for an unknown name. */
 SQY_FUNCTION_PREFIX int SQYAMD_Set_Option(const char* name, long value);
 SQY_FUNCTION_PREFIX long SQYAMD_Get_Option(const char* name);

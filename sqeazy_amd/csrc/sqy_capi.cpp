@@ -66,10 +66,12 @@ struct Options {
     std::atomic<long> block_parallel_warmup;            // bytes parsed in front of a block to guess its table
     std::atomic<long> block_parallel_stats;             // print the blocks that failed the table check
     std::atomic<long> tail_scan;                        // serial-layout decode: the walk over the tails as a scan
+    std::atomic<long> decode_two_waves;                 // chunked-layout decode: two wavefronts per frame (one parses, one copies)
     Options()
         : transpose_chain(env_flag("SQY_NO_TRANSPOSE_CHAIN") ? 0 : 1), transpose_chain_caller_streams(env_flag("SQY_TRANSPOSE_CHAIN_CALLER_STREAMS")),
           block_parallel(env_flag("SQY_NO_BLOCK_PARALLEL") ? 0 : 1), block_parallel_warmup(env_number("SQY_BLOCK_PARALLEL_WARMUP", 65536, 0, kWarmupMax)),
-          block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1) {}
+          block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1),
+          decode_two_waves(env_flag("SQY_NO_DECODE_TWO_WAVES") ? 0 : 1) {}
     std::atomic<long>* find(const char* name)
     {
         if (!name) return nullptr;
@@ -79,6 +81,7 @@ struct Options {
         if (!std::strcmp(name, "block_parallel_warmup")) return &block_parallel_warmup;
         if (!std::strcmp(name, "block_parallel_stats")) return &block_parallel_stats;
         if (!std::strcmp(name, "tail_scan")) return &tail_scan;
+        if (!std::strcmp(name, "decode_two_waves")) return &decode_two_waves;
         return nullptr;
     }
 };
@@ -1464,7 +1467,7 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                         const bool side_ok = cx.ensure_side();           // (without it the copy simply follows on the same stream)
                         ProfScope ps("lz4_frames_decode", stream, pend);
                         SQY_HIP(sqy::launch_lz4_frames_decode(cur, blk, frame_first, nframes, out, total, chunk, block_bytes, hc[3], counts + 4, stream, side_ok ? cx.side : nullptr, cx.fork, cx.join,
-                                                              remap, remap_bytes));
+                                                              remap, remap_bytes, g_opt.decode_two_waves.load() && hc[1] == nframes));
                     }
                     // (the decoder's verdict is read at the END of the call, with the call's last synchronisation: the stages in between are
                     // plain data movement and stay inside their buffers whatever the bytes are -- one host round trip less per decode)

@@ -188,7 +188,8 @@ hipError_t launch_lz4_linked_decode_parallel(const uint8_t* in, const void* blk,
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
                                     uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream = nullptr, hipEvent_t fork = nullptr,
-                                    hipEvent_t join = nullptr, const uint64_t* remap = nullptr, uint64_t remap_bytes = 0);
+                                    hipEvent_t join = nullptr, const uint64_t* remap = nullptr, uint64_t remap_bytes = 0, bool two_waves = false);
+// (two_waves: every frame is ONE block -- two wavefronts per frame, lz4_frames_decode2_kernel)
 // (remap: the inverse of frame_shuffle folded into the decode -- the chunk that starts at byte o of the sorted stream goes to
 // remap[o / remap_bytes] * remap_bytes + o % remap_bytes; remap_bytes a multiple of frame_stride, out_bytes = nframes * frame_stride)
 // decode of quantiser->bitswap1: inverse transpose of the 8-bit planes and the quantiser's look-up in one pass

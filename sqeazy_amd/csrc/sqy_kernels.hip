@@ -3503,6 +3503,27 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         };
         auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };   // cnt <= DEC_IN - 16, at + cnt <= sz
         auto sbyte_at = [&](uint32_t at) -> uint32_t { return stage[at - sbase]; };
+        // A run of length-extension bytes from `at` on (255 .. 255, closed by a byte below 255), 64 bytes per LDS round trip (round 5: byte by
+        // byte, a round trip each, the thousand 255s of a chunk of zeros were a seventh of a millisecond -- the frames of the nearly empty
+        // planes, a few hundred sequences of kilobyte matches, were the slowest of the bench stack).  acc += the bytes; at -> behind the run;
+        // false: the block ends inside the run.
+        auto ext_run = [&](uint32_t& at, uint32_t& acc) -> bool {
+            for (;;) {
+                if (at >= sz) return false;
+                const uint32_t cnt = sz - at < 64u ? sz - at : 64u;
+                need(at, cnt);
+                const uint32_t bv = (uint32_t)lane < cnt ? (uint32_t)stage[at - sbase + (uint32_t)lane] : 0u;
+                const uint64_t closing = ballot((uint32_t)lane < cnt && bv != 255u);
+                if (closing) {
+                    const uint32_t k = ctz64(closing);
+                    acc += 255u * k + lane_read(bv, k);
+                    at += k + 1u;
+                    return true;
+                }
+                acc += 255u * cnt;
+                at += cnt;
+            }
+        };
 
         // cnt <= 1024 bytes from LDS (ring or stage: `from`, contiguous) onto the ring at dp (dp + cnt <= DEC_RING), 16 bytes per lane and
         // the last cnt % 16 one per lane; every read is issued before the first write.  (A lane's 16-byte read may run up to 15 bytes
@@ -3862,13 +3883,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
                             ml_ok = sb != 255u;
                         }
                         ip = ipl + lit + used2;
-                        while (!ml_ok) {                                             // (a match of more than 3.3 KiB: byte by byte from here)
-                            if (ip >= sz) { bad = true; break; }
-                            need(ip, 1);
-                            const uint32_t sb = sbyte_at(ip++);
-                            ml += sb;
-                            ml_ok = sb != 255u;
-                        }
+                        if (!ml_ok && !ext_run(ip, ml)) bad = true;                  // (a match of more than 3.3 KiB: the rest of its length bytes)
                         ml += 4u;
                         if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
                         copy_match(offset, ml);
@@ -3879,10 +3894,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             if (!have_token) { need(ip, 1); token = sbyte_at(ip); }
             ++ip;
             uint32_t lit = token >> 4;
-            if (lit == 15) {
-                uint32_t sbyte;
-                do { if (ip >= sz) { bad = true; break; } need(ip, 1); sbyte = sbyte_at(ip++); lit += sbyte; } while (sbyte == 255);
-            }
+            if (lit == 15 && !ext_run(ip, lit)) bad = true;
             if (bad || ip + lit > sz || pos - block_start + lit > block_bytes) { bad = true; break; }
             if (lit <= DEC_IN - 64u) {
                 if (lit) need(ip, lit);
@@ -3911,10 +3923,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             const uint32_t offset = sbyte_at(ip) | (sbyte_at(ip + 1) << 8);
             ip += 2;
             uint32_t ml = token & 15u;
-            if (ml == 15) {
-                uint32_t sbyte;
-                do { if (ip >= sz) { bad = true; break; } need(ip, 1); sbyte = sbyte_at(ip++); ml += sbyte; } while (sbyte == 255);
-            }
+            if (ml == 15 && !ext_run(ip, ml)) bad = true;
             ml += 4;
             if (bad || offset == 0 || offset > pos || pos - block_start + ml > block_bytes) { bad = true; break; }
             copy_match(offset, ml);
@@ -3929,6 +3938,614 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         if ((uint64_t)pos != expect) bad = true;
     }
     if (bad && lane == 0) atomicExch(errflag, 1u);
+}
+
+// ---- the same decode by TWO wavefronts per frame (round 5) ------------------------------------------------------------------------------
+// A frame's decode is one dependent chain, and a lone wavefront issues an instruction every five cycles or so: 2000 cycles per sequence on
+// the sparse planes of the bench stack, 380 per sequence on streams of short ones.  Taken apart (a build whose copies do nothing): 42 % / 58 %
+// of that is finding out WHAT the sequences are -- a chain through the compressed bytes alone -- and the rest is moving the bytes.  So two
+// wavefronts share a frame: wave 0 walks the compressed bytes and writes what it finds -- {first literal, literals, offset, match length},
+// up to 64 sequences to a unit, two units in LDS --, wave 1 takes a unit into its registers, gives the slot back and does the copies (the
+// rounds of 64 output bytes for short sequences, one sequence after the other for long ones), while wave 0 is two units ahead.  Frames of
+// ONE block only (what the chunked layout writes); everything else, and streams with so many compressed frames that the decode is bound
+// by the instructions issued rather than by one chain (the 8 KiB ring's range), stays with the kernel above.
+// Hand-over: prod / cons count units in LDS, a wave that waits sleeps and looks again; `stop` ends both (an error on either side); every wait
+// is bounded (2^22 looks: seconds), so that the grid drains whatever happens.
+// Diagnostic builds (tools/dec_stats.sh; never the product): -DSQY_DEC_STATS makes both waves count what they do and leave the counts in the
+// first 256 bytes of their frame's OUTPUT (which is garbage then); -DSQY_DEC_INERT makes wave 1 take its units and do nothing.
+#ifdef SQY_DEC_STATS
+#define SQY_DST(x) x
+#else
+#define SQY_DST(x)
+#endif
+constexpr uint32_t DEC2_PIN = 4096;                   // wave 0's own stage of compressed bytes: a ring of two halves (+ 32 bytes of mirror)
+constexpr uint32_t DEC2_UNIT = 64;                    // sequences per unit
+
+// wave 0 of lz4_frames_decode2_kernel (a function of its own: the two roles in one body had the register allocator spill)
+__device__ __noinline__ void lz4_decode2_parse(const uint8_t* __restrict__ src, uint32_t sz, lds_u8* pstage, SQY_LDS uint4* units,
+                                               volatile SQY_LDS uint32_t* ctrl, int lane, uint64_t* stats)
+{
+    constexpr uint32_t SPIN = 1u << 22;
+    SQY_DST(uint64_t st_t0 = __builtin_amdgcn_s_memtime(); uint64_t st_a = st_t0; uint64_t st_batches = 0; uint64_t st_nst = 0; uint64_t st_singles = 0;
+            uint64_t st_cb = 0; uint64_t st_cs = 0; uint64_t st_pub = 0; uint64_t st_cp = 0; uint64_t st_stall = 0; uint64_t st_ext = 0;)
+    // ================================================= wave 0: what the sequences are =================================================
+    // Its stage is a ring of two halves; the half behind the one it reads is on its way from global memory while it parses (the
+    // sparse planes' sequences are 100-300 compressed bytes apart: with a stage filled when it runs out, a third of this wave's
+    // time was the wait for the fill) -- by LDS-DMA, as the encoder's window: no registers held across the parse loop.
+    // lo_ok .. hi_ok: the block bytes that can be read; the first 32 bytes of the ring are mirrored behind its end, so that the short
+    // reads below never wrap.  A half is fetched into the slot of the half BEHIND the one being read, i.e. only once the reads have
+    // moved into the newest half.
+    constexpr uint32_t PH = DEC2_PIN / 2u, PR = DEC2_PIN;
+    uint32_t lo_ok = 0, hi_ok = 0;
+    bool pend = false;                                                // [hi_ok, hi_ok + PH) is on its way
+    auto dma_issue = [&]() {
+#pragma unroll
+        for (uint32_t j = 0; j < PH / 1024u; ++j) {
+            const uint32_t a = hi_ok + j * 1024u + (uint32_t)lane * 16u;
+            if (a + 16u <= sz) {                                      // lanes past the block's last whole 16 bytes stay off
+                const uint32_t lds_dst = sgpr((uint32_t)(uintptr_t)pstage + ((hi_ok + j * 1024u) & (PR - 1u)));   // wave-uniform; the copy adds lane * 16
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep) : "v"(src + a), "s"(lds_dst) : "memory");
+            }
+        }
+        if (hi_ok >= PH && lo_ok < hi_ok - PH) lo_ok = hi_ok - PH;   // (the slot held [hi_ok - PR, hi_ok - PH))
+        pend = true;
+    };
+    auto dma_commit = [&]() {
+        SQY_DST(const uint64_t q0 = __builtin_amdgcn_s_memtime();)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SQY_DST(st_stall += __builtin_amdgcn_s_memtime() - q0;)
+        wave_lds_sync();
+        // the block's last, partial 16 bytes, when they lie in this half: byte by byte (never a read past the block)
+        if (sz < hi_ok + PH && (sz & 15u) && (sz & ~15u) >= hi_ok) {
+            const uint32_t a = (sz & ~15u) + (uint32_t)lane;
+            if (a < sz) pstage[a & (PR - 1u)] = src[a];
+            wave_lds_sync();
+        }
+        if ((hi_ok & (PR - 1u)) == 0u) {                              // the half with ring offset 0: its first 32 bytes once more behind the end
+            if (lane < 8) *reinterpret_cast<SQY_LDS uint32_t*>(pstage + PR + 4u * (uint32_t)lane) = *reinterpret_cast<const SQY_LDS uint32_t*>(pstage + 4u * (uint32_t)lane);
+            wave_lds_sync();
+        }
+        hi_ok += PH;
+        pend = false;
+    };
+    auto need = [&](uint32_t at, uint32_t cnt) {                      // cnt <= PH - 16, at + cnt <= sz
+        while (!(at >= lo_ok && at + cnt <= hi_ok)) {
+            if (!(at >= lo_ok && at < hi_ok + PH)) {                  // the first use, or a jump over more than the half on its way
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (a copy in flight must not land on top of the new ones)
+                lo_ok = hi_ok = at & ~(PH - 1u);
+                pend = false;
+            }
+            if (!pend) dma_issue();
+            dma_commit();
+        }
+        if (!pend && hi_ok < sz && hi_ok >= PH && at >= hi_ok - PH) dma_issue();      // the next half, early
+    };
+    auto byte_at = [&](uint32_t at) -> uint32_t { need(at, 1); return pstage[at & (PR - 1u)]; };
+    // the 16 bytes at `at` (at + 16 <= sz) as two uniform 64-bit words
+    auto window = [&](uint32_t at, uint64_t& lo, uint64_t& hi) {
+        need(at, 16);
+        const uint32_t o = at & (PR - 1u), sh = o & 3u;
+        const uint4 d = lds_ld_4dw(pstage + (o & ~3u));
+        const uint32_t d4 = *reinterpret_cast<const volatile SQY_LDS uint32_t*>(pstage + (o & ~3u) + 16u);
+        const uint32_t x0 = sgpr(__builtin_amdgcn_alignbyte(d.y, d.x, sh)), x1 = sgpr(__builtin_amdgcn_alignbyte(d.z, d.y, sh));
+        const uint32_t x2 = sgpr(__builtin_amdgcn_alignbyte(d.w, d.z, sh)), x3 = sgpr(__builtin_amdgcn_alignbyte(d4, d.w, sh));
+        lo = ((uint64_t)x1 << 32) | x0; hi = ((uint64_t)x3 << 32) | x2;
+    };
+    auto wb = [](uint64_t lo, uint64_t hi, uint32_t i) -> uint32_t { return i < 8u ? (uint32_t)(lo >> (8u * i)) & 0xffu : (uint32_t)(hi >> (8u * (i - 8u))) & 0xffu; };
+    // a run of length-extension bytes from `at` on, 64 bytes per LDS round trip (see ext_run in the kernel above)
+    auto ext_run = [&](uint32_t& at, uint32_t& acc) -> bool {
+        for (;;) {
+            SQY_DST(++st_ext;)
+            if (at >= sz) return false;
+            const uint32_t cnt = sz - at < 64u ? sz - at : 64u;
+            need(at, cnt);
+            const uint32_t bv = (uint32_t)lane < cnt ? (uint32_t)pstage[(at + (uint32_t)lane) & (PR - 1u)] : 0u;
+            const uint64_t closing = ballot((uint32_t)lane < cnt && bv != 255u);
+            if (closing) {
+                const uint32_t k = ctz64(closing);
+                acc += 255u * k + lane_read(bv, k);
+                at += k + 1u;
+                return true;
+            }
+            acc += 255u * cnt;
+            at += cnt;
+        }
+    };
+
+    uint32_t published = 0, m = 0;                         // units handed over, sequences in the unit under way
+    bool stopped = false;
+    // the slot of unit `published` is free once unit `published - 2` has been taken
+    auto slot_wait = [&]() {
+        for (uint32_t spin = 0; published >= ctrl[1] + 2u; ++spin) {
+            if (ctrl[2] || spin >= SPIN) { stopped = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto publish = [&](uint32_t flags) {
+        wave_lds_sync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) { ctrl[4u + (published & 1u)] = m | (flags << 8); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) ctrl[0] = published + 1u;
+        ++published;
+        m = 0;
+    };
+    uint32_t ip = 0;
+    uint32_t one_by_one = 0, backoff = 1;
+    bool damaged = false, ended = false;
+    slot_wait();
+    while (!stopped && !ended && !damaged) {
+        SQY_DST(st_a = __builtin_amdgcn_s_memtime();)
+        if (ip >= sz) { ended = true; break; }             // (a block that ends behind a match: the byte count decides, as in the kernel above)
+        // ---- a batch: the next 64 compressed bytes, every lane the sequence that WOULD start at its byte (see the kernel above) ----
+        if (one_by_one) --one_by_one;
+        else if (ip + 96u <= sz) {
+            if (m + 22u > DEC2_UNIT) {
+                SQY_DST(const uint64_t q0 = __builtin_amdgcn_s_memtime();)
+                publish(0); slot_wait();
+                SQY_DST(st_cp += __builtin_amdgcn_s_memtime() - q0; ++st_pub;)
+                if (stopped) break;
+            }
+            need(ip, 96);
+            const uint32_t wi = (ip + (uint32_t)lane) & (PR - 1u);
+            const uint32_t tokb = pstage[wi];
+            const uint32_t flit = tokb >> 4, fml = tokb & 15u;
+            const uint32_t w = lds_ld_u32_via_aligned(pstage, (wi + 1u + flit) & (PR - 1u));
+            const uint32_t lw = lds_ld_u32_via_aligned(pstage, (wi + 1u) & (PR - 1u));      // the four bytes behind the token: up to four literals travel in the record
+            const uint32_t offs = w & 0xffffu, ext = (w >> 16) & 0xffu;
+            const bool okl = flit < 15u && (fml < 15u || ext < 255u);
+            const uint32_t mlen = fml < 15u ? fml + 4u : 19u + ext;
+            const uint32_t nxt = (uint32_t)lane + 3u + flit + (fml == 15u ? 1u : 0u);
+            const uint32_t step = (okl && nxt <= 64u) ? nxt : 0u;
+            uint64_t starts = 0;
+            uint32_t cur = 0;
+            {
+                uint32_t t0;
+                asm volatile(
+                    "1:\n\t"
+                    "v_readlane_b32 %[t0], %[step], %[cur]\n\t"
+                    "s_cmp_eq_u32 %[t0], 0\n\t"
+                    "s_cbranch_scc1 2f\n\t"
+                    "s_bitset1_b64 %[st], %[cur]\n\t"
+                    "s_mov_b32 %[cur], %[t0]\n\t"
+                    "s_cmp_lt_u32 %[cur], 64\n\t"
+                    "s_cbranch_scc1 1b\n"
+                    "2:"
+                    : [t0] "=&s"(t0), [cur] "+s"(cur), [st] "+s"(starts)
+                    : [step] "v"(step)
+                    : "scc");
+            }
+            const uint32_t nst = (uint32_t)__builtin_popcountll(starts);
+            if (nst) {                                                 // (whatever the walk found is parsed: it goes into the unit)
+                if ((starts >> lane) & 1ull) {
+                    const uint32_t r = (uint32_t)__builtin_popcountll(starts & ((1ull << lane) - 1ull));
+                    const v4u rec = {flit <= 4u ? lw : ip + (uint32_t)lane + 1u, flit | (flit <= 4u ? 0x80000000u : 0u), offs, mlen};
+                    *reinterpret_cast<SQY_LDS v4u*>(units + (published & 1u) * DEC2_UNIT + m + r) = rec;
+                }
+                m += nst;
+                ip += cur;
+            }
+            // why the walk stopped: a sequence that runs past the 64 bytes (the next batch takes it), or one that does not fit the mould
+            // (15+ literals, a long match) -- that one goes the single way; streams made of such sequences try a batch ever more rarely
+            const bool mould = cur >= 64u || lane_read(okl ? 1u : 0u, cur & 63u) != 0u;
+            if (nst >= 4u) backoff = 1;                                // (a stretch of short sequences: the next batch right behind the odd one out)
+            SQY_DST(++st_batches; st_nst += nst; { const uint64_t q1 = __builtin_amdgcn_s_memtime(); st_cb += q1 - st_a; st_a = q1; })
+            if (mould) continue;
+            one_by_one = backoff - 1u;                                 // (this one, below, is the first of them)
+            if (nst < 4u) backoff = backoff < 256u ? backoff * 2u : 256u;
+            if (m >= DEC2_UNIT) { publish(0); slot_wait(); if (stopped) break; }
+        }
+        // ---- one sequence ----
+        if (m >= DEC2_UNIT) { publish(0); slot_wait(); if (stopped) break; }
+        uint32_t token, lit, used = 1;
+        uint64_t lo = 0, hi = 0;
+        bool win = false;
+        uint32_t inl = 0;                                      // the four bytes behind the token (when a window holds them)
+        if (ip + 16u <= sz) { window(ip, lo, hi); win = true; token = wb(lo, hi, 0); inl = (uint32_t)(lo >> 8); }
+        else token = byte_at(ip);
+        const bool have_inl = win;
+        lit = token >> 4;
+        if (lit == 15u) {
+            bool ok = false;
+            while (win && used < 16u) { const uint32_t sb = wb(lo, hi, used++); lit += sb; if (sb != 255u) { ok = true; break; } }
+            if (!ok) {
+                uint32_t at = ip + used;
+                if (!ext_run(at, lit)) { damaged = true; break; }
+                used = at - ip;
+                win = false;                                   // (the window in hand is behind us)
+            }
+        }
+        const uint32_t ipl = ip + used;                        // the first literal
+        if (ipl > sz || lit > sz - ipl) { damaged = true; break; }
+        uint32_t offset = 0, ml = 0;
+        if (ipl + lit == sz) ended = true;                     // the block's last sequence: literals only
+        else {
+            const uint32_t ipo = ipl + lit;
+            if (ipo + 2u > sz) { damaged = true; break; }
+            uint32_t o2 = 0;                                  // index of the offset's first byte inside the window in hand
+            if (win && used + lit + 2u <= 16u) o2 = used + lit;
+            else if (ipo + 16u <= sz) { window(ipo, lo, hi); win = true; }
+            else win = false;
+            uint32_t used2;
+            if (win) { offset = wb(lo, hi, o2) | (wb(lo, hi, o2 + 1u) << 8); used2 = o2 + 2u; }
+            else { offset = byte_at(ipo) | (byte_at(ipo + 1u) << 8); used2 = 2u; }
+            const uint32_t wbase = win ? ipo - o2 : ipo;          // block position of window byte 0 (no window: of the offset)
+            ml = token & 15u;
+            if (ml == 15u) {
+                bool ok = false;
+                while (win && used2 < 16u) { const uint32_t sb = wb(lo, hi, used2++); ml += sb; if (sb != 255u) { ok = true; break; } }
+                if (!ok) {
+                    uint32_t at = wbase + used2;
+                    if (!ext_run(at, ml)) { damaged = true; break; }
+                    used2 = at - wbase;
+                }
+            }
+            ml += 4u;
+            ip = wbase + used2;
+        }
+        if (lane == 0) {
+            const bool in_rec = have_inl && lit <= 4u;         // (lit < 15: the literals begin right behind the token)
+            const v4u rec = {in_rec ? inl : ipl, lit | (in_rec ? 0x80000000u : 0u), offset, ml};
+            *reinterpret_cast<SQY_LDS v4u*>(units + (published & 1u) * DEC2_UNIT + m) = rec;
+        }
+        ++m;
+        SQY_DST(++st_singles; st_cs += __builtin_amdgcn_s_memtime() - st_a;)
+    }
+    if (!stopped) publish(damaged ? 2u : 1u);
+    SQY_DST(if (lane == 0 && stats) {
+        stats[0] = __builtin_amdgcn_s_memtime() - st_t0; stats[1] = st_batches; stats[2] = st_nst; stats[3] = st_singles; stats[4] = st_cb; stats[5] = st_cs;
+        stats[6] = st_pub; stats[7] = st_cp; stats[8] = sz; stats[9] = st_stall; stats[10] = st_ext;
+    })
+}
+
+// wave 1 of lz4_frames_decode2_kernel
+template <uint32_t DEC_RING>
+__device__ __noinline__ void lz4_decode2_copy(const uint8_t* __restrict__ src, uint32_t sz, uint8_t* __restrict__ out, uint64_t frame_out, uint64_t out_bytes,
+                                              uint64_t block_bytes, uint64_t expect, lds_u8* ring, lds_u8* stage, lds_u8* owner_mark,
+                                              SQY_LDS uint4* units, volatile SQY_LDS uint32_t* ctrl, uint32_t* __restrict__ errflag, int lane)
+{
+    constexpr uint32_t DEC_IN = 3072u;
+    constexpr uint32_t SPIN = 1u << 22;
+    SQY_DST(uint64_t ct_t0 = __builtin_amdgcn_s_memtime(); uint64_t ct_wait = 0; uint64_t ct_units = 0; uint64_t ct_runits = 0; uint64_t ct_rounds = 0;
+            uint64_t ct_cr = 0; uint64_t ct_seqs = 0; uint64_t ct_ci = 0; uint64_t ct_fill = 0; uint64_t ct_flush = 0; uint64_t ct_nflush = 0;
+            uint64_t ct_short = 0; uint64_t ct_cshort = 0; uint64_t ct_long = 0; uint64_t ct_clong = 0; uint64_t ct_far = 0; uint64_t ct_cfar = 0;)
+    // ===================================================== wave 1: the bytes =====================================================
+    uint32_t pos = 0, flushed = 0;
+    bool bad = false;
+    auto flush = [&](bool all) {
+        SQY_DST(const uint64_t fl0 = __builtin_amdgcn_s_memtime(); if (flushed + 4096u <= pos) ++ct_nflush;)
+        // 4 KiB at a time: four reads of the ring in flight, then four stores (a KiB per call, each behind its own LDS round trip, was a fifth
+        // of this wave's time).  What has not left yet stays inside the ring (a step adds at most 1 KiB), and a match that reaches behind the
+        // ring (offset > DEC_RING >= 16 KiB) ends more than 15 KiB back: flushed.
+        while (flushed + 4096u <= pos) {
+            const uint64_t o = frame_out + flushed;
+            if (o + 4096u > out_bytes) { bad = true; flushed = pos; break; }
+            v4u v[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const SQY_LDS v4u*>(ring + ((flushed + q * 1024u + (uint32_t)lane * 16u) & (DEC_RING - 1)));
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) st_u128(out + o + q * 1024u + (uint32_t)lane * 16u, make_uint4(v[q].x, v[q].y, v[q].z, v[q].w));
+            flushed += 4096u;
+        }
+        while (all && flushed < pos) {
+            const uint32_t cnt = (pos - flushed >= 1024u) ? 1024u : (pos - flushed);
+            const uint64_t o = frame_out + flushed;
+            if (o + cnt > out_bytes) { bad = true; flushed = pos; break; }
+            const uint32_t nvec = cnt >> 4;
+            if ((uint32_t)lane < nvec) {
+                const v4u v = *reinterpret_cast<const SQY_LDS v4u*>(ring + ((flushed + (uint32_t)lane * 16u) & (DEC_RING - 1)));
+                st_u128(out + o + (uint32_t)lane * 16u, make_uint4(v.x, v.y, v.z, v.w));
+            }
+            const uint32_t done = nvec << 4;
+            if ((uint32_t)lane < cnt - done) out[o + done + lane] = ring[(flushed + done + lane) & (DEC_RING - 1)];
+            flushed += cnt;
+        }
+        SQY_DST(ct_flush += __builtin_amdgcn_s_memtime() - fl0;)
+    };
+    uint32_t sbase = 0, shi = 0;
+    auto fill = [&](uint32_t at) {
+        SQY_DST(const uint64_t f0 = __builtin_amdgcn_s_memtime();)
+        sbase = at & ~15u;
+#pragma unroll
+        for (uint32_t j = 0; j < DEC_IN / 1024; ++j) {
+            const uint32_t a = sbase + j * 1024u + (uint32_t)lane * 16u;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (a + 16u <= sz) v = ld_u128(src + a);
+            else if (a < sz) {
+                uint32_t wv[4] = {0, 0, 0, 0};
+                for (uint32_t k = 0; a + k < sz; ++k) wv[k >> 2] |= (uint32_t)src[a + k] << (8u * (k & 3u));
+                v = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+            }
+            const v4u vv = {v.x, v.y, v.z, v.w};
+            *reinterpret_cast<SQY_LDS v4u*>(stage + j * 1024u + (uint32_t)lane * 16u) = vv;
+        }
+        wave_lds_sync();
+        shi = sbase + DEC_IN < sz ? sbase + DEC_IN : sz;
+        SQY_DST(ct_fill += __builtin_amdgcn_s_memtime() - f0;)
+    };
+    auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };       // cnt <= DEC_IN - 16, at + cnt <= sz
+    auto wide_copy = [&](const lds_u8* from, uint32_t dp, uint32_t cnt) {
+        const uint32_t full = cnt >> 4, r = cnt & 15u;
+        v4u_any v = {0, 0, 0, 0};
+        uint32_t t = 0;
+        if ((uint32_t)lane < full) v = *reinterpret_cast<const SQY_LDS v4u_any*>(from + (uint32_t)lane * 16u);
+        if ((uint32_t)lane < r) t = from[full * 16u + (uint32_t)lane];
+        if ((uint32_t)lane < full) *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = v;
+        if ((uint32_t)lane < r) ring[dp + full * 16u + (uint32_t)lane] = (uint8_t)t;
+        wave_lds_sync();
+    };
+    auto copy_match = [&](uint32_t offset, uint32_t ml) {
+        SQY_DST(const uint64_t cm0 = __builtin_amdgcn_s_memtime();)
+        if (DEC_RING < 65536u && offset > DEC_RING) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint8_t* const gsrc = out + frame_out;
+            for (uint32_t j = 0; j < ml;) {
+                const uint32_t dp = pos & (DEC_RING - 1);
+                uint32_t cnt = ml - j < 1024u ? ml - j : 1024u;
+                cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
+                if (j + cnt + 2048u > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                const uint32_t full = cnt >> 4, r = cnt & 15u;
+                const uint8_t* const g = gsrc + (pos - offset);
+                uint4 v = make_uint4(0, 0, 0, 0);
+                uint32_t t = 0;
+                if ((uint32_t)lane < full) v = ld_u128_agent(g + (uint32_t)lane * 16u);
+                if ((uint32_t)lane < r) t = __hip_atomic_load(g + full * 16u + (uint32_t)lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if ((uint32_t)lane < full) { const v4u_any vv = {v.x, v.y, v.z, v.w}; *reinterpret_cast<SQY_LDS v4u_any*>(ring + dp + (uint32_t)lane * 16u) = vv; }
+                if ((uint32_t)lane < r) ring[dp + full * 16u + (uint32_t)lane] = (uint8_t)t;
+                wave_lds_sync();
+                pos += cnt;
+                j += cnt;
+                flush(false);
+            }
+            SQY_DST(++ct_far; ct_cfar += __builtin_amdgcn_s_memtime() - cm0;)
+            return;
+        }
+        if (ml <= 64u) {
+            uint32_t lm = (uint32_t)lane;
+            if (offset < 64u && offset < ml) lm = (uint32_t)lane % offset;    // (a branch: the division is forty instructions)
+            uint32_t v = 0;
+            if ((uint32_t)lane < ml) v = ring[(pos - offset + lm) & (DEC_RING - 1)];
+            if ((uint32_t)lane < ml) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+            wave_lds_sync();
+            pos += ml;
+            flush(false);
+            SQY_DST(++ct_short; ct_cshort += __builtin_amdgcn_s_memtime() - cm0;)
+            return;
+        }
+        uint32_t rem = ml, period = offset;
+        if (offset < 64u) {
+            const uint32_t lm = (uint32_t)lane % offset;
+            const uint32_t v = ring[(pos - offset + lm) & (DEC_RING - 1)];
+            ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
+            wave_lds_sync();
+            pos += 64u;
+            rem -= 64u;
+            flush(false);
+            period = ((64u + offset) / offset) * offset;
+        }
+        while (rem) {
+            const uint32_t sp = (pos - period) & (DEC_RING - 1), dp = pos & (DEC_RING - 1);
+            uint32_t cnt = rem < 1024u ? rem : 1024u;
+            cnt = cnt < period ? cnt : period;
+            cnt = cnt < DEC_RING - sp ? cnt : DEC_RING - sp;
+            cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
+            wide_copy(ring + sp, dp, cnt);
+            pos += cnt;
+            rem -= cnt;
+            flush(false);
+            if (cnt == period && period < 1024u) period <<= 1;
+        }
+        SQY_DST(++ct_long; ct_clong += __builtin_amdgcn_s_memtime() - cm0;)
+    };
+
+    for (uint32_t taken = 0; !bad;) {
+        bool timed_out = false;
+        SQY_DST(const uint64_t w0 = __builtin_amdgcn_s_memtime();)
+        for (uint32_t spin = 0; ctrl[0] == taken; ++spin) {
+            if (ctrl[2] || spin >= SPIN) { timed_out = true; break; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        SQY_DST(ct_wait += __builtin_amdgcn_s_memtime() - w0; ++ct_units;)
+        if (timed_out) { bad = true; break; }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint32_t meta = ctrl[4u + (taken & 1u)];
+        const uint32_t m = meta & 0xffu, flags = meta >> 8;
+        v4u rec = {0, 0, 0, 0};
+        if ((uint32_t)lane < m) rec = *reinterpret_cast<const SQY_LDS v4u*>(units + (taken & 1u) * DEC2_UNIT + (uint32_t)lane);
+        wave_lds_sync();
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        ++taken;
+        if (lane == 0) ctrl[1] = taken;                            // the slot is wave 0's again
+        if (flags & 2u) { bad = true; break; }
+#ifdef SQY_DEC_INERT
+        if (flags & 1u) break;
+        continue;
+#endif
+        if (m) {
+            SQY_DST(const uint64_t u0 = __builtin_amdgcn_s_memtime();)
+            // (up to four literals travel in the record itself, rec.x, instead of their place in the block: no read of the stage for them)
+            const uint32_t lip = rec.x, lit = rec.y & 0x7fffffffu, inl = rec.y >> 31, off = rec.z, mlen = rec.w;
+            const uint32_t len = lit + mlen;                       // (lanes >= m: 0)
+            uint32_t inc = len;
+            inc += __builtin_amdgcn_update_dpp(0u, inc, 0x111, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0u, inc, 0x112, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0u, inc, 0x114, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0u, inc, 0x118, 0xf, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0u, inc, 0x142, 0xa, 0xf, false);
+            inc += __builtin_amdgcn_update_dpp(0u, inc, 0x143, 0xc, 0xf, false);
+            const uint32_t total = lane_read(inc, 63);
+            const uint32_t rel = inc - len;
+            const uint32_t base = pos;
+            // (64 sequences of up to sz literals and 2^20-ish match bytes each: no 32-bit overflow below -- lit <= sz < 2^23, mlen < 2^23)
+            const bool wrong = (uint32_t)lane < m && (lit > 0x7fffffu || mlen > 0x7fffffu || (mlen && (off == 0u || off > base + rel + lit)));
+            if (ballot(wrong) || (uint64_t)base + total > block_bytes) { bad = true; break; }
+            // the literals that are NOT in their records: from the first to the last of them in the block (they lie in order)
+            const uint64_t staged = ballot((uint32_t)lane < m && !inl && lit > 0u);
+            const uint32_t lip0 = staged ? lane_read(lip, ctz64(staged)) : 0u;
+            const uint32_t lend = staged ? lane_read(lip + lit, 63u - (uint32_t)__builtin_clzll(staged)) : 0u;
+            const bool any_inl = ballot((uint32_t)lane < m && inl && lit > 0u) != 0ull;
+            // (a round of 64 output bytes costs about as much as one and a half sequences taken on their own: rounds below 32 bytes a sequence)
+            if (total < 32u * m && total < 4096u && lend - lip0 <= DEC_IN - 32u) {
+                // short sequences: the unit's output 64 bytes per step, one byte per lane (see the kernel above)
+                if (lend > lip0) need(lip0, lend - lip0);
+                const uint32_t inf = lit | (inl << 15) | (off << 16), rl = rel | ((inl ? 0u : lip - lip0) << 12);
+                uint32_t carry = 0;
+                for (uint32_t r0 = 0; r0 < total; r0 += 64u) {
+                    const uint32_t q = r0 + (uint32_t)lane;
+                    owner_mark[lane] = 0;
+                    wave_lds_sync();
+                    if ((uint32_t)lane < m && len && rel - r0 < 64u) owner_mark[rel - r0] = (uint8_t)(lane + 1);
+                    wave_lds_sync();
+                    uint32_t mx = owner_mark[lane];
+                    if (lane == 0 && mx == 0u) mx = carry;
+                    {
+                        uint32_t t;
+                        t = __builtin_amdgcn_update_dpp(0u, mx, 0x111, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                        t = __builtin_amdgcn_update_dpp(0u, mx, 0x112, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                        t = __builtin_amdgcn_update_dpp(0u, mx, 0x114, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                        t = __builtin_amdgcn_update_dpp(0u, mx, 0x118, 0xf, 0xf, false); mx = mx > t ? mx : t;
+                        t = __builtin_amdgcn_update_dpp(0u, mx, 0x142, 0xa, 0xf, false); mx = mx > t ? mx : t;
+                        t = __builtin_amdgcn_update_dpp(0u, mx, 0x143, 0xc, 0xf, false); mx = mx > t ? mx : t;
+                    }
+                    carry = lane_read(mx, 63);
+                    const uint32_t s_of = mx - 1u;
+                    const uint32_t inf_s = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_of * 4u), (int)inf);
+                    const uint32_t rl_s = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_of * 4u), (int)rl);
+                    uint32_t x_s = 0;
+                    if (any_inl) x_s = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(s_of * 4u), (int)lip);
+                    const uint32_t k = q - (rl_s & 0xfffu), fl = inf_s & 0x7fffu, o = inf_s >> 16;
+                    const bool inl_s = (inf_s >> 15) & 1u;
+                    const bool active = q < total;
+                    const bool is_lit = k < fl;
+                    const uint32_t roundpos = base + r0;
+                    const uint32_t P = base + q - o;
+                    const bool in_step = active && !is_lit && P >= roundpos;
+                    uint32_t val = 0;
+                    if (active && is_lit && inl_s) val = (x_s >> (8u * (k & 3u))) & 0xffu;
+                    if (active && is_lit && !inl_s) val = stage[lip0 - sbase + (rl_s >> 12) + k];
+                    if (DEC_RING < 65536u) {
+                        const bool far = active && !is_lit && o > DEC_RING;
+                        if (ballot(far)) {
+                            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                            if (far) val = __hip_atomic_load(out + frame_out + P, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                        if (active && !is_lit && !in_step && !far) val = ring[P & (DEC_RING - 1)];
+                    } else {
+                        if (active && !is_lit && !in_step) val = ring[P & (DEC_RING - 1)];
+                    }
+                    bool has = !in_step;
+                    uint32_t dep = in_step ? P - roundpos : (uint32_t)lane;
+                    while (ballot(!has)) {
+                        const uint32_t g = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(dep * 4u), (int)((has ? 0x80000000u : 0u) | (dep << 8) | val));
+                        if (!has) {
+                            if (g >> 31) { val = g & 0xffu; has = true; }
+                            else dep = (g >> 8) & 63u;
+                        }
+                    }
+                    if (active) ring[(roundpos + (uint32_t)lane) & (DEC_RING - 1)] = (uint8_t)val;
+                    wave_lds_sync();
+                    pos = roundpos + (total - r0 < 64u ? total - r0 : 64u);
+                    flush(false);
+                    SQY_DST(++ct_rounds;)
+                }
+                SQY_DST(++ct_runits; ct_cr += __builtin_amdgcn_s_memtime() - u0;)
+            } else {
+                // one sequence after the other
+                for (uint32_t i = 0; i < m && !bad; ++i) {
+                    const uint32_t l = lane_read(lit, i), lp = lane_read(lip, i), o = lane_read(off, i), mln = lane_read(mlen, i);
+                    if (l && lane_read(inl, i)) {
+                        // the literals out of the record: a write, no read (and the match's read behind it sees it: one wave's LDS
+                        // operations keep their order)
+                        if ((uint32_t)lane < l) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)(lp >> (8u * ((uint32_t)lane & 3u)));
+                        wave_lds_sync();
+                        pos += l;
+                        if (!mln) flush(false);
+                    } else if (l) {
+                        if (l <= DEC_IN - 64u) {
+                            need(lp, l);
+                            for (uint32_t j = 0; j < l;) {
+                                const uint32_t dp = pos & (DEC_RING - 1);
+                                uint32_t cnt = l - j < 1024u ? l - j : 1024u;
+                                cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
+                                wide_copy(stage + (lp - sbase + j), dp, cnt);
+                                pos += cnt;
+                                j += cnt;
+                                flush(false);
+                            }
+                        } else {
+                            for (uint32_t j = 0; j < l; j += 64) {                // a long literal run: stream -> ring
+                                const uint32_t cnt = l - j < 64 ? l - j : 64;
+                                if ((uint32_t)lane < cnt) ring[(pos + lane) & (DEC_RING - 1)] = src[lp + j + lane];
+                                wave_lds_sync();
+                                pos += cnt;
+                                flush(false);
+                            }
+                        }
+                    }
+                    if (mln) copy_match(o, mln);
+                }
+                SQY_DST(ct_seqs += m; ct_ci += __builtin_amdgcn_s_memtime() - u0;)
+            }
+        }
+        if (flags & 1u) break;
+    }
+    flush(true);
+    if ((uint64_t)pos != expect) bad = true;
+    if (bad) {
+        if (lane == 0) { ctrl[2] = 1u; atomicExch(errflag, 1u); }
+    }
+    SQY_DST(if (lane == 0 && frame_out + 512 <= out_bytes) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint64_t* cs = reinterpret_cast<uint64_t*>(out + frame_out) + 16;
+        cs[0] = __builtin_amdgcn_s_memtime() - ct_t0; cs[1] = ct_units; cs[2] = ct_wait; cs[3] = ct_runits; cs[4] = ct_rounds; cs[5] = ct_cr; cs[6] = ct_seqs; cs[7] = ct_ci;
+        cs[8] = ct_fill; cs[9] = ct_nflush; cs[10] = ct_flush; cs[11] = ct_short; cs[12] = ct_cshort; cs[13] = ct_long; cs[14] = ct_clong; cs[15] = ct_far;
+        cs[16] = ct_cfar;
+    })
+}
+
+template <uint32_t DEC_RING>
+__global__ __launch_bounds__(128)
+void lz4_frames_decode2_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
+                               uint8_t* __restrict__ out, uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes,
+                               uint32_t* __restrict__ errflag, const uint64_t* __restrict__ remap, uint64_t remap_bytes)
+{
+    constexpr uint32_t DEC_IN = 3072u;
+    __shared__ __attribute__((aligned(16))) uint8_t d2_raw[DEC_RING + DEC_IN + DEC2_PIN + 64 + 2 * DEC2_UNIT * 16 + 32 + 32];
+    lds_u8* ring = (lds_u8*)d2_raw;
+    lds_u8* stage = (lds_u8*)d2_raw + DEC_RING;                                     // wave 1: the literals come from here
+    lds_u8* pstage = (lds_u8*)d2_raw + DEC_RING + DEC_IN;                           // wave 0: tokens, lengths, offsets
+    lds_u8* owner_mark = (lds_u8*)d2_raw + DEC_RING + DEC_IN + DEC2_PIN + 32;
+    SQY_LDS uint4* units = reinterpret_cast<SQY_LDS uint4*>((lds_u8*)d2_raw + DEC_RING + DEC_IN + DEC2_PIN + 32 + 64);
+    volatile SQY_LDS uint32_t* ctrl = reinterpret_cast<volatile SQY_LDS uint32_t*>((lds_u8*)d2_raw + DEC_RING + DEC_IN + DEC2_PIN + 32 + 64 + 2 * DEC2_UNIT * 16);
+    // ctrl[0] units published, [1] units taken, [2] stop, [4 + s] slot s: sequences | flags << 8 (1 = the frame's last unit, 2 = damaged)
+    const int lane = threadIdx.x & 63;
+    const uint32_t role = sgpr(threadIdx.x >> 6);
+    const uint32_t f = blockIdx.x;
+    const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
+    if (threadIdx.x < 8) ctrl[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t frame_out = lz4_decode_frame_out((uint64_t)f * frame_stride, remap, remap_bytes);
+    const uint64_t room = frame_out < out_bytes ? out_bytes - frame_out : 0;
+    const uint64_t expect = remap ? frame_stride : (gridDim.x == 1 || room < frame_stride) ? room : frame_stride;
+    if (b1 - b0 != 1) {                                       // (the host sends such streams to the other kernel)
+        if (threadIdx.x == 0) atomicExch(errflag, 1u);
+        return;
+    }
+    const uint4 e = blk[b0];
+    const uint8_t* __restrict__ src = in + (((uint64_t)e.y << 32) | e.x);
+    const uint32_t sz = e.z & 0x7fffffffu;
+    if (e.z >> 31) {
+        // a stored frame: lz4_stored_frames_copy_kernel moves it, this kernel only vouches for the bounds
+        if (threadIdx.x == 0 && (frame_out + sz > out_bytes || (uint64_t)sz != expect || (uint64_t)sz > block_bytes)) atomicExch(errflag, 1u);
+        return;
+    }
+    uint64_t* stats = nullptr;
+    SQY_DST(if (frame_out + 512 <= out_bytes) stats = reinterpret_cast<uint64_t*>(out + frame_out);)
+    if (role == 0) lz4_decode2_parse(src, sz, pstage, units, ctrl, lane, stats);
+    else lz4_decode2_copy<DEC_RING>(src, sz, out, frame_out, out_bytes, block_bytes, expect, ring, stage, owner_mark, units, ctrl, errflag, lane);
 }
 
 // stored (uncompressed) blocks of single-block frames: plain copy stream -> output, one workgroup per 32 KiB slice
@@ -5366,7 +5983,7 @@ constexpr uint32_t SQY_RING8_MIN = 2560;
 hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const uint32_t* frame_first, uint32_t nframes, uint8_t* out,
                                     uint64_t out_bytes, uint64_t frame_stride, uint64_t block_bytes, uint32_t ncompressed,
                                     uint32_t* errflag, hipStream_t stream, hipStream_t copy_stream, hipEvent_t fork, hipEvent_t join,
-                                    const uint64_t* remap, uint64_t remap_bytes)
+                                    const uint64_t* remap, uint64_t remap_bytes, bool two_waves)
 {
     if (nframes == 0) return hipSuccess;
     // (remap: frame f goes to remap[f * stride / remap_bytes] * remap_bytes + the rest -- whole chunks inside whole shuffle frames only)
@@ -5387,6 +6004,16 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     // occupancy wins; below that the frames are few and long, and every match served from LDS wins
     // (round 4) more compressed frames than even the 16 KiB-ring kernel keeps resident (8 per CU) plus a quarter: the 8 KiB ring's 13 waves
     // per CU win although more matches reach behind the ring -- the C3 slab's 3584 frames 3.37 -> 2.65 ms (a 4 KiB ring: no better)
+    // (round 5) frames of one block, few enough for every one of them to be resident: two wavefronts per frame, one finds out what the
+    // sequences are, the other moves the bytes (lz4_frames_decode2_kernel)
+    if (two_waves && !(ncompressed > SQY_RING8_MIN && nframes > SQY_RING8_MIN)) {
+        if (ncompressed > 768u && nframes > 768u)
+            hipLaunchKernelGGL(lz4_frames_decode2_kernel<16384>, dim3(nframes), dim3(128), 0, stream, in, (const uint4*)blk, frame_first, out,
+                               out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);
+        else
+            hipLaunchKernelGGL(lz4_frames_decode2_kernel<65536>, dim3(nframes), dim3(128), 0, stream, in, (const uint4*)blk, frame_first, out,
+                               out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);
+    } else
     if (ncompressed > SQY_RING8_MIN && nframes > SQY_RING8_MIN)
         hipLaunchKernelGGL(lz4_frames_decode_kernel<8192>, dim3(nframes), dim3(64), 0, stream, in, (const uint4*)blk, frame_first, out,
                            out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);
