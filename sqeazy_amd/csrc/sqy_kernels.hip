@@ -3439,8 +3439,20 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
     bool bad = false;
 
     auto flush = [&](bool all) {
-        // write ring bytes [flushed, pos) (all) or the whole KiB pieces of it
-        while (flushed + 1024u <= pos || (all && flushed < pos)) {
+        // write ring bytes [flushed, pos) (all) or whole pieces of 4 KiB of it (round 5: four reads of the ring in flight, then four stores;
+        // before, a KiB per call, each behind its own LDS round trip.  What has not left yet stays inside the ring -- a step adds at most
+        // 1 KiB, the smallest ring has 8 --, and a match that reaches behind the ring ends more than 7 KiB back: flushed)
+        while (flushed + 4096u <= pos) {
+            const uint64_t o = frame_out + flushed;
+            if (o + 4096u > out_bytes) { bad = true; flushed = pos; break; }
+            v4u v[4];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const SQY_LDS v4u*>(ring + ((flushed + q * 1024u + (uint32_t)lane * 16u) & (DEC_RING - 1)));
+#pragma unroll
+            for (uint32_t q = 0; q < 4; ++q) st_u128(out + o + q * 1024u + (uint32_t)lane * 16u, make_uint4(v[q].x, v[q].y, v[q].z, v[q].w));
+            flushed += 4096u;
+        }
+        while (all && flushed < pos) {
             const uint32_t cnt = (pos - flushed >= 1024u) ? 1024u : (pos - flushed);
             const uint64_t o = frame_out + flushed;
             if (o + cnt > out_bytes) { bad = true; flushed = pos; break; }
@@ -3571,7 +3583,8 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
             // step that uses it up (byte p equals byte p - offset, hence p - period) --, so its source ends where its destination
             // begins and all reads come before the writes: one LDS round trip per step.
             if (ml <= 64u) {
-                const uint32_t lm = (offset >= 64u || offset >= ml) ? (uint32_t)lane : (uint32_t)lane % offset;
+                uint32_t lm = (uint32_t)lane;
+                if (offset < 64u && offset < ml) lm = (uint32_t)lane % offset;    // (a branch: the division is forty instructions)
                 uint32_t v = 0;
                 if ((uint32_t)lane < ml) v = ring[(pos - offset + lm) & (DEC_RING - 1)];
                 if ((uint32_t)lane < ml) ring[(pos + lane) & (DEC_RING - 1)] = (uint8_t)v;
@@ -4090,6 +4103,7 @@ __device__ __noinline__ void lz4_decode2_parse(const uint8_t* __restrict__ src, 
                 if (stopped) break;
             }
             need(ip, 96);
+            // (both fields behind ONE read of 24 bytes per lane, picked out of registers: measured, 3.7 -> 4.4 ms on the quantised stack)
             const uint32_t wi = (ip + (uint32_t)lane) & (PR - 1u);
             const uint32_t tokb = pstage[wi];
             const uint32_t flit = tokb >> 4, fml = tokb & 15u;
@@ -6007,6 +6021,8 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     // (round 5) frames of one block, few enough for every one of them to be resident: two wavefronts per frame, one finds out what the
     // sequences are, the other moves the bytes (lz4_frames_decode2_kernel)
     if (two_waves && !(ncompressed > SQY_RING8_MIN && nframes > SQY_RING8_MIN)) {
+        // (a 32 KiB ring here would serve nine in ten of the matches that reach behind 16 KiB -- a seventh of the bench stack's -- out of
+        // LDS, but only three frames fit a CU then: measured, 0.63 -> 0.73 ms)
         if (ncompressed > 768u && nframes > 768u)
             hipLaunchKernelGGL(lz4_frames_decode2_kernel<16384>, dim3(nframes), dim3(128), 0, stream, in, (const uint4*)blk, frame_first, out,
                                out_bytes, frame_stride, block_bytes, errflag, remap, remap_bytes);

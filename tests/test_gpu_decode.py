@@ -621,3 +621,79 @@ def test_handmade_sequences_chunked_layout(sqy, oracle, nframes):
     assert np.array_equal(oracle.pipeline_decode(blob).reshape(-1), want)
     rc, back = sqy.decode(blob)
     assert rc == 0 and np.array_equal(back.reshape(-1), want)
+
+
+# ---- the chunked layout decoded by two wavefronts per frame (round 5) -----------------------------------------------------------------
+# Frames of one block are decoded by lz4_frames_decode2_kernel: wave 0 parses the compressed bytes into units of up to 64 sequences, wave 1
+# moves the bytes.  "decode_two_waves" = 0 sends the same blobs through the one-wavefront kernel (which also takes multi-block frames and
+# the streams with more than 2560 compressed frames): both have to give the volume back, whatever the sequences look like -- streams of
+# three-byte sequences (units taken 64 bytes a round), matches of a KiB and more (one after the other), chunks of zeros (a thousand length
+# bytes in a row), literals of every length around the 4 that travel inside a record and the 3008 that fit the stage, matches behind the
+# 16 KiB ring, the parser's stage running dry in the middle of a header, hand-made sequences on every boundary.
+def _two_wave_streams(n, seed):
+    rng = np.random.default_rng(seed)
+    yield "zeros", np.zeros(n, np.uint8)
+    yield "noise2bit", rng.integers(0, 4, n, dtype=np.uint8)                      # short sequences throughout
+    a = np.zeros(n, np.uint8)
+    idx = rng.integers(0, n, n // 200)
+    a[idx] = rng.integers(1, 256, idx.size)
+    yield "sparse", a                                                              # a few literals, long matches
+    b = rng.integers(0, 256, n, dtype=np.uint8)
+    pos = 5000
+    while pos < n - 9000:                                                           # literal runs of 0 .. 9000 bytes between copies from near and far
+        ln = int(rng.integers(4, 600))
+        back = int(rng.integers(1, min(pos, 65535)))
+        b[pos:pos + ln] = b[pos - back:pos - back + ln]
+        pos += ln + int(rng.choice([0, 1, 2, 3, 4, 5, 14, 15, 16, 270, 3000, 3008, 3009, 4500, 9000]))
+    yield "literal_runs", b
+    c = np.repeat(rng.integers(0, 256, n // 700 + 1, dtype=np.uint8), 700)[:n].copy()
+    c[::997] ^= 1
+    yield "runs", c                                                                 # offset 1, matches of hundreds of bytes
+    d = np.tile(rng.integers(0, 256, 20000, dtype=np.uint8), n // 20000 + 1)[:n].copy()
+    d[rng.integers(0, n, n // 300)] ^= 0x55
+    yield "period20000", d                                                          # every match behind the 16 KiB ring
+    e = synth.stack((n // (64 * 64), 64, 64), np.uint8).reshape(-1)
+    yield "stack8", np.resize(e, n)
+
+
+@pytest.mark.parametrize("nframes,cfg", [(5, ""), (40, "(blocksize_kb=64,framestep_kb=64)"), (900, "(blocksize_kb=64,framestep_kb=64)")])
+@pytest.mark.parametrize("name", [s[0] for s in _two_wave_streams(1 << 16, 0)])
+def test_chunked_layout_two_wavefronts_and_one_agree(sqy, oracle, options, name, nframes, cfg):
+    chunk = (64 << 10) if cfg else (256 << 10)
+    n = nframes * chunk - 12345
+    data = dict(_two_wave_streams(n, 77))[name]
+    vol = data.reshape(1, 1, -1)
+    blob = oracle.pipeline_encode("lz4" + cfg, vol, nthreads=2)
+    for two in (1, 0):
+        options("decode_two_waves", two)
+        sqy.profile_reset(); sqy.profile_enable(True)
+        rc, back = sqy.decode(blob)
+        sqy.profile_enable(False)
+        assert rc == 0, (name, two)
+        assert np.array_equal(back.reshape(-1), data), (name, two)
+
+
+def test_chunked_layout_two_wavefronts_damaged_blocks(sqy, oracle, options):
+    """bytes of a compressed block overwritten (tokens, offsets, length bytes): either kernel refuses or gives different bytes, neither hangs
+    nor writes outside the volume (the byte behind it stays as it was)"""
+    rng = np.random.default_rng(5)
+    n = 6 * (256 << 10)
+    data = dict(_two_wave_streams(n, 3))["literal_runs"]
+    blob = oracle.pipeline_encode("lz4", data.reshape(1, 1, -1), nthreads=2)
+    h = oracle.header_unpack(blob)
+    for trial in range(12):
+        bad = bytearray(blob)
+        at = h["size"] + 11 + int(rng.integers(0, len(blob) - h["size"] - 64))
+        kind = trial % 4
+        if kind == 0:
+            bad[at] = 0xFF                                   # a token that promises 15+ literals and a 19+ match
+        elif kind == 1:
+            bad[at:at + 2] = b"\x00\x00"                     # an offset of zero, if it lands on one
+        elif kind == 2:
+            bad[at:at + 40] = b"\xff" * 40                   # a run of length bytes
+        else:
+            bad[at:at + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8))
+        for two in (1, 0):
+            options("decode_two_waves", two)
+            rc, back = sqy.decode(bytes(bad))
+            assert rc != 0 or back.size == data.size

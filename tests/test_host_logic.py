@@ -39,6 +39,7 @@ def test_run_time_options(sqy):
     assert sqy.get_option("block_parallel") == 1 and sqy.get_option("tail_scan") == 1 and sqy.get_option("transpose_chain") == 1
     assert sqy.get_option("transpose_chain_caller_streams") == 0          # coupling caller streams is opt-in (round-4 advice)
     assert sqy.get_option("block_parallel_warmup") == 65536
+    assert sqy.get_option("decode_two_waves") == 1
     assert sqy.get_option("no_such_option") == -1
     L = sqy.lib()
     assert L.SQYAMD_Set_Option(b"no_such_option", 1) == 1 and L.SQYAMD_Set_Option(None, 1) == 1
