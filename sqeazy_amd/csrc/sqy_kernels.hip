@@ -6020,6 +6020,8 @@ hipError_t launch_lz4_frames_decode(const uint8_t* in, const void* blk, const ui
     // per CU win although more matches reach behind the ring -- the C3 slab's 3584 frames 3.37 -> 2.65 ms (a 4 KiB ring: no better)
     // (round 5) frames of one block, few enough for every one of them to be resident: two wavefronts per frame, one finds out what the
     // sequences are, the other moves the bytes (lz4_frames_decode2_kernel)
+    // (not beyond that: the C3 slab's 3584 frames through two waves each, 8 KiB ring, take 7.1 ms against 2.6 -- that range is bound by the
+    // instructions issued, and two waves issue more of them)
     if (two_waves && !(ncompressed > SQY_RING8_MIN && nframes > SQY_RING8_MIN)) {
         // (a 32 KiB ring here would serve nine in ten of the matches that reach behind 16 KiB -- a seventh of the bench stack's -- out of
         // LDS, but only three frames fit a CU then: measured, 0.63 -> 0.73 ms)
