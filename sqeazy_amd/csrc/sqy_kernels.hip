@@ -4714,6 +4714,24 @@ void lz4_blocks_decode_sym_kernel(const uint8_t* __restrict__ in, const uint4* _
     };
     auto need = [&](uint32_t at, uint32_t cnt) { if (at < sbase || at + cnt > shi) fill(at); };   // cnt <= SYM_IN - 16, at + cnt <= sz
     auto sbyte_at = [&](uint32_t at) -> uint32_t { return stage[at - sbase]; };
+    // a run of length-extension bytes from `at` on, 64 bytes per LDS round trip (round 5; see ext_run in lz4_frames_decode_kernel)
+    auto ext_run = [&](uint32_t& at, uint32_t& acc) -> bool {
+        for (;;) {
+            if (at >= sz) return false;
+            const uint32_t cnt = sz - at < 64u ? sz - at : 64u;
+            need(at, cnt);
+            const uint32_t bv = (uint32_t)lane < cnt ? (uint32_t)stage[at - sbase + (uint32_t)lane] : 0u;
+            const uint64_t closing = ballot((uint32_t)lane < cnt && bv != 255u);
+            if (closing) {
+                const uint32_t k = ctz64(closing);
+                acc += 255u * k + lane_read(bv, k);
+                at += k + 1u;
+                return true;
+            }
+            acc += 255u * cnt;
+            at += cnt;
+        }
+    };
     // 16 window bytes at block offset `at` (inside the stage) as four scalars
     auto window = [&](uint32_t at) -> uint4 {
         const uint32_t a = at - sbase, sh = a & 3u;
@@ -4872,13 +4890,7 @@ void lz4_blocks_decode_sym_kernel(const uint8_t* __restrict__ in, const uint4* _
             lit_ok = lit < 15u;
         }
         uint32_t ipl = ip + used;
-        while (!lit_ok) {
-            if (ipl >= sz) { bad = true; break; }
-            need(ipl, 1);
-            const uint32_t sb = sbyte_at(ipl++);
-            lit += sb;
-            lit_ok = sb != 255u;
-        }
+        if (!lit_ok && !ext_run(ipl, lit)) bad = true;
         if (bad || ipl + lit > sz || pos + lit > expect) { bad = true; break; }
         const bool second_window = lit <= SYM_IN - 128u && ipl + lit + 16u <= sz;
         uint4 xw = make_uint4(0, 0, 0, 0);
@@ -4918,13 +4930,7 @@ void lz4_blocks_decode_sym_kernel(const uint8_t* __restrict__ in, const uint4* _
             offset = sbyte_at(ip) | (sbyte_at(ip + 1u) << 8);
             ip += 2u;
         }
-        while (!ml_ok) {
-            if (ip >= sz) { bad = true; break; }
-            need(ip, 1);
-            const uint32_t sb = sbyte_at(ip++);
-            ml += sb;
-            ml_ok = sb != 255u;
-        }
+        if (!ml_ok && !ext_run(ip, ml)) bad = true;
         ml += 4u;
         if (bad || offset == 0u || offset > pos + reach || pos + ml > expect) { bad = true; break; }
         copy_match(offset, ml);
