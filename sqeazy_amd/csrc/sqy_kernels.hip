@@ -5261,48 +5261,73 @@ void bitswap1_u8_decode_lut_kernel(const uint8_t* __restrict__ in, uint16_t* __r
                                    const uint16_t* __restrict__ lut)
 {
     __shared__ uint16_t sl[256];
+    __shared__ __attribute__((aligned(16))) uint8_t xch[4][16384];     // a wave's 16 KiB of output, so that it leaves 1 KiB per store instruction
     sl[threadIdx.x] = lut[threadIdx.x];
     __syncthreads();
-    for (uint64_t v = (uint64_t)blockIdx.x * 256 + threadIdx.x; v < nvec; v += (uint64_t)gridDim.x * 256) {
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    lds_u8* const xw = (lds_u8*)xch[wv];
+    for (uint64_t v0 = (uint64_t)blockIdx.x * 256 + wv * 64u; v0 < nvec; v0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t v = v0 + lane;
+        const bool mine = v < nvec;
+        if (mine) {
         uint32_t pw[8][4];                                               // pw[b] = 16 bytes of the plane that carries bit b
 #pragma unroll
         for (int b = 0; b < 8; ++b) {
             const v4u t = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(in + (uint64_t)(7 - b) * seg) + v);
             pw[b][0] = t.x; pw[b][1] = t.y; pw[b][2] = t.z; pw[b][3] = t.w;
         }
-        v4u* dst = reinterpret_cast<v4u*>(out + v * 128);
 #pragma unroll
         for (int g = 0; g < 16; ++g) {
-            // byte b of t = plane byte of bit b, voxel j at bit j after the per-byte bit reversal (stored with voxel j at bit 7-j)
-            uint64_t t = 0;
-#pragma unroll
-            for (int b = 0; b < 8; ++b) {
-                const uint32_t byte = (pw[b][g >> 2] >> (8 * (g & 3))) & 0xffu;
-                t |= (uint64_t)(__brev(byte) >> 24) << (8 * b);
-            }
-            // 8x8 bit transpose (its own inverse): byte j = voxel j
-            uint64_t y;
-            y = (t ^ (t >> 7)) & 0x00AA00AA00AA00AAull; t = t ^ y ^ (y << 7);
-            y = (t ^ (t >> 14)) & 0x0000CCCC0000CCCCull; t = t ^ y ^ (y << 14);
-            y = (t ^ (t >> 28)) & 0x00000000F0F0F0F0ull; t = t ^ y ^ (y << 28);
-            const uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+            // byte b of (hi:lo) = plane byte of bit b, as stored: voxel j at bit 7 - j.  (Round 5: the eight bytes gathered by six
+            // v_perm instead of eight extract / reverse / shift / or chains, no per-byte bit reversal -- the transpose of the
+            // unreversed bytes holds voxel j in byte 7 - j, and the look-ups simply take the bytes from the top down --, the transpose
+            // on the two 32-bit halves: ~60 instead of ~110 vector instructions per eight voxels; the kernel was bound by them.)
+            constexpr uint32_t Z = 0x0c;                                             // v_perm selector: a zero byte
+            const uint32_t c = (uint32_t)(g & 3), wdx = (uint32_t)(g >> 2);
+            const uint32_t s01 = c | ((4u + c) << 8) | (Z << 16) | (Z << 24), s23 = Z | (Z << 8) | (c << 16) | ((4u + c) << 24);
+            uint32_t lo = __builtin_amdgcn_perm(pw[1][wdx], pw[0][wdx], s01) | __builtin_amdgcn_perm(pw[3][wdx], pw[2][wdx], s23);
+            uint32_t hi = __builtin_amdgcn_perm(pw[5][wdx], pw[4][wdx], s01) | __builtin_amdgcn_perm(pw[7][wdx], pw[6][wdx], s23);
+            // 8x8 bit transpose (its own inverse) of the 64-bit word hi:lo; the first two stages stay inside a half
+            uint32_t y;
+            y = (lo ^ (lo >> 7)) & 0x00AA00AAu; lo ^= y ^ (y << 7);
+            y = (hi ^ (hi >> 7)) & 0x00AA00AAu; hi ^= y ^ (y << 7);
+            y = (lo ^ (lo >> 14)) & 0x0000CCCCu; lo ^= y ^ (y << 14);
+            y = (hi ^ (hi >> 14)) & 0x0000CCCCu; hi ^= y ^ (y << 14);
+            y = (lo ^ (hi << 4)) & 0xF0F0F0F0u; lo ^= y; hi ^= y >> 4;
+            // byte i of hi:lo = voxel 7 - i
             v4u o;
-            o.x = (uint32_t)sl[lo & 0xffu] | ((uint32_t)sl[(lo >> 8) & 0xffu] << 16);
-            o.y = (uint32_t)sl[(lo >> 16) & 0xffu] | ((uint32_t)sl[lo >> 24] << 16);
-            o.z = (uint32_t)sl[hi & 0xffu] | ((uint32_t)sl[(hi >> 8) & 0xffu] << 16);
-            o.w = (uint32_t)sl[(hi >> 16) & 0xffu] | ((uint32_t)sl[hi >> 24] << 16);
-            dst[g] = o;
+            o.x = (uint32_t)sl[hi >> 24] | ((uint32_t)sl[(hi >> 16) & 0xffu] << 16);
+            o.y = (uint32_t)sl[(hi >> 8) & 0xffu] | ((uint32_t)sl[hi & 0xffu] << 16);
+            o.z = (uint32_t)sl[lo >> 24] | ((uint32_t)sl[(lo >> 16) & 0xffu] << 16);
+            o.w = (uint32_t)sl[(lo >> 8) & 0xffu] | ((uint32_t)sl[lo & 0xffu] << 16);
+            // piece g of lane t: row t, column g ^ (t & 15) (the columns of sixteen lanes in a row differ: no bank conflict either way)
+            *reinterpret_cast<SQY_LDS v4u*>(xw + lane * 256u + (((uint32_t)g ^ (lane & 15u)) << 4)) = o;
         }
+        }
+        wave_lds_sync();
+        // the wave's 16 KiB in order: store k, lane L = piece 64 k + L = piece (L & 15) of lane 4 k + (L >> 4)
+        v4u* dst = reinterpret_cast<v4u*>(out + v0 * 128);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t t = 4u * k + (lane >> 4), g = lane & 15u;
+            const v4u o = *reinterpret_cast<const SQY_LDS v4u*>(xw + t * 256u + ((g ^ (t & 15u)) << 4));
+            if (v0 + t < nvec) dst[64u * k + lane] = o;
+        }
+        wave_lds_sync();
     }
 }
 
 // 16-bit, whole tiles of 8192 voxels: the mirror image of bitswap1_u16_regs.  A lane takes 8 consecutive words of every plane
-// (16 coalesced 1 KiB loads per wave), transposes them two groups at a time (the bit transpose is its own inverse) and writes its
-// 128 voxels as 16 x 16 B.  (The generic kernel moves 2 bytes per lane and instruction.)
+// (16 coalesced 1 KiB loads per wave), transposes them two groups at a time (the bit transpose is its own inverse) and has its
+// 128 voxels as 16 x 16 B.  Round 5: those leave through LDS, 1 KiB in a row per store instruction -- a lane storing its own 256 bytes
+// 16 at a time (sixteen-byte pieces 256 bytes apart across the wave) kept the kernel at 4.9 TB/s of read + write, the 8-bit sibling,
+// which writes two bytes for every byte it reads, at 2.8.  (The generic kernel moves 2 bytes per lane and instruction.)
 __global__ __launch_bounds__(256)
 void bitswap1_decode_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words)
 {
-    const int lane = threadIdx.x & 63;
+    __shared__ __attribute__((aligned(16))) uint8_t xch[4][16384];     // a wave's tile of output
+    const uint32_t lane = threadIdx.x & 63;
+    lds_u8* const xw = (lds_u8*)xch[threadIdx.x >> 6];
     const uint64_t wave_global = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     const uint64_t wave_stride = (uint64_t)gridDim.x * 4;
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
@@ -5313,7 +5338,8 @@ void bitswap1_decode_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restr
             const v4u t = __builtin_nontemporal_load(src + lane);
             pl[b][0] = t.x; pl[b][1] = t.y; pl[b][2] = t.z; pl[b][3] = t.w;
         }
-        v4u* dst = reinterpret_cast<v4u*>(out + tile * BSW_TILE_VOX) + lane * 16;
+        // piece g (16 bytes) of lane t: row t, column g ^ (t & 15) (the columns of sixteen lanes in a row differ: no bank conflicts)
+        auto put = [&](uint32_t g, const v4u& val) { *reinterpret_cast<SQY_LDS v4u*>(xw + lane * 256u + ((g ^ (lane & 15u)) << 4)) = val; };
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             uint32_t r[16];
@@ -5328,8 +5354,17 @@ void bitswap1_decode_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restr
             }
             const v4u a0 = {ga[0], ga[1], ga[2], ga[3]}, a1 = {ga[4], ga[5], ga[6], ga[7]};
             const v4u b0 = {gb[0], gb[1], gb[2], gb[3]}, b1 = {gb[4], gb[5], gb[6], gb[7]};
-            dst[4 * q] = a0; dst[4 * q + 1] = a1; dst[4 * q + 2] = b0; dst[4 * q + 3] = b1;
+            put(4u * q, a0); put(4u * q + 1u, a1); put(4u * q + 2u, b0); put(4u * q + 3u, b1);
         }
+        wave_lds_sync();
+        // the tile's 16 KiB in order: store k, lane L = piece 64 k + L = piece (L & 15) of lane 4 k + (L >> 4)
+        v4u* dst = reinterpret_cast<v4u*>(out + tile * BSW_TILE_VOX);
+#pragma unroll
+        for (uint32_t k = 0; k < 16; ++k) {
+            const uint32_t t = 4u * k + (lane >> 4), g = lane & 15u;
+            dst[64u * k + lane] = *reinterpret_cast<const SQY_LDS v4u*>(xw + t * 256u + ((g ^ (t & 15u)) << 4));
+        }
+        wave_lds_sync();
     }
 }
 
