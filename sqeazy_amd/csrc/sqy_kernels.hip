@@ -4209,6 +4209,7 @@ __device__ __noinline__ void lz4_decode2_parse(const uint8_t* __restrict__ src, 
         SQY_DST(++st_singles; st_cs += __builtin_amdgcn_s_memtime() - st_a;)
     }
     if (!stopped) publish(damaged ? 2u : 1u);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no half of the stage may still be on its way into LDS when this wave is gone
     SQY_DST(if (lane == 0 && stats) {
         stats[0] = __builtin_amdgcn_s_memtime() - st_t0; stats[1] = st_batches; stats[2] = st_nst; stats[3] = st_singles; stats[4] = st_cb; stats[5] = st_cs;
         stats[6] = st_pub; stats[7] = st_cp; stats[8] = sz; stats[9] = st_stall; stats[10] = st_ext;
