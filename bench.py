@@ -84,7 +84,7 @@ def measured_traffic(sha, kernel, launches_per_call):
             if j.get("library_sha256") == sha and kernel in j.get("traffic", {}):
                 # (one timing scope of the library may cover several small kernels: their names in the rocprofv3 summary)
                 alias = {"lz4_dedupe": ["lz4_dedupe_clear", "lz4_dedupe_key"], "lz4_frame_scan": ["lz4_frame_scan", "lz4_tail_marks"],
-                         "lz4_frame_gather": ["lz4_stash_raw", "lz4_frame_gather", "lz4_inplace_finish"]}
+                         "lz4_frame_gather": ["lz4_stash_raw", "lz4_frame_gather", "lz4_inplace_finish"], "lz4_inplace_tail": ["lz4_inplace_tail_fused"]}
                 per_call, missing = 0.0, []
                 for k, n in launches_per_call.items():
                     names = [x for x in alias.get(k, [k]) if x in j["traffic"]]
@@ -351,6 +351,139 @@ def secondary_configs(dev):
     return out
 
 
+class StepRunner:
+    """The step loop of the timed region: `inflight` caller threads that live as long as the run (an application's encoder threads do),
+    thread t takes steps t, t + inflight, ..; the main thread takes the finished steps IN STEP ORDER and, for N > 1, either exchanges the
+    blob sizes (sharded container) or hands the blob to the gatherer (north_star's gather to rank 0, overlapped), then gives the buffer
+    back to its thread.  Everything device- or library-specific is passed in, so that tests/test_multi_gpu_gloo.py can drive this very loop
+    under two gloo processes with the CPU oracle standing in for the encoder:
+      encode(t, b) -> (offset, bytes)      one step of caller thread t into its buffer b (two buffers per thread); raises on failure
+      blob_view(t, b, offset)              the tensor that starts at the blob inside buffer b of thread t (what the gatherer is handed)
+      exchange(nbytes, slot)               N > 1 without gather: enqueue the all_gather of this step's blob size
+      gatherer                             multi.SlabGatherer or None
+      thread_init()                        run once by every caller thread (torch.cuda.set_device)"""
+
+    def __init__(self, inflight, encode, dist_on=False, blob_view=None, exchange=None, gatherer=None, thread_init=None):
+        self.inflight, self.encode, self.dist_on = inflight, encode, dist_on
+        self.blob_view, self.exchange, self.gatherer, self.thread_init = blob_view, exchange, gatherer, thread_init
+        self.last_at = (0, 0, 0)                 # (thread, buffer, offset) of the blob of the last step taken
+        self.last_blob = [None] * inflight       # per caller thread: (buffer, offset, bytes) of the last blob it produced
+        self.job_q = [queue.Queue() for _ in range(inflight)]
+        self.callers = [threading.Thread(target=self._caller, args=(t,), daemon=True) for t in range(inflight)]
+        for th in self.callers:
+            th.start()
+
+    def _caller(self, t):
+        if self.thread_init:
+            self.thread_init()
+        inflight = self.inflight
+        while True:
+            job = self.job_q[t].get()
+            if job is None:
+                return
+            k, free_qt, done_q, stop, errors = job
+            try:
+                if free_qt is None:
+                    # one GPU, nothing consumes the blobs between the steps: the thread's steps back to back, its two buffers taking turns
+                    i = 0
+                    for s_ in range(t, k, inflight):
+                        off, n = self.encode(t, i & 1)
+                        self.last_blob[t] = (i & 1, off, n)
+                        i += 1
+                    if i:
+                        done_q.put((-3, t, self.last_blob[t][0], self.last_blob[t][2], self.last_blob[t][1]))
+                else:
+                    for s_ in range(t, k, inflight):
+                        b = free_qt.get()
+                        if b is None or stop.is_set():
+                            break
+                        off, n = self.encode(t, b)
+                        self.last_blob[t] = (b, off, n)
+                        done_q.put((s_, t, b, n, off))
+            except Exception as e:   # pragma: no cover
+                errors.append(e)
+                done_q.put((-1, t, 0, 0, 0))
+            done_q.put((-2, t, 0, 0, 0))          # this thread's share of the block is over
+
+    def run_steps(self, k, gather=False):
+        """k steps: thread t encodes steps t, t+inflight, ...; the main thread takes them in step order and either exchanges the
+        sizes (sharded container) or hands the blob to the gatherer (overlapped gather to rank 0), then recycles the buffer"""
+        inflight = self.inflight
+        done_q = queue.Queue()
+        handoff = self.dist_on                  # N > 1: the main thread takes every step's blob (size exchange / gather) before its buffer is reused
+        free_q = [queue.Queue() for _ in range(inflight)]
+        for fq in free_q:
+            fq.put(0)
+            fq.put(1)
+        errors = []
+        stop = threading.Event()
+        for t in range(inflight):
+            self.job_q[t].put((k, free_q[t] if handoff else None, done_q, stop, errors))
+        pending, nxt, last_n, finished = {}, 0, 0, 0
+        while finished < inflight:
+            s_, t, b, n, off = done_q.get()
+            if s_ == -2:
+                finished += 1
+                continue
+            if s_ == -3:                        # (one GPU) a thread's block is done: remember where its last blob sits
+                self.last_at = (t, b, off)
+                last_n = n
+                continue
+            if s_ < 0:
+                stop.set()
+                for fq in free_q:                    # wake every caller thread that waits for a buffer, then fail loudly
+                    fq.put(None)
+                continue
+            pending[s_] = (t, b, n, off)
+            while nxt in pending:
+                t2, b2, n2, off2 = pending.pop(nxt)
+                self.last_at = (t2, b2, off2)
+                if self.dist_on and gather:
+                    # posted, not waited for: the buffer goes back to its caller thread when the gather of this step is done
+                    # (the blob sits at off2 inside its buffer: frames in place)
+                    self.gatherer.post(self.blob_view(t2, b2, off2), n2, on_done=lambda q=free_q[t2], bb=b2: q.put(bb))
+                else:
+                    if self.dist_on:
+                        self.exchange(n2, nxt)      # enqueued; the closing fence waits for it
+                    free_q[t2].put(b2)
+                last_n = n2
+                nxt += 1
+        if self.dist_on and gather:
+            self.gatherer.drain()
+        if errors:
+            raise errors[0]
+        return last_n
+
+    def close(self):
+        for q in self.job_q:
+            q.put(None)
+        for th in self.callers:
+            th.join(timeout=10)
+
+
+def per_rank_rows(local_blocks, steps, world, device, device_index):
+    """every rank's own median ms per step (before / after the closing fence) and what the backend says the world is, gathered to every
+    rank: makes a first real N > 1 run readable -- a slow rank, a rank that waits at the fence, a world that is not the one asked for"""
+    import torch
+    import torch.distributed as dist
+    loc = local_blocks or [(0.0, 0.0)]
+    mine = torch.tensor([statistics.median(a for a, _ in loc) / steps * 1e3, statistics.median(b for _, b in loc) / steps * 1e3,
+                         float(device_index)], dtype=torch.float64, device=device)
+    allr = torch.zeros(world * 3, dtype=torch.float64, device=device)
+    dist.all_gather_into_tensor(allr, mine)
+    rows = allr.reshape(world, 3).tolist()
+    return {"ms_per_step_own": [round(r[0], 4) for r in rows], "ms_per_step_fenced": [round(r[1], 4) for r in rows],
+            "device_index": [int(r[2]) for r in rows], "world_size_rccl": int(dist.get_world_size()), "backend": dist.get_backend(),
+            "world_size_env": int(os.environ.get("WORLD_SIZE", "1"))}
+
+
+def gather_stats_delta(g0, g1):
+    """what the gather thread did between two snapshots of SlabGatherer.stats"""
+    ng = max(g1["gathers"] - g0["gathers"], 1)
+    return {"gathers_timed": g1["gathers"] - g0["gathers"], "bytes_gathered_per_step": int((g1["bytes"] - g0["bytes"]) / ng),
+            "gather_ms_per_step": round((g1["seconds"] - g0["seconds"]) / ng * 1e3, 4)}
+
+
 def spawn_ranks(n, argv):
     """--gpus N without a launcher: start the N ranks as a torchrun child (nothing in this process has touched the GPU yet)"""
     s = socket.socket()
@@ -433,12 +566,6 @@ def main():
     gatherer = multi.SlabGatherer(world * cap, dev) if (dist_on and not args.no_gather) else None
     torch.cuda.synchronize()
 
-    last_at = [(0, 0, 0)]            # (thread, buffer, offset) of the blob of the last step taken
-    last_blob = [None] * inflight    # per caller thread: (buffer, offset, bytes) of the last blob it produced
-
-    # the caller threads live as long as the run (an application's encoder threads do); a block of steps is handed to them as a job
-    job_q = [queue.Queue() for _ in range(inflight)]
-
     # the C call of every (thread, buffer), marshalled once: what a C caller's loop looks like (no Python object is built per step)
     entry = sqeazy_amd.lib().SQYAMD_PipelineEncode_UI16_DeviceAt
     pipe_b = PIPELINE.encode()
@@ -452,94 +579,20 @@ def main():
 
     calls = [[prepared(t, b) for b in range(2)] for t in range(inflight)]
 
-    def caller(t):
-        torch.cuda.set_device(local_rank)
-        while True:
-            job = job_q[t].get()
-            if job is None:
-                return
-            k, free_qt, done_q, stop, errors = job
-            try:
-                if free_qt is None:
-                    # one GPU, nothing consumes the blobs between the steps: the thread's steps back to back, its two buffers taking turns
-                    i = 0
-                    for s_ in range(t, k, inflight):
-                        args, doff, dlen = calls[t][i & 1]
-                        rc = entry(*args)
-                        if rc:
-                            raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
-                        last_blob[t] = (i & 1, doff.value, dlen.value)
-                        i += 1
-                    if i:
-                        done_q.put((-3, t, last_blob[t][0], last_blob[t][2], last_blob[t][1]))
-                else:
-                    for s_ in range(t, k, inflight):
-                        b = free_qt.get()
-                        if b is None or stop.is_set():
-                            break
-                        args, doff, dlen = calls[t][b]
-                        rc = entry(*args)
-                        if rc:
-                            raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
-                        off, n = doff.value, dlen.value
-                        last_blob[t] = (b, off, n)
-                        done_q.put((s_, t, b, n, off))
-            except Exception as e:   # pragma: no cover
-                errors.append(e)
-                done_q.put((-1, t, 0, 0, 0))
-            done_q.put((-2, t, 0, 0, 0))          # this thread's share of the block is over
+    def encode_step(t, b):
+        args, doff, dlen = calls[t][b]
+        rc = entry(*args)
+        if rc:
+            raise RuntimeError("SQYAMD_PipelineEncode_UI16_DeviceAt returned %d" % rc)
+        return doff.value, dlen.value
 
-    callers = [threading.Thread(target=caller, args=(t,), daemon=True) for t in range(inflight)]
-    for th in callers:
-        th.start()
-
-    def run_steps(k, gather=False):
-        """k steps: thread t encodes steps t, t+inflight, ...; the main thread takes them in step order and either exchanges the
-        sizes (sharded container) or hands the blob to the gatherer (overlapped gather to rank 0), then recycles the buffer"""
-        done_q = queue.Queue()
-        handoff = dist_on                       # N > 1: the main thread takes every step's blob (size exchange / gather) before its buffer is reused
-        free_q = [queue.Queue() for _ in range(inflight)]
-        for fq in free_q:
-            fq.put(0)
-            fq.put(1)
-        errors = []
-        stop = threading.Event()
-        for t in range(inflight):
-            job_q[t].put((k, free_q[t] if handoff else None, done_q, stop, errors))
-        pending, nxt, last_n, finished = {}, 0, 0, 0
-        while finished < inflight:
-            s_, t, b, n, off = done_q.get()
-            if s_ == -2:
-                finished += 1
-                continue
-            if s_ == -3:                        # (one GPU) a thread's block is done: remember where its last blob sits
-                last_at[0] = (t, b, off)
-                last_n = n
-                continue
-            if s_ < 0:
-                stop.set()
-                for fq in free_q:                    # wake every caller thread that waits for a buffer, then fail loudly
-                    fq.put(None)
-                continue
-            pending[s_] = (t, b, n, off)
-            while nxt in pending:
-                t2, b2, n2, off2 = pending.pop(nxt)
-                last_at[0] = (t2, b2, off2)
-                if dist_on and gather:
-                    # posted, not waited for: the buffer goes back to its caller thread when the gather of this step is done
-                    # (the blob sits at off2 inside its buffer: frames in place)
-                    gatherer.post(outs[t2][b2][off2:], n2, on_done=lambda q=free_q[t2], bb=b2: q.put(bb))
-                else:
-                    if dist_on:
-                        multi.exchange_sizes(n2, dev, out=index_rows[nxt % len(index_rows)], sync=False)   # enqueued; the closing fence waits for it
-                    free_q[t2].put(b2)
-                last_n = n2
-                nxt += 1
-        if dist_on and gather:
-            gatherer.drain()
-        if errors:
-            raise errors[0]
-        return last_n
+    # the caller threads live as long as the run; a block of steps is handed to them as a job (StepRunner above: the same loop the
+    # world-size-2 gloo test drives with the CPU oracle as the encoder)
+    runner = StepRunner(inflight, encode_step, dist_on=dist_on, blob_view=lambda t, b, off: outs[t][b][off:],
+                        exchange=(lambda n, slot: multi.exchange_sizes(n, dev, out=index_rows[slot % len(index_rows)], sync=False)) if dist_on else None,
+                        gatherer=gatherer, thread_init=lambda: torch.cuda.set_device(local_rank))
+    run_steps = runner.run_steps
+    last_blob = runner.last_blob
 
     def fence():
         torch.cuda.synchronize()
@@ -570,19 +623,9 @@ def main():
     local_blocks = {}
 
     def per_rank_report(gather):
-        """every rank's own median ms per step (before / after the closing fence) and what RCCL says the world is, on rank 0's line:
-        makes a first real N > 1 run readable -- a slow rank, a rank that waits at the fence, a world that is not the one asked for"""
         if not dist_on:
             return None
-        loc = local_blocks.get(bool(gather)) or [(0.0, 0.0)]
-        mine = torch.tensor([statistics.median(a for a, _ in loc) / args.steps * 1e3, statistics.median(b for _, b in loc) / args.steps * 1e3,
-                             float(torch.cuda.current_device())], dtype=torch.float64, device=dev)
-        allr = torch.zeros(world * 3, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(allr, mine)
-        rows = allr.reshape(world, 3).tolist()
-        return {"ms_per_step_own": [round(r[0], 4) for r in rows], "ms_per_step_fenced": [round(r[1], 4) for r in rows],
-                "device_index": [int(r[2]) for r in rows], "world_size_rccl": int(dist.get_world_size()), "backend": dist.get_backend(),
-                "world_size_env": int(os.environ.get("WORLD_SIZE", "1"))}
+        return per_rank_rows(local_blocks.get(bool(gather)), args.steps, world, dev, torch.cuda.current_device())
 
     run_steps(inflight)          # untimed priming: every caller thread's context allocates its HBM workspace once
     if args.warmup:
@@ -627,10 +670,7 @@ def main():
         run_steps(max(2, inflight), True)
         g0 = dict(gatherer.stats)
         gather_times, _ = timed_blocks(True)
-        g1 = dict(gatherer.stats)
-        ng = max(g1["gathers"] - g0["gathers"], 1)
-        gather_stats = {"gathers_timed": g1["gathers"] - g0["gathers"], "bytes_gathered_per_step": int((g1["bytes"] - g0["bytes"]) / ng),
-                        "gather_ms_per_step": round((g1["seconds"] - g0["seconds"]) / ng * 1e3, 4)}
+        gather_stats = gather_stats_delta(g0, dict(gatherer.stats))
         per_rank_gather = per_rank_report(True)
 
     # other operating points of the same step, for comparison with earlier rounds (round-3 advice): fewer calls in flight, and the entry
@@ -732,10 +772,7 @@ def main():
         except Exception as e:   # reported, never required
             serial_layout = {"error": repr(e)}
     fence()
-    for q in job_q:                      # the caller threads are done
-        q.put(None)
-    for th in callers:
-        th.join()
+    runner.close()                       # the caller threads are done
 
     if rank == 0:
         dt = statistics.median(times)

@@ -266,6 +266,66 @@ def headline_serial():
     print("wrote", path)
 
 
+def _slab_volume(shape, z0, ztot, frames_per_step=16):
+    """frames [z0, z0 + Z) of a (ztot, Y, X) synthetic uint16 volume, built a few frames at a time (1 Gi voxels at once would need ~25 GiB)"""
+    Z, Y, X = shape
+    per = Y * X
+    vol = np.empty(shape, dtype=np.uint16)
+    for a in range(0, Z, frames_per_step):
+        nz = min(frames_per_step, Z - a)
+        noise = synth._noise((z0 + a) * per, nz * per, synth.SEED).reshape(nz, Y, X)
+        sh = synth._shell(z0 + a, nz, ztot, Y, X)
+        vol[a:a + nz] = (100 + (noise >> 2) + sh * 6000).astype(np.uint16)
+    return vol
+
+
+def headline_slabs():
+    """tests/golden/headline_slabs.json (round 6): every z-slab a rank of the sharded BASELINE volumes encodes, at
+    FULL plane size -- the shell sweeps through z, slabs 3 and 4 carry data (12-bit shell voxels over whole frames) that slab 0 never sees.
+      * north_star 2048^3 u16 'bitswap1->lz4': all eight 2048 x 2048 x 256 slabs; payload = the REFERENCE pieces (SSE bit-plane gather +
+        liblz4 1.9.3 through encode_parallel), the oracle's blob asserted equal on the way;
+      * configs[2] 2048^3 'diff3x3x1->bitswap1->lz4', slabs 3 and 4, and configs[4] 2048 x 2048 x 1024 'quantiser->bitswap1->lz4', slabs 1
+        and 2 of its four (the two around the shell's centre): the ORACLE's blob (those stages of the reference need Boost: unbuildable here).
+    One slab at a time; resumes from what the file already holds."""
+    assert ref.available() and ref.lz4_version() == 10903
+    path = os.path.join(GOLD, "headline_slabs.json")
+    H = {"_meta": {"generator": "oracle/gen_golden.py --headline-slabs",
+                   "north_star": "payload: reference simd_segment_broadcast (sse_utils.hpp:1365-1433) + liblz4 1.9.3 via encode_parallel (lz4_utils.hpp:193-274); header: oracle",
+                   "c3_c5": "blob: oracle (oracle/sqy_oracle.c / sqy_oracle_float.c); the reference's diff / quantiser stages include Boost and cannot be built here",
+                   "stack": "frames [z_offset, z_offset + 256) of sqeazy_amd.synth's (z_total, 2048, 2048) uint16 volume"}, "slabs": []}
+    if os.path.exists(path):
+        with open(path) as f:
+            H = json.load(f)
+    have = {(e["pipeline"], e["z_total"], e["z_offset"]) for e in H["slabs"]}
+    shape = (256, 2048, 2048)
+    todo = [("bitswap1->lz4", 2048, s) for s in range(8)] + [("diff3x3x1->bitswap1->lz4", 2048, s) for s in (3, 4)] + \
+           [("quantiser->bitswap1->lz4", 1024, s) for s in (1, 2)]
+    for pipeline, ztot, slab in todo:
+        z0 = 256 * slab
+        if (pipeline, ztot, z0) in have:
+            continue
+        vol = _slab_volume(shape, z0, ztot)
+        mine = o.pipeline_encode(pipeline, vol)
+        h = o.header_unpack(mine)
+        e = {"name": "%s slab %d of %d (2048x2048x256 of %dx2048x2048)" % (pipeline, slab, ztot // 256, ztot), "pipeline": pipeline, "slab": slab,
+             "shape_zyx": list(shape), "z_offset": z0, "z_total": ztot, "voxels_sha256": sha(vol.tobytes()), "blob_bytes": len(mine),
+             "blob_sha256": sha(mine), "header_bytes": h["size"], "payload_bytes": len(mine) - h["size"], "payload_sha256": sha(mine[h["size"]:])}
+        if pipeline == "bitswap1->lz4":
+            planes = ref.bitswap1_encode_u16(vol, 8)
+            payload = ref.lz4_encode_parallel(planes.view(np.uint8), nthreads=8)
+            assert mine[h["size"]:] == payload.tobytes(), ("oracle payload differs from the reference pieces", e["name"])
+            e["source"] = "payload: reference SSE bitswap + liblz4 1.9.3 (oracle blob asserted equal); header: oracle"
+            del planes, payload
+        else:
+            e["source"] = "oracle"
+        H["slabs"].append(e)
+        print(e["name"], e["payload_bytes"], e["payload_sha256"][:16], flush=True)
+        with open(path, "w") as f:
+            json.dump(H, f, indent=1, sort_keys=True)
+        del vol, mine
+    print("wrote", path)
+
+
 def accel():
     """tests/golden/accel.json: liblz4 1.9.3 with an acceleration above 1 -- sqeazy's lz4(accel=-k), a negative LZ4F compression level
     (encoders/lz4.hpp:103-113) -- block level, the chunked layout and the serial block-linked layout; asserts oracle == liblz4 on the way"""
@@ -297,6 +357,8 @@ def accel():
 if __name__ == "__main__":
     if "--accel" in sys.argv:
         accel()
+    elif "--headline-slabs" in sys.argv:
+        headline_slabs()
     elif "--headline-serial" in sys.argv:
         headline_serial()
     elif "--headline" in sys.argv:

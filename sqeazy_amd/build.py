@@ -16,7 +16,8 @@ HEADERS = ["sqy_kernels.h", "sqy_pipeline.hpp", os.path.join("..", "..", "includ
 ARCH = "gfx950"
 # the one and only configuration of libsqeazy_amd.so; kernel experiments live in tools/ and build their own binaries
 # (tried: -mllvm -amdgpu-sched-strategy=max-ilp -- the LZ4 parse kernels alone 3 % faster, the bench with three calls in flight 1.5 % slower)
-FLAGS = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-DSQY_PRODUCT_BUILD"]
+# SQY_EXTRA_FLAGS: experiment builds of tools/ only (-DSQY_EXP_STATS for tools/exp_stats.py); the product is built without it
+FLAGS = ["-O3", "-fPIC", "-std=c++17", "-fvisibility=hidden", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-DSQY_PRODUCT_BUILD"] + os.environ.get("SQY_EXTRA_FLAGS", "").split()
 BINDIR = os.path.join(HERE, "bin")
 CLI = os.path.join(BINDIR, "sqy")                 # command line front end over the C-ABI (csrc/sqy_cli.cpp)
 

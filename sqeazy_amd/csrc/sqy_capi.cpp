@@ -875,9 +875,14 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         const uint32_t hc = (sqy::xxh32(fd, 2, 0) >> 8) & 0xff;
                         uint8_t* outb = static_cast<uint8_t*>(d_dst);
                         volatile uint64_t* record = static_cast<volatile uint64_t*>(ws->pinned);
-                        auto tail = [&](const uint32_t* guard) -> int {
+                        // (round 6) scan, tail marks, gather and header are ONE kernel (lz4_inplace_tail_fused_kernel: no workgroup waits for
+                        // another; with calls in flight the five launches it replaces were 0.3 ms of a call's 2.4).  Only when stored chunks
+                        // sit in front of the stored tail -- their bodies lie where gathered frames go -- does it hand back (status 4) to the
+                        // separate kernels, which put those chunks aside first.
+                        const bool fused_tail = lz4_nchunks <= 65536;         // (a workgroup of the fused kernel owns at most 64 chunks)
+                        auto tail_separate = [&](const uint32_t* guard, bool scan_too) -> int {
                             record[0] = 0;
-                            {
+                            if (scan_too) {
                                 ProfScope ps("lz4_frame_scan", stream, pend);
                                 SQY_HIP(sqy::launch_lz4_frame_scan(static_cast<uint32_t*>(ws->csize.p), lz4_nchunks, lz4_total, (uint32_t)lz4_chunk,
                                                                    static_cast<uint64_t*>(ws->frame_off.p), stream, nullptr, lz4_dup_of, lz4_tail_info, guard,
@@ -891,11 +896,26 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                                                  (uint32_t)elem_size, guard, const_cast<uint64_t*>(record), stream));
                             return 0;
                         };
+                        auto tail = [&](const uint32_t* guard) -> int {
+                            if (!fused_tail) return tail_separate(guard, true);
+                            record[0] = 0;
+                            ProfScope ps("lz4_inplace_tail", stream, pend);
+                            SQY_HIP(sqy::launch_lz4_inplace_tail_fused(outb, inplace_t0, lz4_in_stride, lz4_total, (uint32_t)lz4_chunk, lz4_nchunks,
+                                                                       static_cast<uint8_t*>(ws->lz4_scratch.p), lz4_stride, static_cast<uint32_t*>(ws->csize.p),
+                                                                       static_cast<uint64_t*>(ws->frame_off.p), lz4_dup_of, lz4_tail_info, fd[1], hc,
+                                                                       hdr_prefix.data(), (uint32_t)hdr_prefix.size(), hdr_suffix.data(),
+                                                                       (uint32_t)hdr_suffix.size(), (uint32_t)elem_size, guard, const_cast<uint64_t*>(record), stream));
+                            return 0;
+                        };
                         if (tail(d_redo)) return 1;
                         SQY_HIP(hipStreamSynchronize(stream));
                         if (record[0] == 2) {
                             if (dense_pass((uint32_t)record[6])) return 1;
                             if (tail(nullptr)) return 1;
+                            SQY_HIP(hipStreamSynchronize(stream));
+                        }
+                        if (record[0] == 4) {                                  // stored chunks in front of the stored tail: put aside first
+                            if (tail_separate(nullptr, false)) return 1;
                             SQY_HIP(hipStreamSynchronize(stream));
                         }
                         if (record[0] != 1) {

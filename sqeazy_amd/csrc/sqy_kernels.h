@@ -121,6 +121,12 @@ hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64
 // hdr_suffix, padded in front to a multiple of elem_size) written in front of them.  record (pinned host memory, 7 words) takes
 // [0] 1 done / 2 dense pass needed (guard[0] != 0: nothing was touched) / 3 no room for the header, [1] blob offset in `out`,
 // [2] blob bytes, [3] payload bytes, [4] chunks in front of the stored tail, [5] stored chunks among them, [6] guard[0].
+// (round 6) the same in one kernel; record[0] = 4 when stored chunks sit in front of the stored tail (then: the kernels above / below)
+hipError_t launch_lz4_inplace_tail_fused(uint8_t* out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
+                                         const uint8_t* scratch, uint64_t stride, const uint32_t* csize, uint64_t* frame_off, const uint32_t* dup_of,
+                                         uint64_t* tail_info, uint32_t bd_byte, uint32_t hc_byte, const char* hdr_prefix, uint32_t prefix_len,
+                                         const char* hdr_suffix, uint32_t suffix_len, uint32_t elem_size, const uint32_t* guard, uint64_t* record,
+                                         hipStream_t stream);
 hipError_t launch_lz4_inplace_tail(uint8_t* out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
                                    uint8_t* scratch, uint64_t stride, const uint32_t* csize, const uint64_t* frame_off, const uint32_t* dup_of,
                                    const uint64_t* tail_info, uint32_t bd_byte, uint32_t hc_byte, const char* hdr_prefix, uint32_t prefix_len,

@@ -15,7 +15,6 @@
 #include <atomic>
 #include <mutex>
 #include <stdint.h>
-#include <cstdlib>
 #include <cstring>
 
 #include "sqy_kernels.h"
@@ -200,6 +199,8 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
     const uint32_t wpb = blockDim.x >> 6;
     const uint64_t wave_global = (uint64_t)blockIdx.x * wpb + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint64_t wave_stride = (uint64_t)gridDim.x * wpb;
+    // (round 6, measured and not kept: consecutive tiles on one wave, so that the line two neighbouring 1 KiB pieces share is written
+    // whole -- 3 % slower, alone and in flight; non-temporal loads -- the eight loads that share a line no longer hit in L1: 0.47 -> 0.80 ms)
     for (uint64_t tile = wave_global; tile < n_tiles; tile += wave_stride) {
         const v4u* src = reinterpret_cast<const v4u*>(in + tile * BSW_TILE_VOX) + lane * 16;
         if (side) {
@@ -227,31 +228,21 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
 #pragma unroll
             for (int b = 0; b < 16; ++b) pl[b][q] = r[b];
         }
+        // One pass over the planes: the piece's hash, then the piece (round 6: hash and store of a plane next to each other, its four
+        // registers are free behind them; two separate loops kept all sixty-four alive across sixteen branches).
+        const uint32_t pm = 2u * (uint32_t)lane + 1u;                    // position inside the piece
 #pragma unroll
         for (int b = 0; b < 16; ++b) {
-            const v4u val = {pl[b][0], pl[b][1], pl[b][2], pl[b][3]};
-            if (GAP) {
-                // HOLES: a piece that is all zero is not written at all -- its hash says so (the exact zero marker below), and
-                // lz4_dedupe_verify_kernel fills such pieces in for the chunks somebody is going to read.  Chunks that are all
-                // zero are never read but for the first: bit planes above the largest voxel value are HBM traffic nobody needs.
-                if (ballot((pl[b][0] | pl[b][1] | pl[b][2] | pl[b][3]) != 0u) == 0ull) continue;
-                const uint64_t B = (uint64_t)(15 - b) * seg_words * 2u + tile * 1024u;      // byte offset of the piece in the plane stream
-                uint8_t* dst = reinterpret_cast<uint8_t*>(out) + B + (B >> gap_shift) * 15u;
-                *reinterpret_cast<v4u_any*>(dst + lane * 16) = val;
-            } else {
-                v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
-                __builtin_nontemporal_store(val, dst + lane);
-            }
-        }
-        if (piece_hash) {
-            const uint32_t pm = 2u * (uint32_t)lane + 1u;                // position inside the piece
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                uint32_t a = pl[b][0] * 0x9E3779B1u + pl[b][1] * 0x85EBCA77u + pl[b][2] * 0xC2B2AE3Du + pl[b][3] * 0x27D4EB2Fu;
+            uint32_t vx = pl[b][0], vy = pl[b][1], vz = pl[b][2], vw = pl[b][3];
+            // (nothing of plane b is computed before plane b - 1 has left: hoisted, the sixteen planes' hash terms cost 40 registers)
+            asm volatile("" : "+v"(vx), "+v"(vy), "+v"(vz), "+v"(vw) :: "memory");
+            const v4u val = {vx, vy, vz, vw};
+            const uint64_t nzm = ballot((val.x | val.y | val.z | val.w) != 0u);
+            if (piece_hash) {
+                uint32_t a = val.x * 0x9E3779B1u + val.y * 0x85EBCA77u + val.z * 0xC2B2AE3Du + val.w * 0x27D4EB2Fu;
                 a = (a ^ (a >> 15)) * pm;
                 // EXACT zero marker: a row of 16 lanes stores 0 if and only if all its 256 bytes are zero (its hash terms are
                 // all 0 then; a row with any non-zero word gets bit 0 forced on) -- all-zero chunks need no byte compare
-                const uint64_t nzm = ballot((pl[b][0] | pl[b][1] | pl[b][2] | pl[b][3]) != 0u);
                 const bool row_nz = ((nzm >> (lane & 48)) & 0xffffull) != 0ull;
                 a += __builtin_amdgcn_update_dpp(0u, a, 0x111, 0xf, 0xf, false);      // row_shr:1  (sum over the 16-lane row ends in its last lane)
                 a += __builtin_amdgcn_update_dpp(0u, a, 0x112, 0xf, 0xf, false);
@@ -260,6 +251,24 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
                 // piece = 1 KiB of segment 15-b: (byte offset of the piece in the plane stream) / 1024
                 const uint64_t piece = ((uint64_t)(15 - b) * seg_words * 2u + tile * 1024u) >> 10;
                 if ((lane & 15) == 15) piece_hash[piece * 4u + (uint32_t)(lane >> 4)] = row_nz ? (a | 1u) : 0u;
+            }
+            if (GAP) {
+                // HOLES: a piece that is all zero is not written at all -- its hash says so (the exact zero marker above), and
+                // lz4_dedupe_verify_kernel fills such pieces in for the chunks somebody is going to read.  Chunks that are all
+                // zero are never read but for the first: bit planes above the largest voxel value are HBM traffic nobody needs.
+                if (nzm == 0ull) continue;
+                const uint64_t B = (uint64_t)(15 - b) * seg_words * 2u + tile * 1024u;       // byte offset of the piece in the plane stream
+                // (round 6) the piece's address stays SCALAR: "* 15" as shift and subtract -- there is no 64-bit scalar multiply, the
+                // compiler moved the product, and with it sixteen 64-bit store addresses, into vector registers
+                const uint64_t kq = B >> gap_shift;
+                const uint64_t off = B + (kq << 4) - kq;
+                const uint32_t off_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
+                const uint32_t off_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32));
+                uint8_t* dst = reinterpret_cast<uint8_t*>(out) + (((uint64_t)off_hi << 32) | off_lo);
+                *reinterpret_cast<v4u_any*>(dst + (uint32_t)lane * 16u) = val;
+            } else {
+                v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
+                __builtin_nontemporal_store(val, dst + lane);
             }
         }
     }
@@ -741,7 +750,23 @@ __device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4)
 // The first pass keeps the ring at 8 KiB (26 KiB of LDS per chunk wave = 6 waves per CU).  The DENSE kernel, which only
 // runs the chunks the first pass gave up, takes 32 KiB: with 64 probes per batch nearly every batch would otherwise have
 // a candidate behind the ring, i.e. a global round trip per batch.
+#ifdef SQY_EXP_STATS
+// EXPERIMENT BUILDS ONLY (tools/exp_stats.py; SQY_EXTRA_FLAGS=-DSQY_EXP_STATS): every parse wave of the first pass logs when it ran and
+// what it waited for -- g_exp_buf[0] = records written, then records of eight 64-bit words.
+__device__ unsigned long long* g_exp_buf;
+__device__ unsigned long long g_exp_cap;
+extern "C" __attribute__((visibility("default"))) int SQYAMD_Exp_Set_Buffer(void* p, unsigned long long cap_records)
+{
+    unsigned long long* q = static_cast<unsigned long long*>(p);
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_exp_buf), &q, sizeof q) != hipSuccess) return 1;
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_exp_cap), &cap_records, sizeof cap_records) != hipSuccess;
+}
+#define SQY_EXP(...) __VA_ARGS__
+#else
+#define SQY_EXP(...)
+#endif
 constexpr uint32_t LZ4_RINGLESS_U = 64u * 15u;   // probes since the last match from which on the batches stride over the ring (step >= 16)
+constexpr uint32_t LZ4_NOHIT_U = 0u;  //          // probes since the last match from which on batches are first tried as "nothing found" (tags only)
 constexpr uint32_t LZ4_WIN_LEAN = 8192, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 template <uint32_t LZ4_WIN>
@@ -753,6 +778,7 @@ struct Lz4WindowT {
     uint32_t nif;          // blocks [whi, whi + nif * FB) are in flight into their slots (1 in the steady state)
     uint32_t lane16;       // lane * 16
     uint32_t pmin;         // first position of the block being parsed (0, or 65536 in a block-linked frame): the ring never holds less
+    SQY_EXP(unsigned long long x_wait = 0; uint32_t x_nwait = 0;)
 
     __device__ __forceinline__ void issue()
     {
@@ -771,7 +797,9 @@ struct Lz4WindowT {
     // everything in flight has landed and becomes readable
     __device__ __forceinline__ void commit()
     {
+        SQY_EXP(const unsigned long long x_t0 = __builtin_amdgcn_s_memtime();)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SQY_EXP(x_wait += __builtin_amdgcn_s_memtime() - x_t0; x_nwait += 1;)
         wave_lds_sync();
         const uint32_t end = whi + nif * LZ4_FB;
         if (((end - 1u) & ~(LZ4_WIN - 1)) != ((whi - 1u) & ~(LZ4_WIN - 1)) || whi == 0) {   // a block with ring offset 0 among them
@@ -906,16 +934,19 @@ __device__ __forceinline__ uint32_t common16(const Lz4Window& w, uint32_t a, uin
 // issues almost no global stores, so the s_waitcnt vmcnt(0) in front of the occasional global LOAD (far
 // candidate, window refill) no longer queues behind a stream of tiny stores on the critical path.
 constexpr uint32_t LZ4_OB = 2048;
+constexpr uint32_t LZ4_COUNT_ONLY_LIT = 256;     // literals of one sequence from which on a chunk that is not ahead stops writing (count_only)
 
 struct Lz4Out {
     SQY_GLB uint8_t* dst;        // chunk's scratch (global)
     lds_u8* ob;                  // LDS stage
     uint32_t base;               // dst offset of ob[0]; bytes [base, op) live in the stage
     int lane;
+    bool mute = false;           // count only (see `count_only` in lz4_chunks_kernel): staged bytes are dropped instead of written
 
     // write everything staged; afterwards base == op
     __device__ __forceinline__ void flush(uint32_t op)
     {
+        if (mute) { base = op; return; }
         wave_lds_sync();                                       // staged bytes were written by other lanes
         const uint32_t cnt = op - base;
         const uint32_t nvec = cnt >> 4;
@@ -1090,6 +1121,10 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         // measured, the bench lost a quarter.)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
+    SQY_EXP(const unsigned long long x_start = __builtin_amdgcn_s_memrealtime(); const unsigned long long x_c0 = __builtin_amdgcn_s_memtime();
+            unsigned long long x_far = 0, x_commit = 0; uint32_t x_nfar = 0, x_ncommit = 0, x_nseq = 0, x_ngen = 0;
+            unsigned long long x_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long x_last = x_c0;
+            auto x_lap = [&](int i) { const unsigned long long t = __builtin_amdgcn_s_memtime(); x_acc[i] += t - x_last; x_last = t; };)
     uint32_t b_first, b_last;
     uint32_t b_out = 0;                                        // LINKED: the first block of the walk whose output counts
     uint32_t spec_mode = 0;
@@ -1199,6 +1234,16 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     uint32_t op = 0, anchor = p0;
     bool failed = false;
     bool redo_dense = false;             // first pass: this chunk is left to the DENSE kernel
+    // (round 6) COUNT ONLY.  A chunk of noise with a short match every kilobyte or two (a noisy bit plane where the data has structure:
+    // plane 8 of the bench stack where the shell is tangent, 150 matches in 256 KiB) ends up stored -- its sequences cost more than
+    // they save -- but until the output limit says so, near the chunk's end, every sequence copies its kilobytes of literals: global
+    // stores that every later global load of the wave queues behind (one vmcnt), 0.25 ms of such a chunk's 0.65 alone and 1.1 ms of its
+    // 1.8 with other calls' transposes streaming -- the wave that sets the length of the whole launch in flight.  So: from the first
+    // sequence with 256 literals or more that finds the chunk NOT ahead (output so far >= input consumed), nothing is written any
+    // more; sizes and limit checks go on exactly as before.  Fails as it would have: stored, nothing lost.  Fits after all (rare:
+    // the data turned compressible later in the chunk): the chunk goes onto the dense kernel's list and is parsed again, with output.
+    bool count_only = false;
+    const bool may_count_only = !LINKED && !DENSE && !ACCEL && redo_list != nullptr;
 
     if (n >= LZ4_MINLENGTH) {
         const uint32_t mflimitPlusOne = pend - LZ4_MFLIMIT + 1;
@@ -1262,6 +1307,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
 
         for (;;) {
             SQY_STAMP(0);
+            SQY_EXP(x_lap(0);)                                  // 0: set-up, loop top, everything not named below
             // Skip-accelerated probing (no match for a while: incompressible data) strides over the ring: at a step of 16 bytes a
             // batch of 64 probes spans a KiB, later several -- most probes lie behind the resident range and are read from global
             // memory anyway, and refilling the ring up to P + AHEAD would cost an HBM round trip per batch for bytes nobody reads.
@@ -1622,7 +1668,9 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         const uint4 ci = lds_ld_4dw(w.win + oi), cm = lds_ld_u128(w.win + om);   // ip side resident and clear of matchlimit (loop condition)
                         x0 = ci.x ^ cm.x; x1 = ci.y ^ cm.y; x2 = ci.z ^ cm.z; x3 = ci.w ^ cm.w;
                     } else {
+                        SQY_EXP(const unsigned long long x_t0 = __builtin_amdgcn_s_memtime();)
                         const uint4 cg = glb_ld_u128(w.src + (uint32_t)(mt0 + dd));     // (32-bit sum: dd wraps for lane 0)  mt0 - 7 >= p_lo; mt0 + 1024 <= ip0 + 1023 < matchlimit
+                        SQY_EXP(asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); x_far += __builtin_amdgcn_s_memtime() - x_t0; x_nfar += 1;)
                         const uint4 ci = lds_ld_4dw(w.win + ((ip0 + dd) & (LZ4_WIN - 1u)));
                         x0 = ci.x ^ cg.x; x1 = ci.y ^ cg.y; x2 = ci.z ^ cg.z; x3 = ci.w ^ cg.w;
                         asm volatile("" : "+v"(x0));                                    // (keeps the optimiser from re-merging the branches)
@@ -1668,6 +1716,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         batch_done = true;
                         break;
                     }
+                    SQY_EXP(x_nseq += 1;)
                     pend = true; pe_lit = f0 - bck; pe_mcode = ml + bck; pe_off = ip0 - mt0;    // < 15 literals
                     pe_litv = b4 >> 24;                                                 // literal k-1 sits at anchor + k - 1 = pos - 1
                     const uint32_t ipn = ip0 + 4u + ml;
@@ -1704,6 +1753,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                         }
                     }
                 }
+                SQY_EXP(x_lap(1);)                              // 1: lean loop (and dense batches)
                 if (finished || failed || redo_dense) break;
                 if (redo) continue;
             }
@@ -1727,32 +1777,66 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // atomics of one instruction did not run in lane order) proves nothing; then, and on any tag hit, the buckets are put
             // back and the batch goes through the generic code below.
             // (first pass and linked frames only: the dense kernel sees chunks of short sequences, and is 3 % slower with this loop compiled in)
-            while (!DENSE && !ACCEL && !batch_done && U >= LZ4_RINGLESS_U && put2 == 0xffffffffu) {
-                const uint32_t s_first = (62 + U) >> 6;
-                const uint32_t ustar = 64 * (s_first + 1) - 62;
-                const uint32_t u = U + lane;
-                const uint32_t pos = P + s_first * lane + (u > ustar ? u - ustar : 0u);
-                const uint32_t nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
-                if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
-                const uint64_t seq = glb_ld_u64(w.src + pos);              // (the ring was left behind at these strides)
-                const uint32_t h = lz4_hash5(seq);
-                const uint32_t mytag = tag_of((uint32_t)seq);
-                const uint32_t mine = (pos << tsh) | mytag;
-                const uint32_t oe = table[h];
-                const uint32_t seen = atomicMax(&table[h], mine);
-                wave_lds_sync();
-                const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
-                const uint32_t sp = seen >> tsh;
-                const bool in_batch = sp >= P && seen != oe;
-                const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
-                if (ballot(trouble)) {
-                    table[h] = oe;                                          // (same value from every probe of a bucket)
+            // (round 6) From the FIRST batch of a search on, not only once the step has reached 16.  The fifteen batches in front of that
+            // went through the generic code (~2.3 us each alone, twice that with other calls' transposes streaming: more than a noise
+            // chunk's other seventy-five together) -- and the chunks that set the length of a launch with calls in flight are not the
+            // sparse planes' but those of a NOISY plane where the shell is tangent (plane 8 of the bench stack, chunk 203: 150 short
+            // matches in 256 KiB of noise, every one of them found after one to four batches that find nothing, 318 generic batches,
+            // 0.7 ms alone and 1.7 ms in flight).  While the step is below 16 the sequences come from the ring (one LDS round trip, no
+            // global load; a batch that then does hold a match goes to the generic code below as before).
+            if (!DENSE && !ACCEL && !batch_done && U >= LZ4_NOHIT_U && put2 == 0xffffffffu) {
+                // geometry of the batch that starts at probe index u0 from position p: this lane's probe, where the next batch begins
+                auto geom = [&](uint32_t p, uint32_t u0, uint32_t& pos, uint32_t& nxt) {
+                    const uint32_t s0 = (62 + u0) >> 6;
+                    const uint32_t s_first = s0 ? s0 : 1u;
+                    const uint32_t ustar = 64 * (s_first + 1) - 62;
+                    const uint32_t u = u0 + lane;
+                    pos = p + s_first * lane + (u > ustar ? u - ustar : 0u);
+                    nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
+                };
+                // one batch: true = proved empty (P, U moved on), false = leave (table as it was; P, U name the batch to redo)
+                auto prove = [&](uint64_t seq, uint32_t pos, uint32_t nxt) -> bool {
+                    const uint32_t h = lz4_hash5(seq);
+                    const uint32_t mytag = tag_of((uint32_t)seq);
+                    const uint32_t mine = (pos << tsh) | mytag;
+                    const uint32_t oe = table[h];
+                    const uint32_t seen = atomicMax(&table[h], mine);
                     wave_lds_sync();
-                    break;
+                    const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
+                    const uint32_t sp = seen >> tsh;
+                    const bool in_batch = sp >= P && seen != oe;
+                    const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
+                    if (ballot(trouble)) {
+                        table[h] = oe;                                          // (same value from every probe of a bucket)
+                        wave_lds_sync();
+                        return false;
+                    }
+                    P = lane_read(nxt, 63);
+                    U += 64;
+                    return true;
+                };
+                // steps below 16: out of the ring
+                bool go_on = true;
+                while (U < LZ4_RINGLESS_U) {
+                    uint32_t pos, nxt;
+                    geom(P, U, pos, nxt);
+                    if (ballot(nxt <= mflimitPlusOne) != ~0ull) { go_on = false; break; }
+                    w.ensure(P);
+                    if (!prove(w.rd64(pos), pos, nxt)) { go_on = false; break; }
                 }
-                P = lane_read(nxt, 63);
-                U += 64;
+                // step 16 and more: the ring is left behind, the sequences come straight from global memory.
+                // (round 6, measured: these loads issued four batches ahead -- where the search probes is a closed form while nothing is
+                // found -- take a chunk of noise from 52 to 35 us alone; with calls in flight they take HBM bandwidth from the other calls'
+                // transposes, which set the pace: the step 3 % slower, exact as it was.  One batch at a time.)
+                while (go_on) {
+                    uint32_t pos, nxt;
+                    geom(P, U, pos, nxt);
+                    if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
+                    if (!prove(glb_ld_u64(w.src + pos), pos, nxt)) break;
+                }
             }
+            SQY_EXP(x_lap(2);)                                  // 2: batches proved empty
+            SQY_EXP(x_ngen += 1;)
             if (!batch_done) {
                 if (U != 0) SQY_REASON(6); else SQY_REASON(7);
                 uint32_t pos, nxt;
@@ -1845,9 +1929,11 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 if (nvalid < 64) break;                               // forwardIp > mflimitPlusOne -> last literals
                 P = sgpr(next_P);
                 U += 64;
+                SQY_EXP(x_lap(3);)
                 continue;
             }
 
+            SQY_EXP(x_lap(3);)                                  // 3: generic batch search
             // ---- a match: ip = pos[f], match = fcand ----
             const uint32_t ip0 = sgpr(ipf);
             const uint32_t mt0 = sgpr(fcand);
@@ -1997,6 +2083,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t matchCode = ml + back;                     // match length - MINMATCH as upstream counts it
             const uint32_t offset = ip0 - mt0;
 
+            SQY_EXP(x_lap(4);)                                  // 4: generic match extension + catch-up
             // upstream's two output-limit checks (token + literals, then offset + match length)
             if (op + 1 + lit + (2 + 1 + LZ4_LASTLITERALS) + lit / 255 > olimit) { failed = true; break; }
             const uint32_t lit_ext = lit >= 15 ? (lit - 15) / 255 + 1 : 0;
@@ -2005,7 +2092,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (matchCode < 15 ? matchCode : 15u);
             const uint32_t seq_bytes = 1 + lit_ext + lit + 2 + ml_ext;
 
-            if (seq_bytes <= 64 && lit < 15) {
+            if (may_count_only && !count_only && lit >= LZ4_COUNT_ONLY_LIT && op >= anchor - p0) { count_only = true; o.mute = true; }
+            if (count_only) {
+                op += seq_bytes;
+                o.base = op;
+            }
+            else if (seq_bytes <= 64 && lit < 15) {
                 // whole sequence at once into the LDS stage: lane k writes byte k
                 o.reserve(op, seq_bytes);
                 const uint32_t k = (uint32_t)lane;
@@ -2059,6 +2151,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             put2 = ipn - 2;
             P = ipn;
             U = 0;
+            SQY_EXP(x_lap(5);)                                  // 5: generic emission
             SQY_STAMP(10);
         }
         if (pend && !failed) emit_pending();
@@ -2069,6 +2162,8 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         const uint32_t lastRun = pend - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
             failed = true;
+        } else if (count_only) {
+            redo_dense = true;                                  // it fits after all: parsed again, with output, by the dense kernel
         } else {
             if (lastRun >= 15) {
                 const uint32_t rest = lastRun - 15;
@@ -2086,6 +2181,28 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // no ring copy may still be in flight when the LDS is released / refilled
+#ifdef SQY_EXP_STATS
+    if constexpr (!LINKED && !DENSE && !ACCEL) if (lane == 0 && g_exp_buf) {
+        const unsigned long long slot = atomicAdd(g_exp_buf, 1ull);
+        if (slot < g_exp_cap) {
+            unsigned long long* r = g_exp_buf + 8 + slot * 8;
+            uint32_t hwid;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+            uint32_t xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            r[0] = x_start; r[1] = __builtin_amdgcn_s_memrealtime(); r[2] = __builtin_amdgcn_s_memtime() - x_c0;
+            r[3] = w.x_wait | ((unsigned long long)w.x_nwait << 40); r[4] = x_far | ((unsigned long long)x_nfar << 40);
+            r[5] = (unsigned long long)blockIdx.x | ((unsigned long long)x_nseq << 32); r[6] = (((unsigned long long)(uintptr_t)scratch >> 12) & 0xffffffffull) | ((unsigned long long)(xcc & 15u) << 32) | ((unsigned long long)hwid << 36);
+            r[7] = (unsigned long long)x_ngen | ((unsigned long long)(failed ? 0u : op) << 32);
+            x_lap(6);                                            // 6: tail (last literals, flush)
+            r[2] = (x_acc[0] >> 8) | ((x_acc[1] >> 8) << 21) | ((x_acc[2] >> 8) << 42);         // (units of 256 ticks, 21 bits each)
+            r[3] |= 0;                                           // (ring waits stay)
+            r[4] |= 0;
+            r[6] = (r[6] & 0xffffffffull) | (((x_acc[3] >> 8) & 0xffffull) << 32) | (((x_acc[4] >> 8) & 0xffffull) << 48);
+            r[7] = (r[7] & 0xffffffff0000ffffull) | (((x_acc[5] >> 8) & 0xffffull) << 16);
+        }
+    }
+#endif
     if (lane == 0) {
         if (!LINKED && !DENSE && redo_dense) redo_list[1u + atomicAdd(&redo_list[0], 1u)] = (uint32_t)blk;
         else if (!LINKED || (bi >= b_out && !redo_dense)) csize[blk] = failed ? 0u : op;      // (LINKED && redo_dense: given up, see below)
@@ -2133,10 +2250,11 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
     __shared__ uint64_t carry_s;
     __shared__ uint32_t last_comp_s, raw_head_s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nt = blockDim.x;                            // (round 6: launched with 256 threads -- a block of sixteen waves waits for a CU to drain when calls are in flight)
     if (guard && guard[0] != 0u) return;
     if (tid == 0) { carry_s = 0; last_comp_s = 0; raw_head_s = 0; }
     __syncthreads();
-    for (uint64_t base = 0; base < nchunks; base += 1024) {
+    for (uint64_t base = 0; base < nchunks; base += nt) {
         const uint64_t k = base + tid;
         uint64_t sz = 0;
         if (k < nchunks) {
@@ -2165,7 +2283,7 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
         const uint64_t carry = carry_s;
         if (k < nchunks) frame_off[k] = carry + woff + x - sz;
         __syncthreads();
-        if (tid == 1023) carry_s = carry + woff + x;
+        if ((uint32_t)tid == nt - 1u) carry_s = carry + woff + x;
         __syncthreads();
     }
     if (tid == 0) frame_off[nchunks] = carry_s;
@@ -2173,7 +2291,7 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
         __syncthreads();
         const uint32_t j = last_comp_s;
         uint32_t nraw = 0;
-        for (uint64_t k = tid; k < j; k += 1024) nraw += csize[dup_of ? dup_of[k] : k] == 0u ? 1u : 0u;
+        for (uint64_t k = tid; k < j; k += nt) nraw += csize[dup_of ? dup_of[k] : k] == 0u ? 1u : 0u;
         if (nraw) atomicAdd(&raw_head_s, nraw);
         __syncthreads();
         if (tid == 0) {
@@ -2183,7 +2301,7 @@ void lz4_frame_scan_kernel(const uint32_t* __restrict__ csize, uint64_t nchunks,
             tail_info[3] = carry_s;
         }
         if (body0) {
-            for (uint64_t k = (uint64_t)j + tid; k < nchunks; k += 1024) {
+            for (uint64_t k = (uint64_t)j + tid; k < nchunks; k += nt) {
                 const uint64_t left = total - k * chunk;
                 const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
                 uint8_t* b = body0 + k * in_stride;
@@ -3418,6 +3536,13 @@ __device__ __forceinline__ uint64_t lz4_decode_frame_out(uint64_t o, const uint6
     return remap[fi] * remap_bytes + (o - fi * remap_bytes);
 }
 
+// The decode kernels' rings leave for global memory in pieces of DEC_FLUSH_PIECE bytes (flush()), a copy step adds at most DEC_STEP_MAX:
+// up to DEC_FLUSH_PIECE - 1 + DEC_STEP_MAX decoded bytes are in the ring only.  A match that reaches behind the ring reads them back
+// from global memory; what it reads must have been STORED (offset > DEC_RING covers that: the static_asserts) and the stores must have
+// LANDED: the wait at the match's start covers everything older, and a step whose source may lie within the bytes this very match has
+// flushed since -- j + cnt + DEC_FLUSH_PIECE + DEC_STEP_MAX > offset -- waits again (round-5 advice: the guard still said 2048 from the
+// time when pieces were 1 KiB).
+constexpr uint32_t DEC_FLUSH_PIECE = 4096u, DEC_STEP_MAX = 1024u;
 template <uint32_t DEC_RING>
 __global__ __launch_bounds__(64)
 void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __restrict__ blk, const uint32_t* __restrict__ frame_first,
@@ -3426,6 +3551,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
 {
     // stage of compressed bytes: 4 KiB, or 3 KiB beside the small ring (ring + stage + marks < 20 KiB: 8 waves per CU, not 7)
     constexpr uint32_t DEC_IN = DEC_RING < 65536u ? 3072u : 4096u;
+    static_assert(DEC_RING >= DEC_FLUSH_PIECE + 2u * DEC_STEP_MAX + 1024u, "a match behind the ring must find its source flushed: ring >= flush piece + two copy steps + margin");
     __shared__ __attribute__((aligned(16))) uint8_t dring_raw[DEC_RING + DEC_IN + 64];   // static: 68 KiB (dynamic LDS stops at 64 KiB by default)
     lds_u8* ring = (lds_u8*)dring_raw;
     lds_u8* stage = (lds_u8*)dring_raw + DEC_RING;
@@ -3442,15 +3568,15 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         // write ring bytes [flushed, pos) (all) or whole pieces of 4 KiB of it (round 5: four reads of the ring in flight, then four stores;
         // before, a KiB per call, each behind its own LDS round trip.  What has not left yet stays inside the ring -- a step adds at most
         // 1 KiB, the smallest ring has 8 --, and a match that reaches behind the ring ends more than 7 KiB back: flushed)
-        while (flushed + 4096u <= pos) {
+        while (flushed + DEC_FLUSH_PIECE <= pos) {
             const uint64_t o = frame_out + flushed;
-            if (o + 4096u > out_bytes) { bad = true; flushed = pos; break; }
+            if (o + DEC_FLUSH_PIECE > out_bytes) { bad = true; flushed = pos; break; }
             v4u v[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const SQY_LDS v4u*>(ring + ((flushed + q * 1024u + (uint32_t)lane * 16u) & (DEC_RING - 1)));
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) st_u128(out + o + q * 1024u + (uint32_t)lane * 16u, make_uint4(v[q].x, v[q].y, v[q].z, v[q].w));
-            flushed += 4096u;
+            flushed += DEC_FLUSH_PIECE;
         }
         while (all && flushed < pos) {
             const uint32_t cnt = (pos - flushed >= 1024u) ? 1024u : (pos - flushed);
@@ -3553,15 +3679,16 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
         // match copy: `ml` bytes from `offset` bytes back, onto the ring at pos
         auto copy_match = [&](uint32_t offset, uint32_t ml) {
             if (DEC_RING < 65536u && offset > DEC_RING) {
-                // behind the ring: those bytes left for global memory at least (offset - 1023) bytes ago.  Loads bypass the L1
-                // (sc1): the line may have been read before this wave's later stores to it.
+                // behind the ring: those bytes have been handed to global memory (at most DEC_FLUSH_PIECE - 1 + DEC_STEP_MAX bytes are
+                // not, and offset > DEC_RING is more than that).  Loads bypass the L1 (sc1): the line may have been read before this
+                // wave's later stores to it.
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint8_t* const gsrc = out + frame_out;
                 for (uint32_t j = 0; j < ml;) {                       // up to 1 KiB per step (round 4; before: 64 bytes)
                     const uint32_t dp = pos & (DEC_RING - 1);
                     uint32_t cnt = ml - j < 1024u ? ml - j : 1024u;
                     cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
-                    if (j + cnt + 2048u > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the source was written by this very match)
+                    if (j + cnt + DEC_FLUSH_PIECE + DEC_STEP_MAX > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the source was written by this very match)
                     const uint32_t full = cnt >> 4, r = cnt & 15u;
                     const uint8_t* const g = gsrc + (pos - offset);
                     uint4 v = make_uint4(0, 0, 0, 0);
@@ -4224,6 +4351,7 @@ __device__ __noinline__ void lz4_decode2_copy(const uint8_t* __restrict__ src, u
 {
     constexpr uint32_t DEC_IN = 3072u;
     constexpr uint32_t SPIN = 1u << 22;
+    static_assert(DEC_RING >= DEC_FLUSH_PIECE + 2u * DEC_STEP_MAX + 1024u, "a match behind the ring must find its source flushed: ring >= flush piece + two copy steps + margin");
     SQY_DST(uint64_t ct_t0 = __builtin_amdgcn_s_memtime(); uint64_t ct_wait = 0; uint64_t ct_units = 0; uint64_t ct_runits = 0; uint64_t ct_rounds = 0;
             uint64_t ct_cr = 0; uint64_t ct_seqs = 0; uint64_t ct_ci = 0; uint64_t ct_fill = 0; uint64_t ct_flush = 0; uint64_t ct_nflush = 0;
             uint64_t ct_short = 0; uint64_t ct_cshort = 0; uint64_t ct_long = 0; uint64_t ct_clong = 0; uint64_t ct_far = 0; uint64_t ct_cfar = 0;)
@@ -4235,15 +4363,15 @@ __device__ __noinline__ void lz4_decode2_copy(const uint8_t* __restrict__ src, u
         // 4 KiB at a time: four reads of the ring in flight, then four stores (a KiB per call, each behind its own LDS round trip, was a fifth
         // of this wave's time).  What has not left yet stays inside the ring (a step adds at most 1 KiB), and a match that reaches behind the
         // ring (offset > DEC_RING >= 16 KiB) ends more than 15 KiB back: flushed.
-        while (flushed + 4096u <= pos) {
+        while (flushed + DEC_FLUSH_PIECE <= pos) {
             const uint64_t o = frame_out + flushed;
-            if (o + 4096u > out_bytes) { bad = true; flushed = pos; break; }
+            if (o + DEC_FLUSH_PIECE > out_bytes) { bad = true; flushed = pos; break; }
             v4u v[4];
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const SQY_LDS v4u*>(ring + ((flushed + q * 1024u + (uint32_t)lane * 16u) & (DEC_RING - 1)));
 #pragma unroll
             for (uint32_t q = 0; q < 4; ++q) st_u128(out + o + q * 1024u + (uint32_t)lane * 16u, make_uint4(v[q].x, v[q].y, v[q].z, v[q].w));
-            flushed += 4096u;
+            flushed += DEC_FLUSH_PIECE;
         }
         while (all && flushed < pos) {
             const uint32_t cnt = (pos - flushed >= 1024u) ? 1024u : (pos - flushed);
@@ -4301,7 +4429,7 @@ __device__ __noinline__ void lz4_decode2_copy(const uint8_t* __restrict__ src, u
                 const uint32_t dp = pos & (DEC_RING - 1);
                 uint32_t cnt = ml - j < 1024u ? ml - j : 1024u;
                 cnt = cnt < DEC_RING - dp ? cnt : DEC_RING - dp;
-                if (j + cnt + 2048u > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (j + cnt + DEC_FLUSH_PIECE + DEC_STEP_MAX > offset) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 const uint32_t full = cnt >> 4, r = cnt & 15u;
                 const uint8_t* const g = gsrc + (pos - offset);
                 uint4 v = make_uint4(0, 0, 0, 0);
@@ -5478,6 +5606,8 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         // (and piece hashes: all-zero pieces are left unwritten, the hashes tell the readers which)
         if (len % BSW_TILE_VOX != 0 || (reinterpret_cast<uintptr_t>(in) & 15) || gap_chunk < 1024u || (gap_chunk & (gap_chunk - 1u)) || !piece_hash)
             return hipErrorInvalidValue;
+        // (round 6, measured: fewer resident blocks -- 8 .. 2 per CU instead of as many as fit -- let the small kernels of the other calls in
+        // flight start sooner, and cost the transposes and with them the step 3 .. 12 %)
         const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * 32;    // (blocks of two waves: see below)
         hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(128), 0, stream, in, out, n_tiles, len / 16,
                            piece_hash, (uint32_t)__builtin_ctz(gap_chunk), side, side_w, X);
@@ -5783,12 +5913,218 @@ hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64
                                  uint64_t* frame_off, hipStream_t stream, const Lz4Block* blocks, const uint32_t* dup_of, uint64_t* tail_info,
                                  const uint32_t* guard, uint8_t* body0, uint64_t in_stride, uint32_t bd_byte, uint32_t hc_byte)
 {
-    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(1024), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of, tail_info,
+    hipLaunchKernelGGL(lz4_frame_scan_kernel, dim3(1), dim3(256), 0, stream, csize, nchunks, total, chunk, frame_off, blocks, dup_of, tail_info,
                        guard, body0, in_stride, bd_byte, hc_byte);
     return hipGetLastError();
 }
 
 // ---- frames in place, the tail of a call driven from the device (round 4): no host round trip between the parse and the blob ----
+// ------------------------------------------------------------------------------------------------
+// Frames in place, the whole tail of a call in ONE kernel (round 6).  Scan, tail marks, stash, gather and header were five dependent
+// launches; alone that is 0.07 ms, but with calls in flight every launch waits its turn on a full chip and every kernel's chain of
+// dependent loads (duplicate map -> size -> offset, sixteen times in a row in the scan) runs at the loaded HBM latency: 0.3 ms of a
+// call's 2.4.  Here every workgroup reads ALL the sizes itself (a few loads per thread, all in flight at once) and reduces them to
+// what it needs: where the stored tail begins (j), the bytes of the frames in front of it, the bytes in front of its own chunks.
+// No workgroup waits for another.  Workgroup b owns chunks [b * cpb, (b + 1) * cpb): frames in front of j are gathered to where they
+// end up, chunks from j on get their marks; workgroup 0 also writes the sqy header and the record the host reads.
+// Stored chunks IN FRONT of j (their bodies lie where gathered frames go) need the stash pass first: status 4, the host runs the
+// separate kernels.  guard[0] != 0 (chunks left to the dense pass): status 2 as before.
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t TAIL_THREADS = 256;
+__global__ __launch_bounds__(TAIL_THREADS)
+void lz4_inplace_tail_fused_kernel(uint8_t* __restrict__ out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
+                                   uint32_t cpb, const uint8_t* __restrict__ scratch, uint64_t stride, const uint32_t* __restrict__ csize,
+                                   uint64_t* __restrict__ frame_off, const uint32_t* __restrict__ dup_of, uint64_t* __restrict__ tail_info,
+                                   uint32_t bd_byte, uint32_t hc_byte, Lz4HeaderParts hp, uint32_t elem_size, const uint32_t* __restrict__ guard,
+                                   uint64_t* __restrict__ record)
+{
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (guard && guard[0] != 0u) {
+        if (blockIdx.x == 0 && tid == 0) { record[6] = guard[0]; record[0] = 2; }
+        return;
+    }
+    __shared__ uint64_t red_sum[TAIL_THREADS / 64], red_before[TAIL_THREADS / 64];
+    __shared__ uint32_t red_j[TAIL_THREADS / 64], red_zero[TAIL_THREADS / 64];
+    __shared__ uint64_t own_off[64];                       // frame offsets of this workgroup's chunks (cpb <= 64)
+    __shared__ uint32_t own_c[64], own_ks[64];
+    const uint64_t k_first = (uint64_t)blockIdx.x * cpb;
+    // ---- every size of the call, eight per thread in flight ----
+    uint64_t sum = 0, before = 0;
+    uint32_t jmax = 0, nzero = 0;
+    for (uint64_t base = 0; base < nchunks; base += TAIL_THREADS * 8u) {
+        uint32_t ks[8], c[8];
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint64_t k = base + u * TAIL_THREADS + tid;
+            ks[u] = k < nchunks ? (dup_of ? dup_of[k] : (uint32_t)k) : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint64_t k = base + u * TAIL_THREADS + tid;
+            c[u] = k < nchunks ? csize[ks[u]] : 0u;
+        }
+#pragma unroll
+        for (uint32_t u = 0; u < 8; ++u) {
+            const uint64_t k = base + u * TAIL_THREADS + tid;
+            if (k < nchunks) {
+                const uint64_t left = total - k * chunk;
+                const uint64_t nk = left < chunk ? left : chunk;
+                const uint64_t sz = 15u + (c[u] ? c[u] : nk);
+                sum += sz;
+                if (k < k_first) before += sz;
+                if (c[u]) jmax = jmax > (uint32_t)k + 1u ? jmax : (uint32_t)k + 1u; else nzero += 1u;
+                if (k >= k_first && k < k_first + cpb) { own_c[k - k_first] = c[u]; own_ks[k - k_first] = ks[u]; }
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        sum += __shfl_xor(sum, d); before += __shfl_xor(before, d); nzero += __shfl_xor(nzero, d);
+        const uint32_t o = __shfl_xor(jmax, d);
+        jmax = jmax > o ? jmax : o;
+    }
+    if (lane == 0) { red_sum[wave] = sum; red_before[wave] = before; red_j[wave] = jmax; red_zero[wave] = nzero; }
+    __syncthreads();
+    sum = 0; before = 0; jmax = 0; nzero = 0;
+#pragma unroll
+    for (uint32_t w = 0; w < TAIL_THREADS / 64; ++w) {
+        sum += red_sum[w]; before += red_before[w]; nzero += red_zero[w];
+        jmax = jmax > red_j[w] ? jmax : red_j[w];
+    }
+    const uint64_t j = jmax;                                                  // first chunk of the stored run that ends the stream
+    const uint64_t tail_bytes = (nchunks - j) * 15u + (total - (j * chunk < total ? j * chunk : total));
+    const uint64_t head_bytes = sum - tail_bytes;                              // bytes of the frames in front of j
+    const uint32_t nraw = nzero - (uint32_t)(nchunks - j);                    // stored chunks among them
+    uint8_t* const body0 = out + t0 + 11;
+    if (blockIdx.x == 0 && tid == 0) {
+        tail_info[0] = j; tail_info[1] = head_bytes; tail_info[2] = nraw; tail_info[3] = sum;
+        frame_off[nchunks] = sum;
+    }
+    // ---- offsets of this workgroup's chunks (a handful: one lane walks them) ----
+    const uint32_t nown = (uint32_t)(k_first < nchunks ? (nchunks - k_first < cpb ? nchunks - k_first : cpb) : 0u);
+    if (tid == 0) {
+        uint64_t o = before;
+        for (uint32_t i = 0; i < nown; ++i) {
+            const uint64_t k = k_first + i;
+            const uint64_t left = total - k * chunk;
+            const uint64_t nk = left < chunk ? left : chunk;
+            own_off[i] = o;
+            frame_off[k] = o;
+            o += 15u + (own_c[i] ? own_c[i] : nk);
+        }
+    }
+    __syncthreads();
+    // ---- marks of the stored chunks that end the stream: final where they stand ----
+    if (tid < nown && k_first + tid >= j) {
+        const uint64_t k = k_first + tid;
+        const uint64_t left = total - k * chunk;
+        const uint32_t nk = (uint32_t)(left < chunk ? left : chunk);
+        uint8_t* b = body0 + k * in_stride;
+        const uint32_t field = nk | 0x80000000u;
+        b[-11] = 0x04; b[-10] = 0x22; b[-9] = 0x4D; b[-8] = 0x18; b[-7] = 0x40; b[-6] = (uint8_t)bd_byte; b[-5] = (uint8_t)hc_byte;
+        b[-4] = (uint8_t)field; b[-3] = (uint8_t)(field >> 8); b[-2] = (uint8_t)(field >> 16); b[-1] = (uint8_t)(field >> 24);
+        b[nk] = 0; b[nk + 1] = 0; b[nk + 2] = 0; b[nk + 3] = 0;
+    }
+    if (nraw != 0u) {                                                          // (uniform over the grid) the stash pass has to run first
+        if (blockIdx.x == 0 && tid == 0) { record[4] = j; record[5] = nraw; record[0] = 4; }
+        return;
+    }
+    // ---- the frames in front of j end where frame j begins ----
+    uint8_t* const dst0 = out + t0 + j * in_stride - head_bytes;
+    for (uint32_t i = 0; i < nown; ++i) {
+        const uint64_t k = k_first + i;
+        if (k >= j) break;
+        const uint32_t c = own_c[i];                                           // (!= 0: no stored chunk in front of j)
+        const uint8_t* __restrict__ s = scratch + (uint64_t)own_ks[i] * stride;
+        uint8_t* __restrict__ d = dst0 + own_off[i];
+        if (tid < 15u) {
+            uint8_t v = 0;
+            uint32_t o = tid;
+            switch (tid) {
+                case 0: v = 0x04; break; case 1: v = 0x22; break; case 2: v = 0x4D; break; case 3: v = 0x18; break;
+                case 4: v = 0x40; break; case 5: v = (uint8_t)bd_byte; break; case 6: v = (uint8_t)hc_byte; break;
+                case 7: v = (uint8_t)c; break; case 8: v = (uint8_t)(c >> 8); break;
+                case 9: v = (uint8_t)(c >> 16); break; case 10: v = (uint8_t)(c >> 24); break;
+                default: v = 0; o = 11u + c + (tid - 11u); break;               // end mark
+            }
+            d[o] = v;
+        }
+        uint8_t* __restrict__ dd = d + 11;
+        const uint8_t* __restrict__ ss = s;
+        uint32_t len = c;
+        const uint32_t head0 = (uint32_t)((16 - (reinterpret_cast<uintptr_t>(dd) & 15)) & 15);
+        const uint32_t head = head0 < len ? head0 : len;
+        if (tid < head) dd[tid] = ss[tid];
+        dd += head; ss += head; len -= head;
+        const uint32_t nvec = len >> 4;
+        for (uint32_t i0 = tid; i0 < nvec; i0 += TAIL_THREADS * 4u) {
+            uint4 v[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) if (i0 + u * TAIL_THREADS < nvec) v[u] = ld_u128(ss + (size_t)(i0 + u * TAIL_THREADS) * 16);
+#pragma unroll
+            for (uint32_t u = 0; u < 4; ++u) if (i0 + u * TAIL_THREADS < nvec) *reinterpret_cast<uint4*>(dd + (size_t)(i0 + u * TAIL_THREADS) * 16) = v[u];
+        }
+        const uint32_t done = nvec << 4;
+        if (tid < len - done) dd[done + tid] = ss[done + tid];
+    }
+    // ---- the sqy header in front of the payload, and what the host wants to know ----
+    if (blockIdx.x != 0) return;
+    const uint64_t payload = sum;
+    const uint64_t payload_at = t0 + j * in_stride - head_bytes;
+    char digits[20];
+    uint32_t nd = 0;
+    {
+        uint64_t v = payload;
+        do { digits[nd++] = (char)('0' + v % 10); v /= 10; } while (v);       // (least significant first)
+    }
+    const uint64_t text = (uint64_t)hp.prefix_len + nd + hp.suffix_len;
+    const uint64_t pad = (elem_size - text % elem_size) % elem_size;           // sqeazy_header.hpp:172-178: the header's size is a multiple of the voxel's
+    const uint64_t hdr_len = text + pad;
+    if (hdr_len > payload_at) {
+        if (tid == 0) record[0] = 3;
+        return;
+    }
+    uint8_t* h = out + payload_at - hdr_len;
+    for (uint64_t i = tid; i < hdr_len; i += TAIL_THREADS) {
+        uint8_t cch;
+        if (i < pad) cch = ' ';
+        else if (i < pad + hp.prefix_len) cch = (uint8_t)hp.text[i - pad];
+        else if (i < pad + hp.prefix_len + nd) cch = (uint8_t)digits[nd - 1 - (i - pad - hp.prefix_len)];
+        else cch = (uint8_t)hp.text[hp.prefix_len + (i - pad - hp.prefix_len - nd)];
+        h[i] = cch;
+    }
+    if (tid == 0) {
+        record[1] = payload_at - hdr_len;
+        record[2] = hdr_len + payload;
+        record[3] = payload;
+        record[4] = j;
+        record[5] = 0;
+        record[6] = 0;
+        record[0] = 1;
+    }
+}
+
+hipError_t launch_lz4_inplace_tail_fused(uint8_t* out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
+                                         const uint8_t* scratch, uint64_t stride, const uint32_t* csize, uint64_t* frame_off, const uint32_t* dup_of,
+                                         uint64_t* tail_info, uint32_t bd_byte, uint32_t hc_byte, const char* hdr_prefix, uint32_t prefix_len,
+                                         const char* hdr_suffix, uint32_t suffix_len, uint32_t elem_size, const uint32_t* guard, uint64_t* record,
+                                         hipStream_t stream)
+{
+    Lz4HeaderParts hp;
+    if ((uint64_t)prefix_len + suffix_len > sizeof(hp.text) || nchunks == 0 || nchunks > 0x7fffffffull) return hipErrorInvalidValue;
+    hp.prefix_len = prefix_len; hp.suffix_len = suffix_len;
+    std::memcpy(hp.text, hdr_prefix, prefix_len);
+    std::memcpy(hp.text + prefix_len, hdr_suffix, suffix_len);
+    // a workgroup owns up to 64 chunks; as many workgroups as that takes, at least a few per CU's worth of small calls
+    uint32_t cpb = (uint32_t)((nchunks + 1023u) / 1024u);
+    if (cpb < 4u) cpb = 4u;
+    if (cpb > 64u) return hipErrorInvalidValue;                                // (more than 65536 chunks: the separate kernels)
+    const unsigned grid = (unsigned)((nchunks + cpb - 1u) / cpb);
+    hipLaunchKernelGGL(lz4_inplace_tail_fused_kernel, dim3(grid), dim3(TAIL_THREADS), 0, stream, out, t0, in_stride, total, chunk, nchunks, cpb, scratch,
+                       stride, csize, frame_off, dup_of, tail_info, bd_byte, hc_byte, hp, elem_size, guard, record);
+    return hipGetLastError();
+}
+
 hipError_t launch_lz4_inplace_tail(uint8_t* out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
                                    uint8_t* scratch, uint64_t stride, const uint32_t* csize, const uint64_t* frame_off, const uint32_t* dup_of,
                                    const uint64_t* tail_info, uint32_t bd_byte, uint32_t hc_byte, const char* hdr_prefix, uint32_t prefix_len,

@@ -92,6 +92,49 @@ def test_lz4_noise_with_planted_repeats(sqy, oracle, layout):
     assert rc == 0 and blob == oracle.pipeline_encode("bitswap1->lz4", v16, nthreads=layout)
 
 
+@pytest.mark.parametrize("layout", [2, 1])
+def test_lz4_count_only_chunks(sqy, oracle, layout):
+    """Round 6: a chunk of the chunked layout whose sequences carry kilobytes of literals while it is not ahead of its input stops writing
+    its output (it will most likely be stored) and only counts; if it fits after all it is parsed again by the dense kernel.  Chunks
+    that go either way, and chunks whose compressed size lands within a few bytes of the capacity n - 1."""
+    rng = np.random.default_rng(61)
+    C = 256 << 10
+    chunks = []
+    # (a) noise with a short match every kilobyte or two: stored in the end (the bench stack's plane 8 where the shell is tangent)
+    x = rng.integers(0, 256, C, dtype=np.uint8)
+    for at in range(3000, C - 100, 1700):
+        x[at:at + 9] = x[at - 777:at - 777 + 9]
+    chunks.append(x)
+    # (b) the same start, then zeros: counts only from its first long literal run on -- and fits after all
+    y = x.copy(); y[40000:] = 0
+    chunks.append(y)
+    # (c) zeros first (well ahead), then noise with matches: never stops writing; fits
+    z = x.copy(); z[:200000] = 0
+    chunks.append(z)
+    # (d) noise, then just enough zeros that the size lands around the capacity: a sweep of the zero run's length across the edge
+    for zeros in (1100, 1120, 1130, 1140, 1150, 1160, 1170, 1180, 1200, 1500):
+        e = rng.integers(0, 256, C, dtype=np.uint8)
+        for at in range(2000, C - 3000, 2300):
+            e[at:at + 6] = e[at - 100:at - 100 + 6]
+        e[C - zeros - 20:C - 20] = 0
+        chunks.append(e)
+    # (e) long literal runs between long matches: compresses well, is ahead all the time
+    f = np.tile(rng.integers(0, 256, 5000, dtype=np.uint8), C // 5000 + 1)[:C].copy()
+    for at in range(6000, C - 600, 9000):
+        f[at:at + 500] = rng.integers(0, 256, 500, dtype=np.uint8)
+    chunks.append(f)
+    vol = np.concatenate(chunks).reshape(1, 1, -1)
+    rc, blob = sqy.encode("lz4", vol, nthreads=layout)
+    assert rc == 0
+    assert blob == oracle.pipeline_encode("lz4", vol, nthreads=layout)
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back, vol)
+    # the same stream as bit planes (frames in place: the device-resident entry point the bench uses)
+    v16 = vol.reshape(-1).view(np.uint16).reshape(1, 1, -1)
+    rc, blob = sqy.encode("bitswap1->lz4", v16, nthreads=layout)
+    assert rc == 0 and blob == oracle.pipeline_encode("bitswap1->lz4", v16, nthreads=layout)
+
+
 def test_diff_bitswap_lz4_u16(sqy, oracle):
     for shape in ((16, 32, 48), (8, 8, 8), (40, 12, 20), (6, 8, 16), (9, 10, 8), (10, 10, 8), (12, 33, 2100), (5, 3, 3), (2, 9, 17),
                   (1, 4, 4), (30, 7, 5)):

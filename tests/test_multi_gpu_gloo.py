@@ -276,3 +276,137 @@ def test_gatherer_failure_reaches_every_rank():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(r, "ok") for r in range(3)], res
+
+
+def _worker_bench_step_loop(rank, world, port, q):
+    """bench.py's OWN step loop (bench.StepRunner: caller threads, two buffers each, steps taken in order, buffer hand-back) under two
+    real processes, both ways it is timed at N > 1 -- sizes exchanged per step (`value`) and the gather to rank 0 inside every step
+    (`with_gather`) -- with the CPU oracle standing in for the encoder, and the two reports rank 0 prints (`per_rank`, `with_gather`)."""
+    sys.path.insert(0, ROOT)
+    import threading
+    import torch
+    import torch.distributed as dist
+    import bench
+    from oracle import sqy_oracle as o
+    from sqeazy_amd import multi, synth
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["WORLD_SIZE"] = str(world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        dev = torch.device("cpu")
+        inflight, cap, pipe = 3, 1 << 15, "bitswap1->lz4"
+        Z, Y, X = 6, 16, 32
+        # rank r holds frames [r*Z, (r+1)*Z) of an (N*Z, Y, X) stack (bench.py's weak-scaling layout); every step another seed
+        vols = [synth.stack((world * Z, Y, X), seed=500 + s)[rank * Z:(rank + 1) * Z] for s in range(7)]
+        blobs = [o.pipeline_encode(pipe, v) for v in vols]
+        outs = [[torch.zeros(cap, dtype=torch.uint8) for _ in range(2)] for _ in range(inflight)]
+        busy = [[False, False] for _ in range(inflight)]           # a buffer handed to the gatherer must not be encoded into before it comes back
+        count = [0] * inflight
+        lock = threading.Lock()
+        step_of = {}
+
+        def encode(t, b):
+            with lock:
+                assert not busy[t][b], "thread %d encodes into buffer %d while the gather still reads it" % (t, b)
+                s = count[t] * inflight + t                       # the step this call is (thread t takes t, t + inflight, ..)
+                count[t] += 1
+            blob = blobs[s % len(blobs)]
+            off = 11 + 3 * t + b                                  # frames in place: the blob starts somewhere inside its buffer
+            outs[t][b][off:off + len(blob)] = torch.frombuffer(bytearray(blob), dtype=torch.uint8)
+            with lock:
+                step_of[(t, b)] = s
+                busy[t][b] = gathering[0]
+            return off, len(blob)
+
+        gathering = [False]
+        index_rows = [torch.zeros(world, dtype=torch.int64) for _ in range(4)]
+        gatherer = multi.SlabGatherer(world * cap, dev)
+        posted = []
+
+        class Watch:                                              # the gatherer, with the hand-back observed
+            stats = gatherer.stats
+
+            def post(self, view, n, on_done=None):
+                posted.append(n)
+
+                def done(od=on_done, key=len(posted) - 1):
+                    with lock:
+                        for t in range(inflight):
+                            for b in range(2):
+                                if outs[t][b].data_ptr() <= view.data_ptr() < outs[t][b].data_ptr() + cap:
+                                    busy[t][b] = False
+                    od()
+                gatherer.post(view, n, on_done=done)
+
+            def drain(self):
+                gatherer.drain()
+
+        runner = bench.StepRunner(inflight, encode, dist_on=True, blob_view=lambda t, b, off: outs[t][b][off:],
+                                  exchange=lambda n, slot: multi.exchange_sizes(n, dev, out=index_rows[slot % len(index_rows)], sync=False),
+                                  gatherer=Watch())
+        # ---- `value`: blobs stay where they are, the sizes are all_gathered per step ----
+        k = 7
+        last = runner.run_steps(k, gather=False)
+        assert last == len(blobs[(k - 1) % len(blobs)])
+        dist.barrier()
+        sizes_all = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(sizes_all, torch.tensor([len(blobs[(k - 1) % len(blobs)])], dtype=torch.int64))
+        assert index_rows[(k - 1) % len(index_rows)].tolist() == [int(x.item()) for x in sizes_all]      # the last step's index row
+        t, b, off = runner.last_at
+        assert bytes(outs[t][b][off:off + last].numpy().tobytes()) == blobs[(k - 1) % len(blobs)]
+        # ---- `with_gather`: the gather to rank 0 inside every step, overlapped; the buffer comes back when its gather is done ----
+        count[:] = [0] * inflight
+        gathering[0] = True
+        g0 = dict(gatherer.stats)
+        local = []
+        import time
+        for _ in range(2):                                        # two timed blocks, like timed_blocks()
+            t0 = time.perf_counter()
+            base = [c for c in count]
+            runner.run_steps(k, gather=True)
+            t_own = time.perf_counter() - t0
+            dist.barrier()
+            local.append((t_own, time.perf_counter() - t0))
+            assert all(not x for tb in busy for x in tb), "a buffer was not handed back"
+            if rank == 0:
+                szs, flat = gatherer.last
+                got = multi.unpack_container(multi.pack_container(szs, flat))
+                assert len(got) == world and got[0] == blobs[(k - 1) % len(blobs)]
+                assert np.array_equal(o.pipeline_decode(got[1]), synth.stack((world * Z, Y, X), seed=500 + (k - 1) % len(blobs))[Z:2 * Z])
+            count[:] = [0] * inflight
+        gs = bench.gather_stats_delta(g0, dict(gatherer.stats))
+        assert gs["gathers_timed"] == 2 * k and len(posted) == 2 * k
+        # bytes of ALL ranks per step, averaged over the steps of the blocks
+        mine = torch.tensor([sum(len(blobs[s % len(blobs)]) for s in range(k))], dtype=torch.int64)
+        dist.all_reduce(mine)
+        assert gs["bytes_gathered_per_step"] == int(mine.item() * 2 / (2 * k))
+        assert gs["gather_ms_per_step"] > 0
+        rep = bench.per_rank_rows(local, k, world, dev, rank)
+        assert rep["world_size_rccl"] == world and rep["world_size_env"] == world and rep["backend"] == "gloo"
+        assert rep["device_index"] == list(range(world)) and len(rep["ms_per_step_own"]) == world
+        assert all(a > 0 and f >= a - 1e-9 for a, f in zip(rep["ms_per_step_own"], rep["ms_per_step_fenced"]))
+        runner.close()
+        gatherer.close()
+        dist.barrier()
+        q.put((rank, "ok"))
+    except Exception as e:   # pragma: no cover
+        import traceback
+        q.put((rank, repr(e) + traceback.format_exc()[-800:]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_step_loop_world2():
+    """the N > 1 path of bench.py -- its own step loop, not only multi.*'s pieces -- under two processes"""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_bench_step_loop, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res
