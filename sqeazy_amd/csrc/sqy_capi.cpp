@@ -1375,6 +1375,17 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
             if (targeted[v]) permutation = false;
             targeted[v] = true;
         }
+        if (!permutation) {
+            // A map that names a place twice (frames of equal metric on the encoder's side: same bytes -- or a crafted blob: not): the
+            // reference's decode walks the frames in order, the LAST one named for a place stays (frame_shuffle_utils.hpp:337-344).
+            // Same here, whatever order the scatter's workgroups run in: the earlier ones are struck from the device's copy of the map.
+            std::vector<uint64_t> last(Z, ~0ull);
+            for (uint64_t i = 0; i < Z; ++i) { uint64_t v; std::memcpy(&v, fs_map.data() + 8 * i, 8); last[v] = i; }
+            for (uint64_t i = 0; i < Z; ++i) {
+                uint64_t v; std::memcpy(&v, fs_map.data() + 8 * i, 8);
+                if (last[v] != i) { const uint64_t none = ~0ull; std::memcpy(fs_map.data() + 8 * i, &none, 8); }
+            }
+        }
         if (ws->small.ensure(std::max<uint64_t>(Z * 8, 4096))) return 1;
         SQY_HIP(hipMemcpyAsync(ws->small.p, fs_map.data(), Z * 8, hipMemcpyHostToDevice, stream));
         SQY_HIP(hipStreamSynchronize(stream));                                   // (pageable source: gone from the host's side before anything can return)
@@ -1437,22 +1448,21 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 // config's decode 1.49 -> 1.1 ms)
                 const uint64_t* remap = nullptr;
                 uint64_t remap_bytes = 0;
-                bool remap_zero = false;
                 if (si >= 1 && pipe.stages[si - 1].kind == StageKind::frame_shuffle && nframes == nchunks && nframes > 1 && total % chunk == 0 &&
                     count_before[si - 1] * (uint64_t)elem_before[si - 1] == total && h.shape.size() == 3) {
                     uint64_t Z = 0, fb = 0;
                     bool permutation = true;
                     if (const int rc = frame_shuffle_prepare(si - 1, Z, fb, permutation)) return rc;
-                    if (fb && fb % chunk == 0 && Z * fb == total) {
+                    // (round-5 advice) only when the map is a permutation: with a frame named twice -- frames of equal metric on the encoder's
+                    // side, or a crafted blob -- several LZ4 frames would decode into the same place at once, and the ring kernels read
+                    // matches that reach behind their ring back from that place.  Then: plain decode, the stage's own inverse behind it.
+                    if (fb && fb % chunk == 0 && Z * fb == total && permutation) {
                         remap = static_cast<const uint64_t*>(ws->small.p);
                         remap_bytes = fb;
-                        remap_zero = !permutation;
                     }
                 }
                 uint8_t* out = out_buf(remap ? si - 1 : si, total);
                 if (!out) return 1;
-                // (frames nobody names come out as zeros, as behind the stage's own inverse below)
-                if (remap_zero) SQY_HIP(hipMemsetAsync(out, 0, total, stream));
                 uint32_t bad = 0;
                 bool decoded = false;
                 // ONE block-linked frame (nthreads = 1 on the encoder's side): every block at once with the history as an unknown, the

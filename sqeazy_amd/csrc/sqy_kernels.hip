@@ -5560,7 +5560,9 @@ void frame_scatter_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ 
     const uint64_t f = blockIdx.x / blocks_per_frame;
     const uint32_t part = blockIdx.x % blocks_per_frame;
     const uint8_t* s = in + f * frame_bytes;
-    uint8_t* d = out + map[f] * frame_bytes;
+    const uint64_t to = map[f];
+    if (to == ~0ull) return;                                   // a later frame of the stream goes to the same place: that one counts (host)
+    uint8_t* d = out + to * frame_bytes;
     const uint64_t nvec = frame_bytes / 16;
     if (((reinterpret_cast<uintptr_t>(s) | reinterpret_cast<uintptr_t>(d)) & 15) == 0) {
         const uint64_t step = (uint64_t)blocks_per_frame * 256;

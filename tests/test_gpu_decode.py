@@ -697,3 +697,122 @@ def test_chunked_layout_two_wavefronts_damaged_blocks(sqy, oracle, options):
             options("decode_two_waves", two)
             rc, back = sqy.decode(bytes(bad))
             assert rc != 0 or back.size == data.size
+
+
+# ---- round 6 (round-5 advice) ---------------------------------------------------------------------------------------------------
+def test_frame_shuffle_crafted_map_names_a_place_twice(sqy, oracle):
+    """A reorder_map that sends two frames with DIFFERENT contents to one place (no encoder writes that: its duplicates are frames of
+    equal bytes): the LZ4 frames are then not decoded straight to their places (several would decode into one at once, and the ring
+    kernels read back from there) but to the stream, and the shuffle's inverse keeps the last frame named -- as the reference's loop does."""
+    import base64
+    rng = np.random.default_rng(9)
+    for dtype, shape in ((np.uint8, (6, 512, 512)), (np.uint16, (5, 512, 256))):
+        hi = 256 if dtype == np.uint8 else 4096
+        vol = (rng.integers(0, hi, shape) * (rng.random(shape) < 0.3)).astype(dtype)      # compressible: matches reach far back
+        blob = bytearray(oracle.pipeline_encode("frame_shuffle->lz4", vol))
+        hs = oracle.header_unpack(bytes(blob))["size"]
+        head = bytes(blob[:hs])
+        a = head.index(b"<verbatim>") + len(b"<verbatim>")
+        b = head.index(b"<\\/verbatim>")
+        m = np.frombuffer(base64.b64decode(head[a:b]), dtype=np.uint64).copy()
+        m[1] = m[0]; m[3] = m[0]                                                          # three frames to one place
+        enc = base64.b64encode(m.tobytes())
+        assert len(enc) == b - a
+        blob[a:b] = enc
+        want = oracle.pipeline_decode(bytes(blob))
+        for _ in range(3):
+            rc, back = sqy.decode(bytes(blob))
+            assert rc == 0
+            assert np.array_equal(back, want)
+
+
+def _lz4_block_sequences(block):
+    """(token position, literal length, offset position, match length) of every sequence of one LZ4 block"""
+    seqs, i, n = [], 0, len(block)
+    while i < n:
+        tok = i
+        t = block[i]; i += 1
+        lit = t >> 4
+        if lit == 15:
+            while True:
+                v = block[i]; i += 1; lit += v
+                if v != 255:
+                    break
+        i += lit
+        if i >= n:
+            seqs.append((tok, lit, None, 0))
+            break
+        offp = i; i += 2
+        ml = t & 15
+        if ml == 15:
+            while True:
+                v = block[i]; i += 1; ml += v
+                if v != 255:
+                    break
+        seqs.append((tok, lit, offp, ml + 4))
+    return seqs
+
+
+@pytest.mark.parametrize("pipeline,nframes,cfg", [("lz4", 6, ""), ("lz4", 900, "(blocksize_kb=64,framestep_kb=64)"), ("frame_shuffle->lz4", 8, "")])
+def test_damaged_blocks_never_write_outside_the_volume(sqy, oracle, options, pipeline, nframes, cfg):
+    """Decode through SQYAMD_Decode_UI8_Device into a buffer with canaries in front of and behind the volume; blocks damaged on purpose:
+    an offset that reaches in front of the frame's first byte, a literal length that runs past the block's end, a match length that
+    overflows the block -- and random bytes.  Both LZ4 decode kernels (two wavefronts per frame / one), the 64 KiB and the 16 KiB ring
+    (6 and 900 compressed frames), and frames decoded straight to their places behind a frame_shuffle.  The call may refuse or return
+    different voxels; it may not touch a byte outside the volume, and it must return."""
+    import ctypes
+    import torch
+    rng = np.random.default_rng(31)
+    chunk = (64 << 10) if cfg else (256 << 10)
+    if pipeline == "lz4":
+        n = nframes * chunk - 4321
+        data = dict(_two_wave_streams(n, 13))["literal_runs"]
+        vol = data.reshape(1, 1, -1)
+    else:
+        vol = dict(_two_wave_streams(nframes * chunk, 17))["literal_runs"].reshape(nframes, 512, 512)
+        vol = vol + (np.arange(nframes, dtype=np.uint8) * 3)[:, None, None]           # distinct frame metrics: the map is a permutation
+    blob = oracle.pipeline_encode(pipeline + cfg, vol, nthreads=2)
+    hs = oracle.header_unpack(blob)["size"]
+    # the first two compressed frames' blocks
+    frames, off = [], hs
+    while off < len(blob) and len(frames) < 3:
+        size = int.from_bytes(blob[off + 7:off + 11], "little")
+        raw, size = bool(size & 0x80000000), size & 0x7fffffff
+        if not raw:
+            frames.append((off + 11, size))
+        off += 11 + size + 4
+    assert frames
+    dev = torch.device("cuda", 0)
+    PAD = 1 << 16
+    L = sqy.lib()
+    L.SQYAMD_Decode_UI8_Device.argtypes = [ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p, ctypes.c_long, ctypes.c_void_p]
+    d_out = torch.empty(PAD + vol.size + PAD, dtype=torch.uint8, device=dev)
+
+    def damaged():
+        for b0, sz in frames:
+            seqs = _lz4_block_sequences(blob[b0:b0 + sz])
+            first = next(s for s in seqs if s[2] is not None)
+            mid = seqs[len(seqs) // 2]
+            x = bytearray(blob); x[b0 + first[2]:b0 + first[2] + 2] = b"\xff\xff"; yield "offset in front of the frame", x
+            x = bytearray(blob); x[b0 + mid[0]] |= 0xF0; x[b0 + mid[0] + 1:b0 + mid[0] + 1 + 64] = b"\xff" * 64; yield "literal length past the block", x
+            if mid[2] is not None:
+                x = bytearray(blob); x[b0 + mid[0]] |= 0x0F
+                p = b0 + mid[2] + 2
+                x[p:p + 600] = b"\xff" * 600; yield "match length overflows the block", x
+            x = bytearray(blob); x[b0 + sz - 12:b0 + sz] = b"\x1f" + b"\x00" * 11; yield "a match in the last bytes", x
+        for _ in range(6):
+            x = bytearray(blob)
+            at = hs + 11 + int(rng.integers(0, len(blob) - hs - 64))
+            x[at:at + 8] = bytes(rng.integers(0, 256, 8, dtype=np.uint8)); yield "random bytes", x
+
+    for what, bad in damaged():
+        d_src = torch.frombuffer(bytearray(bad), dtype=torch.uint8).to(dev)
+        for two in (1, 0):
+            options("decode_two_waves", two)
+            d_out.fill_(0xC3)
+            rc = L.SQYAMD_Decode_UI8_Device(ctypes.c_void_p(d_src.data_ptr()), ctypes.c_long(len(bad)), ctypes.c_void_p(d_out.data_ptr() + PAD),
+                                            ctypes.c_long(vol.size), None)
+            torch.cuda.synchronize()
+            assert bool((d_out[:PAD] == 0xC3).all()) and bool((d_out[PAD + vol.size:] == 0xC3).all()), (what, two, "bytes outside the volume were written")
+            if rc == 0:
+                assert d_out[PAD:PAD + vol.size].numel() == vol.size

@@ -268,3 +268,51 @@ def test_headline_serial_layout_equals_the_reference_digest(sqy, prefix):
     assert rc == 0 and np.array_equal(back, vol.cpu().numpy())
     del vol, out
     torch.cuda.empty_cache()
+
+
+# ---- every full-size slab of the sharded volumes ---------------------------------------------------------------
+# tests/golden/headline_slabs.json (oracle/gen_golden.py --headline-slabs, build container only): all eight 2048 x 2048 x 256 slabs of
+# north_star's 2048^3 'bitswap1->lz4' volume from the REFERENCE pieces (SSE bit-plane gather + liblz4 1.9.3), and the slabs around the
+# shell's centre of configs[2] / configs[4] from the oracle.  The shell sweeps through z: slabs 3 and 4 hold 12-bit shell voxels over whole
+# frames, data slab 0 never sees.  Encoded HERE with ONE call for the whole volume (SQYAMD_PipelineEncode_Slabs_UI16_Device, what bench.py's
+# north_star leg times), so that leg's "blobs equal the single calls" is no longer the only check of slabs 1..7.
+def _slab_goldens(pipeline, z_total):
+    import json, os
+    path = os.path.join(os.path.dirname(__file__), "golden", "headline_slabs.json")
+    if not os.path.exists(path):
+        return {}
+    with open(path) as f:
+        H = json.load(f)
+    return {e["slab"]: e for e in H["slabs"] if e["pipeline"] == pipeline and e["z_total"] == z_total}
+
+
+@pytest.mark.parametrize("pipeline,z_total,want_slabs", [("bitswap1->lz4", 2048, tuple(range(8))), ("diff3x3x1->bitswap1->lz4", 2048, (3, 4)),
+                                                          ("quantiser->bitswap1->lz4", 1024, (1, 2))])
+def test_full_size_slabs_equal_the_golden_digests(sqy, pipeline, z_total, want_slabs):
+    import torch
+    G = _slab_goldens(pipeline, z_total)
+    missing = [s for s in want_slabs if s not in G]
+    assert not missing, "tests/golden/headline_slabs.json lacks slabs %s of %s" % (missing, pipeline)
+    dev = torch.device("cuda", 0)
+    shape = (z_total, 2048, 2048)
+    nslabs = z_total // 256
+    vol = torch.empty(shape, dtype=torch.uint16, device=dev)
+    for s in range(nslabs):                                                     # built slab by slab (the generator's temporaries are 8x a slab)
+        vol[256 * s:256 * (s + 1)] = synth.stack_torch((256, 2048, 2048), np.uint16, dev, z_offset=256 * s, z_total=z_total)
+    cap = sqy.max_compressed_length(pipeline, (256, 2048, 2048), np.uint16)
+    out = torch.full((cap * nslabs,), 0x5A, dtype=torch.uint8, device=dev)
+    rc, offs, lens = sqy.encode_slabs_device(pipeline, vol.data_ptr(), shape, np.uint16, nslabs, out.data_ptr(), cap, inflight=3)
+    assert rc == 0
+    for s in want_slabs:
+        g = G[s]
+        if s == want_slabs[0]:
+            assert _sha(vol[256 * s:256 * (s + 1)].cpu().numpy().tobytes()) == g["voxels_sha256"]      # same voxels as the generator's
+        assert lens[s] == g["blob_bytes"], "slab %d: %d bytes, golden %d" % (s, lens[s], g["blob_bytes"])
+        blob = out[offs[s]:offs[s] + lens[s]].cpu().numpy().tobytes()
+        hs = g["header_bytes"]
+        assert sqy.header_size(blob[:65536]) == hs
+        assert _sha(blob[hs:]) == g["payload_sha256"], "slab %d of %s: payload differs from %s" % (s, pipeline, g["source"])
+        assert _sha(blob) == g["blob_sha256"]
+        del blob
+    del vol, out
+    torch.cuda.empty_cache()

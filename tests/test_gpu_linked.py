@@ -177,3 +177,53 @@ def test_block_parallel_other_block_layouts(sqy, oracle, cfg, nthreads):
         assert blob == want, (cfg, name, nthreads, len(blob), len(want))
         rc, back = sqy.decode(blob)
         assert rc == 0 and np.array_equal(back.reshape(-1), data), (cfg, name)
+
+
+@pytest.mark.parametrize("cfg", ["", "blocksize_kb=64"])
+def test_given_up_blocks_in_linked_frames(sqy, oracle, options, capfd, cfg):
+    """Regression for round 5's GPU memory fault at address 0 (gpurun_out/r05_sc1.log, r05_t1.log; DESIGN.md 3 "The fault of round 5"):
+    a wavefront that GUESSES a block's table (block-parallel parse, mode 1) and meets a stream of short sequences gives the block up --
+    `redo_dense` -- and the first build of that rule still appended such a block to the chunked layout's dense list, which block-linked
+    launches do not have (null).  Here: one frame of linked blocks in which blocks that are given up (a match every few bytes: > 2048
+    short matches per block) are followed by good ones and by more of their kind, so that the verify / parse-again rounds see a given-up
+    block in front of a good one, runs of several blocks, and a second round whose run list is shorter than the first's."""
+    rng = np.random.default_rng(77)
+    B = (64 << 10) if "64" in cfg else (256 << 10)
+    kinds = "gdgddggdgdddgg"                                            # g = good, d = dense (given up while guessing)
+    parts = []
+    word = rng.integers(0, 256, 3000, dtype=np.uint8)
+    for i, k in enumerate(kinds):
+        if k == "d":
+            parts.append(rng.integers(0, 2, B, dtype=np.uint8))        # 0 / 1 bytes: a short match every few bytes
+        else:
+            p = np.tile(word, B // word.size + 1)[:B].copy()
+            p[::997] ^= (i + 1)
+            parts.append(p)
+    data = np.concatenate(parts + [rng.integers(0, 2, 12345, dtype=np.uint8)])
+    vol = data.reshape(1, 1, -1)
+    pipe = "lz4(%s)" % cfg if cfg else "lz4"
+    want = oracle.pipeline_encode(pipe, vol, nthreads=1)
+    options("block_parallel_stats", 1)
+    capfd.readouterr()
+    for _ in range(2):                                                  # (the second call reuses the workspace: stale tables and lists in it)
+        sqy.profile_reset(); sqy.profile_enable(True)
+        rc, blob = sqy.encode(pipe, vol, nthreads=1)
+        sqy.profile_enable(False)
+        assert rc == 0
+        assert blob == want
+        assert "lz4_linked_redo" in _profile_names(sqy), "no block was parsed again: the given-up path did not run"
+    err = capfd.readouterr().err
+    rounds = [ln for ln in err.splitlines() if "lz4 block-parallel: round" in ln]
+    assert rounds, err[-500:]
+    nruns = [int(ln.split(" runs")[0].split()[-1]) for ln in rounds]
+    first = nruns[:len(nruns) // 2]                                     # the first call's rounds (both calls print the same)
+    # blocks were given up and parsed again (round 0 lists them), every later round's list is no longer than the one before, the last is empty
+    assert first[0] >= 1 and first[-1] == 0 and all(a >= b for a, b in zip(first, first[1:])), first
+    nbad = [int(ln.split(" of ")[0].split()[-1]) for ln in rounds][:len(first)]
+    assert nbad[0] >= kinds.count("d"), (nbad, "every dense block is given up while its table is guessed")
+    rc, back = sqy.decode(blob)
+    assert rc == 0 and np.array_equal(back.reshape(-1), data)
+    # the frame walk gives the same bytes
+    options("block_parallel", 0)
+    rc, blob2 = sqy.encode(pipe, vol, nthreads=1)
+    assert rc == 0 and blob2 == want
