@@ -166,6 +166,35 @@ def host_abi(vol_host, shape):
         best = dt if best is None else min(best, dt)
     res = {"value": round(vol_host.nbytes / best / 1e9, 3), "unit": "GB/s", "ms_per_call": round(best * 1e3, 2),
            "entry_point": "SQY_PipelineEncode_UI16 (host pointers: %.2f GB up, kernels, %.2f GB down), best of 4" % (vol_host.nbytes / 1e9, n.value / 1e9)}
+    # Two calls in flight from two host threads (the reference's entry points are re-entrant): inside ONE call the two transfers cannot
+    # overlap -- the blob starts at dst[0], its stored tail (99.5 % of it) sits behind the compressed head, whose size is known only when the
+    # whole volume has been uploaded and parsed (every bit plane spans all voxels) -- but the upload of one call overlaps the download of
+    # the other (PCIe is full duplex): the rate a caller with two buffers gets
+    try:
+        vol2 = vol_host.copy()
+        dst2 = np.zeros(cap, np.uint8)
+        errs = []
+
+        def one(v, d, reps):
+            nn = ctypes.c_long(0)
+            for _ in range(reps):
+                if L.SQY_PipelineEncode_UI16(PIPELINE.encode(), ctypes.c_void_p(v.ctypes.data), shp, 3, ctypes.c_void_p(d.ctypes.data), ctypes.byref(nn), 0):
+                    errs.append("rc")
+        best2 = None
+        for _ in range(2):
+            ths = [threading.Thread(target=one, args=(v, d, 3)) for v, d in ((vol_host, dst), (vol2, dst2))]
+            t0 = time.perf_counter()
+            [t.start() for t in ths]
+            [t.join() for t in ths]
+            dt = time.perf_counter() - t0
+            best2 = dt if best2 is None else min(best2, dt)
+        if errs:
+            raise RuntimeError("SQY_PipelineEncode_UI16 failed with two calls in flight")
+        res["two_calls_in_flight"] = {"value": round(6 * vol_host.nbytes / best2 / 1e9, 3), "unit": "GB/s", "ms_per_call": round(best2 / 6 * 1e3, 2),
+                                      "what": "two host threads, three SQY_PipelineEncode_UI16 calls each on buffers of their own, aggregate; best of 2"}
+        del vol2, dst2
+    except Exception as e:   # reported, never required
+        res["two_calls_in_flight"] = {"error": repr(e)}
     # what a caller of the reference gets who changes nothing: nthreads = 1 (one block-linked frame) and SQY_Decode_UI16 of that blob
     try:
         best1 = None
@@ -530,7 +559,9 @@ def main():
     sqeazy_amd.lib()   # fails loudly when the HIP library has not been built
     # The caller threads' streams below carry nothing but these calls: the library may chain the bit-plane transposes of the calls in
     # flight across them (a hipStreamWaitEvent between caller streams; off unless the caller says so, include/sqeazy_amd.h).  +3 %.
-    sqeazy_amd.set_option("transpose_chain_caller_streams", 1)
+    # (round-5 advice: scoped -- `with sqeazy_amd.option(...)` around the legs with calls in flight only, the line says what `value` was
+    # measured under, and the same leg with the option at its default sits next to it as `default_options`)
+    CHAIN = ("transpose_chain_caller_streams", 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
 
@@ -632,10 +663,23 @@ def main():
         run_steps(args.warmup)
     sqeazy_amd.profile_reset()
     sqeazy_amd.profile_enable(True)
-    times, payload = timed_blocks(False)
+    with sqeazy_amd.option(*CHAIN):
+        times, payload = timed_blocks(False)
+        options_timed = {k: sqeazy_amd.get_option(k) for k in ("transpose_chain", "transpose_chain_caller_streams", "block_parallel")}
     sqeazy_amd.profile_enable(False)
     prof = sqeazy_amd.profile_get()
     nblocks = len(times)
+    # the same leg as an unchanged caller gets it: every option at its default (the transposes of caller streams are not chained)
+    default_leg = None
+    if world == 1 and not args.quick:
+        fence()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        fence()
+        dt0 = time.perf_counter() - t0
+        default_leg = {"value": round(nbytes * args.steps / dt0 / 1e9, 1), "unit": "GB/s", "ms_per_step": round(dt0 / args.steps * 1e3, 4),
+                       "options": {k: sqeazy_amd.get_option(k) for k in ("transpose_chain", "transpose_chain_caller_streams")},
+                       "timing": "one block of %d steps" % args.steps}
     # What was timed is also checked (after the clock stopped): the LAST blob of every caller thread is hashed and compared with the
     # digest the reference pieces themselves give for this stack (tests/golden/headline.json: reference SSE bit-plane gather + liblz4
     # 1.9.3 frames, oracle/gen_golden.py --headline; a data file, nothing of oracle/ runs here)
@@ -667,10 +711,11 @@ def main():
     per_rank = per_rank_report(False)
     gather_times, gather_stats, per_rank_gather = None, None, None
     if gatherer is not None:
-        run_steps(max(2, inflight), True)
-        g0 = dict(gatherer.stats)
-        gather_times, _ = timed_blocks(True)
-        gather_stats = gather_stats_delta(g0, dict(gatherer.stats))
+        with sqeazy_amd.option(*CHAIN):
+            run_steps(max(2, inflight), True)
+            g0 = dict(gatherer.stats)
+            gather_times, _ = timed_blocks(True)
+            gather_stats = gather_stats_delta(g0, dict(gatherer.stats))
         per_rank_gather = per_rank_report(True)
 
     # other operating points of the same step, for comparison with earlier rounds (round-3 advice): fewer calls in flight, and the entry
@@ -708,8 +753,9 @@ def main():
             return {"value": round(nbytes * args.steps / best / 1e9, 1), "unit": "GB/s", "ms_per_step": round(best / args.steps * 1e3, 4),
                     "calls_in_flight": n_inflight, "entry_point": fn_name, "timing": "best of 6 blocks of %d steps" % args.steps}
         try:
-            alt["3_in_flight_DeviceAt"] = alt_point(min(3, inflight), "SQYAMD_PipelineEncode_UI16_DeviceAt")
-            alt["4_in_flight_Device_blob_at_offset_0"] = alt_point(min(4, inflight), "SQYAMD_PipelineEncode_UI16_Device")
+            with sqeazy_amd.option(*CHAIN):
+                alt["3_in_flight_DeviceAt"] = alt_point(min(3, inflight), "SQYAMD_PipelineEncode_UI16_DeviceAt")
+                alt["4_in_flight_Device_blob_at_offset_0"] = alt_point(min(4, inflight), "SQYAMD_PipelineEncode_UI16_Device")
             alt["note"] = ("round 3's headline was 4 in flight / DeviceAt / GPU_MAX_HW_QUEUES=8 as well; round 2's was 3 in flight / _Device; the hardware-queue "
                            "count is read once by the HIP runtime and cannot be varied inside one process")
         except Exception as e:   # reported, never required
@@ -801,7 +847,9 @@ def main():
                 ", slab blobs stay sharded on their GPUs, sizes all_gathered over RCCL" if world > 1 else ""),
                 "input_bytes_per_gpu": nbytes, "payload_bytes": payload_bytes, "blob_bytes": payload, "calls_in_flight_per_gpu": inflight,
                 "env": {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
-                "options": {k: sqeazy_amd.get_option(k) for k in ("transpose_chain", "transpose_chain_caller_streams", "block_parallel")},
+                "options": options_timed, "options_note": "transpose_chain_caller_streams is OFF by default (include/sqeazy_amd.h): `value` is measured with the "
+                                                         "caller opting in; `default_options` is the same leg without",
+                "default_options": default_leg,
                 "single_call_latency_ms": round(single_ms, 4),
                 "one_call_at_a_time": {"value": round(nbytes / (single_ms / 1e3) / 1e9, 1), "unit": "GB/s",
                                        "roofline_frac_whole_call": round(algo_bytes / (single_ms / 1e3) / 1e9 / HBM_PEAK_GBS, 5)}},

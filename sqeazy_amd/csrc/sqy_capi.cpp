@@ -1005,13 +1005,27 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                             SQY_HIP(hipMemcpyAsync(ok.data(), d_ok, list_bytes, hipMemcpyDeviceToHost, stream));
                             SQY_HIP(hipStreamSynchronize(stream));
                             // runs of blocks that did not start from the true table: one wavefront each, in order, from the table in front
-                            uint64_t nruns = 0;
+                            // (round-5 advice) a run is parsed by ONE wavefront, block after block: at most kRunMax blocks of it per launch (the
+                            // rest keep failing the check and are taken by the next rounds, each from the table the last one left) -- the top
+                            // plane of a quantised stack fails as one run of 511 blocks, seconds of work: sixteen launches of a fraction of a
+                            // second instead of one kernel that runs for seconds; and the caller is told, once, what layout to ask for.
+                            constexpr uint64_t kRunMax = 32;
+                            uint64_t nruns = 0, longest_run = 0;
                             for (uint64_t k = 0; k < nblocks; ++k) {
                                 if (ok[k]) continue;
                                 uint64_t e = k;
                                 while (e + 1 < nblocks && !ok[e + 1] && !(plan.blocks[e + 1].flags & 1u)) ++e;
-                                wfirst[nruns] = (uint32_t)k; wlast[nruns] = (uint32_t)e; ++nruns;
+                                longest_run = std::max(longest_run, e - k + 1);
+                                wfirst[nruns] = (uint32_t)k; wlast[nruns] = (uint32_t)std::min(e, k + kRunMax - 1); ++nruns;
                                 k = e;
+                            }
+                            if (longest_run > 4 * kRunMax) {
+                                static std::atomic<bool> told{false};
+                                if (!told.exchange(true))
+                                    std::fprintf(stderr, "[sqeazy]\t lz4: %llu blocks in a row of this block-linked frame (nthreads = 1) can only be parsed one after "
+                                                         "the other -- a stream of short sequences, whose table no guess reproduces -- by one wavefront, "
+                                                         "~10 ms per block.  The chunked layout (nthreads = 0 or > 1: independent frames, same decoder) "
+                                                         "takes milliseconds for the same data.\n", (unsigned long long)longest_run);
                             }
                             if (g_opt.block_parallel_stats.load()) {
                                 uint64_t nbad = 0;
@@ -1022,7 +1036,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                 std::fprintf(stderr, "\n");
                             }
                             if (nruns == 0) break;
-                            if (round > nblocks) {
+                            if (round > nblocks + 8) {
                                 std::fprintf(stderr, "[sqeazy]\t lz4: the block-parallel parse did not settle\n");
                                 return 1;
                             }

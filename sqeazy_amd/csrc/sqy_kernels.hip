@@ -766,7 +766,6 @@ extern "C" __attribute__((visibility("default"))) int SQYAMD_Exp_Set_Buffer(void
 #define SQY_EXP(...)
 #endif
 constexpr uint32_t LZ4_RINGLESS_U = 64u * 15u;   // probes since the last match from which on the batches stride over the ring (step >= 16)
-constexpr uint32_t LZ4_NOHIT_U = 0u;  //          // probes since the last match from which on batches are first tried as "nothing found" (tags only)
 constexpr uint32_t LZ4_WIN_LEAN = 8192, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 template <uint32_t LZ4_WIN>
@@ -934,19 +933,16 @@ __device__ __forceinline__ uint32_t common16(const Lz4Window& w, uint32_t a, uin
 // issues almost no global stores, so the s_waitcnt vmcnt(0) in front of the occasional global LOAD (far
 // candidate, window refill) no longer queues behind a stream of tiny stores on the critical path.
 constexpr uint32_t LZ4_OB = 2048;
-constexpr uint32_t LZ4_COUNT_ONLY_LIT = 256;     // literals of one sequence from which on a chunk that is not ahead stops writing (count_only)
 
 struct Lz4Out {
     SQY_GLB uint8_t* dst;        // chunk's scratch (global)
     lds_u8* ob;                  // LDS stage
     uint32_t base;               // dst offset of ob[0]; bytes [base, op) live in the stage
     int lane;
-    bool mute = false;           // count only (see `count_only` in lz4_chunks_kernel): staged bytes are dropped instead of written
 
     // write everything staged; afterwards base == op
     __device__ __forceinline__ void flush(uint32_t op)
     {
-        if (mute) { base = op; return; }
         wave_lds_sync();                                       // staged bytes were written by other lanes
         const uint32_t cnt = op - base;
         const uint32_t nvec = cnt >> 4;
@@ -1234,16 +1230,12 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     uint32_t op = 0, anchor = p0;
     bool failed = false;
     bool redo_dense = false;             // first pass: this chunk is left to the DENSE kernel
-    // (round 6) COUNT ONLY.  A chunk of noise with a short match every kilobyte or two (a noisy bit plane where the data has structure:
-    // plane 8 of the bench stack where the shell is tangent, 150 matches in 256 KiB) ends up stored -- its sequences cost more than
-    // they save -- but until the output limit says so, near the chunk's end, every sequence copies its kilobytes of literals: global
-    // stores that every later global load of the wave queues behind (one vmcnt), 0.25 ms of such a chunk's 0.65 alone and 1.1 ms of its
-    // 1.8 with other calls' transposes streaming -- the wave that sets the length of the whole launch in flight.  So: from the first
-    // sequence with 256 literals or more that finds the chunk NOT ahead (output so far >= input consumed), nothing is written any
-    // more; sizes and limit checks go on exactly as before.  Fails as it would have: stored, nothing lost.  Fits after all (rare:
-    // the data turned compressible later in the chunk): the chunk goes onto the dense kernel's list and is parsed again, with output.
-    bool count_only = false;
-    const bool may_count_only = !LINKED && !DENSE && !ACCEL && redo_list != nullptr;
+    // (round 6, built, exact, measured, not kept: COUNT ONLY -- a chunk of noise with a short match every kilobyte or two, such as plane 8
+    // of the bench stack where the shell is tangent, ends up stored, but until the output limit says so every sequence copies its
+    // kilobytes of literals: 1.1 ms of such a chunk's 1.8 with calls in flight.  From the first long literal run that found the chunk
+    // 256 bytes behind its input on, nothing was written any more, sizes and limit checks went on, a chunk that fit after all went onto
+    // the dense kernel's list.  That chunk: 1.84 -> 0.75 ms in flight -- and the bench did not move (the transposes set the pace, not the
+    // slowest chunk), the C3 slab's launch was 3 % slower for the extra code: profiles/r06_experiments.txt.)
 
     if (n >= LZ4_MINLENGTH) {
         const uint32_t mflimitPlusOne = pend - LZ4_MFLIMIT + 1;
@@ -1777,63 +1769,37 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // atomics of one instruction did not run in lane order) proves nothing; then, and on any tag hit, the buckets are put
             // back and the batch goes through the generic code below.
             // (first pass and linked frames only: the dense kernel sees chunks of short sequences, and is 3 % slower with this loop compiled in)
-            // (round 6) From the FIRST batch of a search on, not only once the step has reached 16.  The fifteen batches in front of that
-            // went through the generic code (~2.3 us each alone, twice that with other calls' transposes streaming: more than a noise
-            // chunk's other seventy-five together) -- and the chunks that set the length of a launch with calls in flight are not the
-            // sparse planes' but those of a NOISY plane where the shell is tangent (plane 8 of the bench stack, chunk 203: 150 short
-            // matches in 256 KiB of noise, every one of them found after one to four batches that find nothing, 318 generic batches,
-            // 0.7 ms alone and 1.7 ms in flight).  While the step is below 16 the sequences come from the ring (one LDS round trip, no
-            // global load; a batch that then does hold a match goes to the generic code below as before).
-            if (!DENSE && !ACCEL && !batch_done && U >= LZ4_NOHIT_U && put2 == 0xffffffffu) {
-                // geometry of the batch that starts at probe index u0 from position p: this lane's probe, where the next batch begins
-                auto geom = [&](uint32_t p, uint32_t u0, uint32_t& pos, uint32_t& nxt) {
-                    const uint32_t s0 = (62 + u0) >> 6;
-                    const uint32_t s_first = s0 ? s0 : 1u;
-                    const uint32_t ustar = 64 * (s_first + 1) - 62;
-                    const uint32_t u = u0 + lane;
-                    pos = p + s_first * lane + (u > ustar ? u - ustar : 0u);
-                    nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
-                };
-                // one batch: true = proved empty (P, U moved on), false = leave (table as it was; P, U name the batch to redo)
-                auto prove = [&](uint64_t seq, uint32_t pos, uint32_t nxt) -> bool {
-                    const uint32_t h = lz4_hash5(seq);
-                    const uint32_t mytag = tag_of((uint32_t)seq);
-                    const uint32_t mine = (pos << tsh) | mytag;
-                    const uint32_t oe = table[h];
-                    const uint32_t seen = atomicMax(&table[h], mine);
+            // (round 6, built, exact, measured, not kept: the same proof from the second batch of a search on -- steps below 16, the
+            // sequences out of the ring -- and the loads of the batches at step 16 and more issued four batches ahead (where the search probes
+            // is a closed form while nothing is found).  A chunk of noise 75 -> 52 -> 35 us alone, the noise planes' share of the slot time
+            // -40 %; with calls in flight the bench stayed where it was (without the loads ahead) or lost 3 % (with them: they take HBM
+            // bandwidth from the other calls' transposes, which set the pace), and the sparse planes of a diff3x3x1 residual lost up to 12 %
+            // when the proof was tried right behind the lean loop: profiles/r06_experiments.txt.)
+            while (!DENSE && !ACCEL && !batch_done && U >= LZ4_RINGLESS_U && put2 == 0xffffffffu) {
+                const uint32_t s_first = (62 + U) >> 6;
+                const uint32_t ustar = 64 * (s_first + 1) - 62;
+                const uint32_t u = U + lane;
+                const uint32_t pos = P + s_first * lane + (u > ustar ? u - ustar : 0u);
+                const uint32_t nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
+                if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
+                const uint64_t seq = glb_ld_u64(w.src + pos);              // (the ring was left behind at these strides)
+                const uint32_t h = lz4_hash5(seq);
+                const uint32_t mytag = tag_of((uint32_t)seq);
+                const uint32_t mine = (pos << tsh) | mytag;
+                const uint32_t oe = table[h];
+                const uint32_t seen = atomicMax(&table[h], mine);
+                wave_lds_sync();
+                const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
+                const uint32_t sp = seen >> tsh;
+                const bool in_batch = sp >= P && seen != oe;
+                const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
+                if (ballot(trouble)) {
+                    table[h] = oe;                                          // (same value from every probe of a bucket)
                     wave_lds_sync();
-                    const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
-                    const uint32_t sp = seen >> tsh;
-                    const bool in_batch = sp >= P && seen != oe;
-                    const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
-                    if (ballot(trouble)) {
-                        table[h] = oe;                                          // (same value from every probe of a bucket)
-                        wave_lds_sync();
-                        return false;
-                    }
-                    P = lane_read(nxt, 63);
-                    U += 64;
-                    return true;
-                };
-                // steps below 16: out of the ring
-                bool go_on = true;
-                while (U < LZ4_RINGLESS_U) {
-                    uint32_t pos, nxt;
-                    geom(P, U, pos, nxt);
-                    if (ballot(nxt <= mflimitPlusOne) != ~0ull) { go_on = false; break; }
-                    w.ensure(P);
-                    if (!prove(w.rd64(pos), pos, nxt)) { go_on = false; break; }
+                    break;
                 }
-                // step 16 and more: the ring is left behind, the sequences come straight from global memory.
-                // (round 6, measured: these loads issued four batches ahead -- where the search probes is a closed form while nothing is
-                // found -- take a chunk of noise from 52 to 35 us alone; with calls in flight they take HBM bandwidth from the other calls'
-                // transposes, which set the pace: the step 3 % slower, exact as it was.  One batch at a time.)
-                while (go_on) {
-                    uint32_t pos, nxt;
-                    geom(P, U, pos, nxt);
-                    if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
-                    if (!prove(glb_ld_u64(w.src + pos), pos, nxt)) break;
-                }
+                P = lane_read(nxt, 63);
+                U += 64;
             }
             SQY_EXP(x_lap(2);)                                  // 2: batches proved empty
             SQY_EXP(x_ngen += 1;)
@@ -2092,12 +2058,7 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             const uint32_t token = ((lit < 15 ? lit : 15u) << 4) | (matchCode < 15 ? matchCode : 15u);
             const uint32_t seq_bytes = 1 + lit_ext + lit + 2 + ml_ext;
 
-            if (may_count_only && !count_only && lit >= LZ4_COUNT_ONLY_LIT && op >= anchor - p0) { count_only = true; o.mute = true; }
-            if (count_only) {
-                op += seq_bytes;
-                o.base = op;
-            }
-            else if (seq_bytes <= 64 && lit < 15) {
+            if (seq_bytes <= 64 && lit < 15) {
                 // whole sequence at once into the LDS stage: lane k writes byte k
                 o.reserve(op, seq_bytes);
                 const uint32_t k = (uint32_t)lane;
@@ -2162,8 +2123,6 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
         const uint32_t lastRun = pend - anchor;
         if (op + lastRun + 1 + (lastRun + 255 - 15) / 255 > olimit) {
             failed = true;
-        } else if (count_only) {
-            redo_dense = true;                                  // it fits after all: parsed again, with output, by the dense kernel
         } else {
             if (lastRun >= 15) {
                 const uint32_t rest = lastRun - 15;

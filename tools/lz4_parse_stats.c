@@ -15,7 +15,7 @@ static inline uint32_t hash5(const uint8_t* p) { return (uint32_t)(((rd64(p) << 
 typedef struct {
     long seqs, probes, hit_lean, hit_u15_63, hit_later, batches_nohit_lt960, batches_nohit_ge960, batches_hit_lt960, batches_hit_ge960;
     long ml_lt12, ml_lt64, ml_lt1024, ml_ge1024, far8k, tooFar, zero_lit, out;
-    long hit_first64_after_reset;
+    long hit_first64_after_reset; long co_at; long shorts_max; long def_at[5];
 } stats_t;
 
 static int parse(const uint8_t* src, int n, stats_t* s)
@@ -54,6 +54,8 @@ static int parse(const uint8_t* src, int n, stats_t* s)
         {
             const long lit = ip - anchor;
             if (op + lit + (2 + 1 + 5) + lit / 255 > olimit) { s->out = op; return 0; }
+            if (!s->co_at && lit >= 256 && (anchor - src) >= 32768 && op >= (anchor - src) + 256) s->co_at = (anchor - src) + 1;   // the count-only rule of round 6 (measured, not kept)
+            { static const long cp[5] = {16384, 32768, 65536, 131072, 196608}; for (int i = 0; i < 5; ++i) if (!s->def_at[i] && (anchor - src) >= cp[i]) s->def_at[i] = op - (anchor - src) + 1000000; }
             op += 1 + lit + (lit >= 15 ? (lit - 15) / 255 + 1 : 0);
         }
     next_match:
@@ -101,9 +103,9 @@ int main(int argc, char** argv)
             stats_t s;
             const int c = parse(buf + off, len, &s);
             printf("%s +%d: csize %d (%s) seqs %ld probes %ld | hits: lean(u<15) %ld (zero-lit %ld) u15..63 %ld later %ld | no-hit batches U<960 %ld U>=960 %ld, hit batches U<960 %ld U>=960 %ld | "
-                   "ml <16 %ld <64 %ld <1024 %ld >=1024 %ld | offset>8K %ld tooFar %ld\n",
+                   "ml <16 %ld <64 %ld <1024 %ld >=1024 %ld | offset>8K %ld tooFar %ld | count-only from %ld | output - input at 16K %ld 32K %ld 64K %ld 128K %ld 192K %ld end %ld\n",
                    argv[a], off, c, c ? "compressed" : "stored", s.seqs, s.probes, s.hit_lean, s.zero_lit, s.hit_u15_63, s.hit_later, s.batches_nohit_lt960,
-                   s.batches_nohit_ge960, s.batches_hit_lt960, s.batches_hit_ge960, s.ml_lt12, s.ml_lt64, s.ml_lt1024, s.ml_ge1024, s.far8k, s.tooFar);
+                   s.batches_nohit_ge960, s.batches_hit_lt960, s.batches_hit_ge960, s.ml_lt12, s.ml_lt64, s.ml_lt1024, s.ml_ge1024, s.far8k, s.tooFar, s.co_at, s.def_at[0] - 1000000, s.def_at[1] - 1000000, s.def_at[2] - 1000000, s.def_at[3] - 1000000, s.def_at[4] - 1000000, s.out - (long)len);
         }
     }
     return 0;
