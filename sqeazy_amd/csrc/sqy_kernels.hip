@@ -177,6 +177,12 @@ __device__ __forceinline__ void transpose16x16_pairs(uint32_t r[16])
     }
 }
 
+// (round 6, built, exact, measured, not kept: the tile as sixteen non-temporal loads of 4 x 256 contiguous bytes -- 7.1 TB/s for a 1 GiB
+// read on this chip against 5.2 for "every lane its own 256 bytes", tools/read_bench.hip -- and the 16 x 16 transpose of sixteen-byte elements
+// across the sixteen lanes of a DPP row that puts a lane's own 256 bytes back into its registers (four butterfly stages of row_shr / row_shl
+// moves, the bank mask as the select: ~400 vector instructions, no LDS).  The kernel that only reads: 0.249 -> 0.214 ms; the real one, ten
+// planes written: 0.380 -> 0.402; in flight -2 %.  At ~1000 vector instructions per tile the transposer is no longer only memory-bound:
+// profiles/r06_experiments.txt.)
 // No LDS: every lane loads its own 256 contiguous bytes (16 x 16 B at a lane stride of 256 B; the eight loads that share
 // a 128-byte line are issued back to back, so the line is fetched once and hit in L1 after that).  Needs no LDS allocation
 // at all, which matters when the CUs' LDS is held by resident LZ4 chunk waves of other calls in flight: this kernel then
@@ -261,7 +267,11 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
                 // (round 6) the piece's address stays SCALAR: "* 15" as shift and subtract -- there is no 64-bit scalar multiply, the
                 // compiler moved the product, and with it sixteen 64-bit store addresses, into vector registers
                 const uint64_t kq = B >> gap_shift;
+#ifdef SQY_EXP_GAP_BYTES
+                const uint64_t off = B + kq * SQY_EXP_GAP_BYTES;         // (tools/bsw_bench.hip: what the 15-byte gaps' misalignment costs)
+#else
                 const uint64_t off = B + (kq << 4) - kq;
+#endif
                 const uint32_t off_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
                 const uint32_t off_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32));
                 uint8_t* dst = reinterpret_cast<uint8_t*>(out) + (((uint64_t)off_hi << 32) | off_lo);
