@@ -194,6 +194,9 @@ SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
  *   "block_parallel_stats"            0 [SQY_BLOCK_PARALLEL_STATS=1]  print the blocks whose guess failed
  *   "tail_scan"                       1 [SQY_NO_TAIL_SCAN=1 -> 0]  serial-layout decode: the walk over the block tails as a scan
  *   "decode_two_waves"                1 [SQY_NO_DECODE_TWO_WAVES=1 -> 0]  chunked-layout decode: two wavefronts per frame (0: one)
+ *   "noise_digest"                    1 [SQY_NO_NOISE_DIGEST=1 -> 0]  frames in place: the bit-plane transpose leaves bucket and tag of every position
+ *                                     liblz4's search probes in a chunk of noise; the LZ4 parse proves such chunks incompressible from them
+ *                                     instead of reading the plane stream again (0: it reads)
  * Set: 0 = done, 1 = unknown name or value out of range.  Get: the value, -1 for an unknown name. */
 SQY_FUNCTION_PREFIX int SQYAMD_Set_Option(const char* name, long value);
 SQY_FUNCTION_PREFIX long SQYAMD_Get_Option(const char* name);

@@ -67,11 +67,12 @@ struct Options {
     std::atomic<long> block_parallel_stats;             // print the blocks that failed the table check
     std::atomic<long> tail_scan;                        // serial-layout decode: the walk over the tails as a scan
     std::atomic<long> decode_two_waves;                 // chunked-layout decode: two wavefronts per frame (one parses, one copies)
+    std::atomic<long> noise_digest;                     // frames in place: the transpose leaves the noise digest, the parse proves noise chunks empty from it
     Options()
         : transpose_chain(env_flag("SQY_NO_TRANSPOSE_CHAIN") ? 0 : 1), transpose_chain_caller_streams(env_flag("SQY_TRANSPOSE_CHAIN_CALLER_STREAMS")),
           block_parallel(env_flag("SQY_NO_BLOCK_PARALLEL") ? 0 : 1), block_parallel_warmup(env_number("SQY_BLOCK_PARALLEL_WARMUP", 65536, 0, kWarmupMax)),
           block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1),
-          decode_two_waves(env_flag("SQY_NO_DECODE_TWO_WAVES") ? 0 : 1) {}
+          decode_two_waves(env_flag("SQY_NO_DECODE_TWO_WAVES") ? 0 : 1), noise_digest(env_flag("SQY_NO_NOISE_DIGEST") ? 0 : 1) {}
     std::atomic<long>* find(const char* name)
     {
         if (!name) return nullptr;
@@ -82,6 +83,7 @@ struct Options {
         if (!std::strcmp(name, "block_parallel_stats")) return &block_parallel_stats;
         if (!std::strcmp(name, "tail_scan")) return &tail_scan;
         if (!std::strcmp(name, "decode_two_waves")) return &decode_two_waves;
+        if (!std::strcmp(name, "noise_digest")) return &noise_digest;
         return nullptr;
     }
 };
@@ -187,11 +189,12 @@ struct Workspace {
     DevBuf ping, pong, lz4_scratch, csize, frame_off, io_src, io_dst, small, plan, dedupe;
     DevBuf spec;              // block-linked frames parsed block-parallel: per block the table it started from and the one it left, the walk lists
     DevBuf diff_side;         // diff3x3x1 in front of a 16-bit bitswap1: the columns the stage can touch (outside the ping/pong rotation)
+    DevBuf digest;            // frames in place: the noise digest the transpose leaves for the LZ4 parse (19 KB per 256 KiB chunk)
     void* pinned = nullptr;   // 4 KiB of pinned host memory for small read-backs
     void release_buffers()
     {
         ping.release(); pong.release(); lz4_scratch.release(); csize.release(); frame_off.release();
-        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release(); spec.release();
+        io_src.release(); io_dst.release(); small.release(); plan.release(); dedupe.release(); diff_side.release(); spec.release(); digest.release();
     }
 };
 
@@ -454,6 +457,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
     bool inplace_done = false;                   // frames in place, finished on the device: where the blob is
     uint64_t inplace_blob_at = 0, inplace_blob_bytes = 0, inplace_hdr_bytes = 0;
     uint64_t* lz4_holes = nullptr;               // frames in place: which 1 KiB pieces of the plane stream the transpose left unwritten (all zero)
+    uint32_t* lz4_digest = nullptr;              // frames in place: the noise digest (sqy_kernels.h: launch_bitswap1_u16), lz4_digest_stride words per chunk
+    uint32_t lz4_digest_stride = 0;
     static_assert(sizeof(sqy::Lz4Block) == sizeof(sqy::Lz4BlockPlan) && sizeof(sqy::Lz4Block) == 32, "plan entries are read by the kernels as they are");
 
     size_t skip_stage = ~(size_t)0;             // a stage that the stage in front of it has already done (quantiser + bitswap1 in one pass)
@@ -493,6 +498,13 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                                 if (ws->plan.ensure((nch + 1) * sizeof(uint32_t))) return 1;
                                 SQY_HIP(sqy::launch_lz4_dedupe_clear(static_cast<uint8_t*>(ws->dedupe.p) + ph_bytes, nch, static_cast<uint32_t*>(ws->plan.p), stream));
                                 dedupe_cleared = true;
+                                // the noise digest (round 6): every plane segment a whole number of chunks, liblz4's plain search behind it
+                                const uint32_t dstride = sqy::lz4_noise_digest_stride((uint32_t)chunk);
+                                if (g_opt.noise_digest.load() && dstride && (cur_len / 8) % chunk == 0 && pipe.stages[si + 1].lz4.accel >= 0 &&
+                                    !ws->digest.ensure(nch * (uint64_t)dstride * sizeof(uint32_t), true)) {
+                                    lz4_digest = static_cast<uint32_t*>(ws->digest.p);
+                                    lz4_digest_stride = dstride;
+                                }
                             }
                         }
                     }
@@ -527,7 +539,8 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                 ProfScope ps(cur_elem == 2 ? "bitswap1_u16" : "bitswap1_u8", stream, pend);
                 if (cur_elem == 2)
                     SQY_HIP(sqy::launch_bitswap1_u16(reinterpret_cast<const uint16_t*>(cur), reinterpret_cast<uint16_t*>(out), cur_len, stream, ph,
-                                                     (uint32_t)gap_chunk, bsw_side, bsw_side_w, bsw_side_X));
+                                                     (uint32_t)gap_chunk, bsw_side, bsw_side_w, bsw_side_X, gap_chunk ? lz4_digest : nullptr,
+                                                     lz4_digest_stride));
                 else
                     SQY_HIP(sqy::launch_bitswap1_u8(cur, out, cur_len, stream));
                 }
@@ -845,6 +858,7 @@ int encode_on_device(Context& cx, const char* pipeline_c, const void* d_src, con
                         SQY_HIP(sqy::launch_lz4_dedupe(cur, lz4_total, (uint32_t)lz4_chunk, lz4_piece_hash, base, d_dup, stream, lz4_in_stride, lz4_holes,
                                                        dedupe_cleared, fused_dedupe ? &lz4_dedupe_args : nullptr));
                         lz4_dup_of = d_dup;
+                        if (fused_dedupe && lz4_digest) { lz4_dedupe_args.digest = lz4_digest; lz4_dedupe_args.digest_stride = lz4_digest_stride; }
                     }
                     if (ws->plan.ensure((lz4_nchunks + 1) * sizeof(uint32_t))) return 1;
                     uint32_t* d_redo = static_cast<uint32_t*>(ws->plan.p);       // chunks the first pass leaves to the dense batches

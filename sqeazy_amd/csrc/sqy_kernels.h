@@ -18,6 +18,8 @@ struct Lz4DedupeArgs {
     const uint32_t* piece_hash = nullptr;
     const uint64_t* holes_map = nullptr;
     uint64_t nchunks_full = 0;
+    const uint32_t* digest = nullptr;    // the noise digest the transpose left (launch_bitswap1_u16), digest_stride words per chunk
+    uint32_t digest_stride = 0;
 };
 // bitswap1: bit-plane transpose of `len` elements (encoders/bitswap_scheme_impl.hpp:97-145)
 // piece_hash != nullptr (bitswap1_piece_hash_words(..) words, only offered when that is non-zero): a hash of every 1 KiB piece of
@@ -26,8 +28,14 @@ struct Lz4DedupeArgs {
 // will be cut into -- chunk k (gap_chunk bytes, a power of two) at out + k * (gap_chunk + 15), `out` any alignment; needs
 // len % 8192 == 0
 // side != nullptr (launch_diff3x3x1_side): columns x < side_w of every row of X voxels are read from the compact buffer `side`
+// digest != nullptr (round 6, frames in place only, len / 8 a multiple of gap_chunk): the NOISE DIGEST -- bucket << 16 | tag of the five bytes at
+// every position liblz4's search probes from probe 961 on when it starts with a chunk and finds nothing, digest_stride
+// (= lz4_noise_digest_stride(gap_chunk)) words per chunk of the plane stream; the LZ4 parse of a chunk takes its batches from there as long
+// as nothing has matched (Lz4DedupeArgs::digest) instead of reading the plane bytes again
 hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash = nullptr,
-                               uint32_t gap_chunk = 0, const uint16_t* side = nullptr, uint32_t side_w = 0, uint32_t X = 0);
+                               uint32_t gap_chunk = 0, const uint16_t* side = nullptr, uint32_t side_w = 0, uint32_t X = 0,
+                               uint32_t* digest = nullptr, uint32_t digest_stride = 0);
+uint32_t lz4_noise_digest_stride(uint32_t chunk);      // words per chunk, 0 = no digest for this chunk size
 uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len);
 // duplicate chunks of a plane stream (chunk a multiple of 1 KiB): dup_of[k] = the earliest chunk with the same bytes (k itself when
 // there is none); the hashes only nominate, a byte compare decides.  work: lz4_dedupe_work_bytes(nchunks) bytes

@@ -195,10 +195,12 @@ __device__ __forceinline__ void transpose16x16_pairs(uint32_t r[16])
 // off a 16-byte boundary; plain unaligned 16-byte stores (measured within 8 % of aligned ones, tools/ubench_align.hip).
 // side != nullptr (diff3x3x1 right in front, see diff3x3x1_u16_rows_kernel): columns x < side_w of every row (X voxels, a multiple
 // of the 128 a lane owns) come from the compact buffer `side` (rows side_w voxels apart), everything else from `in`.
+__device__ __forceinline__ uint32_t lz4_hash5_32(uint32_t lo, uint32_t byte4);      // (liblz4's 5-byte hash, defined with the LZ4 kernels below)
 template <bool GAP>
 __global__ __launch_bounds__(256)       // (launched in blocks of 128; bounds of 128 let the compiler take 173 registers instead of 127)
 void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ out, uint64_t n_tiles, uint64_t seg_words,
-                       uint32_t* __restrict__ piece_hash, uint32_t gap_shift, const uint16_t* __restrict__ side, uint32_t side_w, uint32_t X)
+                       uint32_t* __restrict__ piece_hash, uint32_t gap_shift, const uint16_t* __restrict__ side, uint32_t side_w, uint32_t X,
+                       uint32_t* __restrict__ digest, uint32_t digest_stride)
 {
     const int lane = threadIdx.x & 63;
     // (the wave number through readfirstlane: tile and every piece address below are then scalar, the lane part a 32-bit offset)
@@ -234,6 +236,35 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
 #pragma unroll
             for (int b = 0; b < 16; ++b) pl[b][q] = r[b];
         }
+        // ---- the NOISE DIGEST (round 6; GAP only, the host offers it when every plane segment is a whole number of chunks) ----
+        // While liblz4's search finds nothing, WHERE it probes is a closed form: probe u of a search that starts with a chunk sits at
+        // B_s + (u - u_s) * s for u_s = 64 s - 62 <= u <= 64 s + 1, B_s = 2 + 32 s (s - 1) (s = the step; tools/lz4_parse_stats.c, checked
+        // against the loop itself).  A chunk of noise is parsed -- to find that it has to be stored -- by ~5760 such probes, each of which
+        // needs the bucket and the tag of five bytes: 0.6 GB of plane stream read again per GiB of voxels for 23 KB per chunk of answers.
+        // Those answers are left HERE, where the bytes are in registers: from probe 961 on (step >= 16: at most one probe per lane's
+        // sixteen bytes) lane L works out which probe, if any, starts inside its bytes [x, x + 16) of the chunk, takes the five bytes
+        // from there (the next lane's first dword through a DPP shift; the wave's last lane cannot see behind its bytes: such an entry
+        // says "look yourself"), and stores bucket << 16 | tag at digest[chunk][u - 961].  The chunk's parse wave (lz4_chunks_kernel, the
+        // batches proved empty) takes its batches from there as long as nothing has matched.  Exact by construction: the entries are what
+        // the parse computes from the same bytes.  Pieces that are all zero write nothing; a chunk with such a piece is parsed from its bytes.
+        uint32_t dg = 0;                       // one register across the planes: bit 31 = a probe starts in my bytes | probe number - 961 << 4 | its byte
+        if (GAP && digest) {
+            const uint32_t x = (((uint32_t)tile << 10) & ((1u << gap_shift) - 1u)) + (uint32_t)lane * 16u;     // my bytes inside the chunk
+            if (x + 16u > 7667u) {                                              // (probe 961 sits at byte 7667)
+                const uint32_t xx = x > 7667u ? x : 7667u;
+                uint32_t st = (uint32_t)((1.0f + __builtin_sqrtf(1.0f + (float)(xx - 2u) * 0.125f)) * 0.5f);
+                if (2u + 32u * (st + 1u) * st <= xx) ++st;                      // B_{s+1} <= xx
+                if (2u + 32u * st * (st - 1u) > xx) --st;                       // B_s > xx
+                const uint32_t Bs = 2u + 32u * st * (st - 1u), num = xx - Bs;  // num < 64 s
+                uint32_t kk = (uint32_t)((float)num / (float)st);
+                if (kk * st > num) --kk;
+                if ((kk + 1u) * st <= num) ++kk;
+                if (kk * st != num) ++kk;                                      // ceil
+                const uint32_t cand = Bs + kk * st, u = 64u * st - 62u + kk;
+                if (cand < x + 16u && u >= 961u && u - 961u < digest_stride) dg = 0x80000000u | ((u - 961u) << 4) | (cand - x);
+            }
+        }
+        const uint32_t dg_tsh = 31u - gap_shift;                            // the parse's tag width for a whole chunk (positions take gap_shift bits)
         // One pass over the planes: the piece's hash, then the piece (round 6: hash and store of a plane next to each other, its four
         // registers are free behind them; two separate loops kept all sixty-four alive across sixteen branches).
         const uint32_t pm = 2u * (uint32_t)lane + 1u;                    // position inside the piece
@@ -264,6 +295,22 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
                 // zero are never read but for the first: bit planes above the largest voxel value are HBM traffic nobody needs.
                 if (nzm == 0ull) continue;
                 const uint64_t B = (uint64_t)(15 - b) * seg_words * 2u + tile * 1024u;       // byte offset of the piece in the plane stream
+                if (digest) {
+                    const uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)val.x, 0x130, 0xf, 0xf, true);      // wave_shl:1: the next lane's first dword
+                    const uint32_t dg_off = dg & 15u, dg_q = dg_off >> 2, dg_r = dg_off & 3u;
+                    const uint32_t d0 = dg_q == 0u ? val.x : dg_q == 1u ? val.y : dg_q == 2u ? val.z : val.w;
+                    const uint32_t d1 = dg_q == 0u ? val.y : dg_q == 1u ? val.z : dg_q == 2u ? val.w : nx;
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, dg_r);                  // bytes off .. off + 3
+                    const uint32_t b5 = d1 >> (8u * dg_r);                                          // byte off + 4 (in its low byte)
+                    uint32_t e = (lz4_hash5_32(lo, b5) << 16) | ((lo * 2654435761u) >> (32u - dg_tsh));
+                    if (lane == 63 && dg_off > 11u) e = 0xffffffffu;                                // its five bytes end in the next tile's piece
+                    // (the chunk's row of the digest as a SCALAR base, the lane's entry a 32-bit offset: see the piece's address below)
+                    const uint64_t drow = (B >> gap_shift) * (uint64_t)digest_stride * 4u;
+                    const uint32_t drow_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)drow);
+                    const uint32_t drow_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(drow >> 32));
+                    uint8_t* const dbase = reinterpret_cast<uint8_t*>(digest) + (((uint64_t)drow_hi << 32) | drow_lo);
+                    if ((int32_t)dg < 0) *reinterpret_cast<uint32_t*>(dbase + ((dg >> 2) & 0x1ffffffcu)) = e;
+                }
                 // (round 6) the piece's address stays SCALAR: "* 15" as shift and subtract -- there is no 64-bit scalar multiply, the
                 // compiler moved the product, and with it sixteen 64-bit store addresses, into vector registers
                 const uint64_t kq = B >> gap_shift;
@@ -1236,6 +1283,17 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     __syncthreads();
     n_prev = n;
 
+    // (round 6) the noise digest the transpose left for this chunk (see bitswap1_u16_regs): usable for a whole chunk none of whose 1 KiB
+    // pieces is all zero (those write no entries: what lies there is a former call's)
+    const uint32_t* __restrict__ dgp = nullptr;
+    uint32_t dg_words = 0;
+    if constexpr (!LINKED && !DENSE && !ACCEL) {
+        if (dd.digest && n == chunk && dd.holes_map &&
+            (uint32_t)dd.holes_map[blk * (1u + ((chunk >> 10) + 63u) / 64u)] == 0u) {
+            dgp = dd.digest + blk * (uint64_t)dd.digest_stride;
+            dg_words = dd.digest_stride;
+        }
+    }
     const uint32_t olimit = n - 1;       // capacity n-1 (LZ4F_makeBlock); offsets into dst
     uint32_t op = 0, anchor = p0;
     bool failed = false;
@@ -1792,9 +1850,24 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
                 const uint32_t pos = P + s_first * lane + (u > ustar ? u - ustar : 0u);
                 const uint32_t nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
                 if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
-                const uint64_t seq = glb_ld_u64(w.src + pos);              // (the ring was left behind at these strides)
-                const uint32_t h = lz4_hash5(seq);
-                const uint32_t mytag = tag_of((uint32_t)seq);
+                uint32_t h, mytag;
+                // Nothing has matched since the chunk began (anchor == p0: the search started at probe 1 and these are the positions the
+                // transpose foresaw): bucket and tag of this batch's probes come from the digest, 256 bytes instead of 64 scattered reads
+                // of the plane stream.  An entry of all ones: the probe's five bytes end in another wave's piece -- that lane looks itself.
+                if (dgp && anchor == p0 && U >= 961u && U - 961u + 64u <= dg_words) {
+                    const uint32_t e = dgp[U - 961u + (uint32_t)lane];
+                    h = e >> 16; mytag = e & 0xffffu;
+                    if (ballot(e == 0xffffffffu)) {
+                        if (e == 0xffffffffu) {
+                            const uint64_t seq = glb_ld_u64(w.src + pos);
+                            h = lz4_hash5(seq); mytag = tag_of((uint32_t)seq);
+                        }
+                    }
+                } else {
+                    const uint64_t seq = glb_ld_u64(w.src + pos);          // (the ring was left behind at these strides)
+                    h = lz4_hash5(seq);
+                    mytag = tag_of((uint32_t)seq);
+                }
                 const uint32_t mine = (pos << tsh) | mytag;
                 const uint32_t oe = table[h];
                 const uint32_t seen = atomicMax(&table[h], mine);
@@ -5566,7 +5639,7 @@ static inline int num_cus()
 }
 
 hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash, uint32_t gap_chunk,
-                               const uint16_t* side, uint32_t side_w, uint32_t X)
+                               const uint16_t* side, uint32_t side_w, uint32_t X, uint32_t* digest, uint32_t digest_stride)
 {
     if (len == 0) return hipSuccess;
     if (side && (X == 0 || X % 128u != 0 || side_w % 128u != 0 || side_w > X || len % X != 0 || (reinterpret_cast<uintptr_t>(side) & 15) ||
@@ -5580,8 +5653,11 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         // (round 6, measured: fewer resident blocks -- 8 .. 2 per CU instead of as many as fit -- let the small kernels of the other calls in
         // flight start sooner, and cost the transposes and with them the step 3 .. 12 %)
         const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * 32;    // (blocks of two waves: see below)
+        // (the noise digest: only when every plane segment is a whole number of chunks -- a lane's place inside its chunk is then the same
+        // in all sixteen planes -- and the chunk long enough for the search to reach step 16)
+        if (digest && ((len / 8) % gap_chunk != 0 || gap_chunk < 16384u || digest_stride == 0)) return hipErrorInvalidValue;
         hipLaunchKernelGGL(bitswap1_u16_regs<true>, dim3((unsigned)(want < cap ? want : cap)), dim3(128), 0, stream, in, out, n_tiles, len / 16,
-                           piece_hash, (uint32_t)__builtin_ctz(gap_chunk), side, side_w, X);
+                           piece_hash, (uint32_t)__builtin_ctz(gap_chunk), side, side_w, X, digest, digest_stride);
         return hipGetLastError();
     }
     const uint64_t seg_words = len / 16;
@@ -5599,7 +5675,8 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         const uint64_t want = (n_tiles + 1) / 2;
         const uint64_t cap = (uint64_t)num_cus() * 32;
         const unsigned grid = (unsigned)(want < cap ? want : cap);
-        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(128), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u, side, side_w, X);
+        hipLaunchKernelGGL(bitswap1_u16_regs<false>, dim3(grid), dim3(128), 0, stream, in, out, n_tiles, seg_words, piece_hash, 0u, side, side_w, X,
+                           (uint32_t*)nullptr, 0u);
     }
     const uint64_t first_word = n_tiles * (BSW_TILE_VOX / 16);
     const uint64_t rest_words = seg_words - first_word;
@@ -5610,6 +5687,22 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
         hipLaunchKernelGGL(bitswap1_u16_generic, dim3((unsigned)blocks), dim3(256), 0, stream, in, out, len, first_word, seg_words);
     }
     return hipGetLastError();
+}
+
+uint32_t lz4_noise_digest_stride(uint32_t chunk)
+{
+    // probes of a search that starts with the chunk and never finds anything (liblz4's step schedule), from probe 961 on; 0: no digest
+    if (chunk < 16384u || (chunk & (chunk - 1u))) return 0;
+    uint64_t p = 1, st = 1, nb = 64, probes = 0;
+    for (;;) {
+        ++probes;
+        const uint64_t p2 = p + st;
+        st = nb >> 6; ++nb;
+        if (p2 > (uint64_t)chunk - 12 + 1) break;
+        p = p2;
+    }
+    if (probes <= 961) return 0;
+    return (uint32_t)(((probes - 960) + 63) & ~(uint64_t)63);
 }
 
 uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len)
