@@ -68,11 +68,13 @@ struct Options {
     std::atomic<long> tail_scan;                        // serial-layout decode: the walk over the tails as a scan
     std::atomic<long> decode_two_waves;                 // chunked-layout decode: two wavefronts per frame (one parses, one copies)
     std::atomic<long> noise_digest;                     // frames in place: the transpose leaves the noise digest, the parse proves noise chunks empty from it
+    std::atomic<long> transpose_blocks_per_cu;          // frames in place: workgroups of the transposer's grid per CU
     Options()
         : transpose_chain(env_flag("SQY_NO_TRANSPOSE_CHAIN") ? 0 : 1), transpose_chain_caller_streams(env_flag("SQY_TRANSPOSE_CHAIN_CALLER_STREAMS")),
           block_parallel(env_flag("SQY_NO_BLOCK_PARALLEL") ? 0 : 1), block_parallel_warmup(env_number("SQY_BLOCK_PARALLEL_WARMUP", 65536, 0, kWarmupMax)),
           block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1),
-          decode_two_waves(env_flag("SQY_NO_DECODE_TWO_WAVES") ? 0 : 1), noise_digest(env_flag("SQY_NO_NOISE_DIGEST") ? 0 : 1) {}
+          decode_two_waves(env_flag("SQY_NO_DECODE_TWO_WAVES") ? 0 : 1), noise_digest(env_flag("SQY_NO_NOISE_DIGEST") ? 0 : 1),
+          transpose_blocks_per_cu(env_number("SQY_TRANSPOSE_BLOCKS_PER_CU", 32, 1, 64)) { sqy::set_bitswap1_blocks_per_cu(transpose_blocks_per_cu.load()); }
     std::atomic<long>* find(const char* name)
     {
         if (!name) return nullptr;
@@ -84,6 +86,7 @@ struct Options {
         if (!std::strcmp(name, "tail_scan")) return &tail_scan;
         if (!std::strcmp(name, "decode_two_waves")) return &decode_two_waves;
         if (!std::strcmp(name, "noise_digest")) return &noise_digest;
+        if (!std::strcmp(name, "transpose_blocks_per_cu")) return &transpose_blocks_per_cu;
         return nullptr;
     }
 };
@@ -2148,6 +2151,7 @@ int SQYAMD_Set_Option(const char* name, long value)
     std::atomic<long>* o = g_opt.find(name);
     if (!o) return 1;
     if (o == &g_opt.block_parallel_warmup) { if (value < 0 || value > kWarmupMax) return 1; }
+    else if (o == &g_opt.transpose_blocks_per_cu) { if (value < 1 || value > 64) return 1; sqy::set_bitswap1_blocks_per_cu(value); }
     else if (value != 0 && value != 1) return 1;
     o->store(value);
     return 0;

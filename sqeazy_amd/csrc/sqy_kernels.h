@@ -35,6 +35,7 @@ struct Lz4DedupeArgs {
 hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash = nullptr,
                                uint32_t gap_chunk = 0, const uint16_t* side = nullptr, uint32_t side_w = 0, uint32_t X = 0,
                                uint32_t* digest = nullptr, uint32_t digest_stride = 0);
+void set_bitswap1_blocks_per_cu(long n);      // workgroups (two waves) of the in-place transposer per CU (default 32: as many as fit)
 uint32_t lz4_noise_digest_stride(uint32_t chunk);      // words per chunk, 0 = no digest for this chunk size
 uint64_t bitswap1_piece_hash_words(const void* in, const void* out, uint64_t len);
 // duplicate chunks of a plane stream (chunk a multiple of 1 KiB): dup_of[k] = the earliest chunk with the same bytes (k itself when

@@ -322,7 +322,10 @@ void bitswap1_u16_regs(const uint16_t* __restrict__ in, uint16_t* __restrict__ o
                 const uint32_t off_lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)off);
                 const uint32_t off_hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(off >> 32));
                 uint8_t* dst = reinterpret_cast<uint8_t*>(out) + (((uint64_t)off_hi << 32) | off_lo);
-                *reinterpret_cast<v4u_any*>(dst + (uint32_t)lane * 16u) = val;
+                // (non-temporal, round 6: the plane stream is read again much later and by other XCDs; kept out of this XCD's L2 it leaves the
+                // lines the LZ4 chunk waves of the calls in flight read twice -- candidates behind their LDS window -- where they are: with the
+                // noise digest in place +3 %; without it, when the HBM's bandwidth was the limit, +-0)
+                __builtin_nontemporal_store((v4u_any)val, reinterpret_cast<v4u_any*>(dst + (uint32_t)lane * 16u));
             } else {
                 v4u* dst = reinterpret_cast<v4u*>(out + (uint64_t)(15 - b) * seg_words + tile * (BSW_TILE_VOX / 16));
                 __builtin_nontemporal_store(val, dst + lane);
@@ -5638,6 +5641,9 @@ static inline int num_cus()
     return cus;
 }
 
+std::atomic<long> g_bsw_blocks_per_cu{32};       // (measurement switch: SQYAMD_Set_Option("transpose_blocks_per_cu"))
+void set_bitswap1_blocks_per_cu(long n) { g_bsw_blocks_per_cu.store(n); }
+
 hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, hipStream_t stream, uint32_t* piece_hash, uint32_t gap_chunk,
                                const uint16_t* side, uint32_t side_w, uint32_t X, uint32_t* digest, uint32_t digest_stride)
 {
@@ -5652,7 +5658,7 @@ hipError_t launch_bitswap1_u16(const uint16_t* in, uint16_t* out, uint64_t len, 
             return hipErrorInvalidValue;
         // (round 6, measured: fewer resident blocks -- 8 .. 2 per CU instead of as many as fit -- let the small kernels of the other calls in
         // flight start sooner, and cost the transposes and with them the step 3 .. 12 %)
-        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * 32;    // (blocks of two waves: see below)
+        const uint64_t n_tiles = len / BSW_TILE_VOX, want = (n_tiles + 1) / 2, cap = (uint64_t)num_cus() * (g_bsw_blocks_per_cu.load() > 0 ? (uint64_t)g_bsw_blocks_per_cu.load() : 32u);    // (blocks of two waves: see below)
         // (the noise digest: only when every plane segment is a whole number of chunks -- a lane's place inside its chunk is then the same
         // in all sixteen planes -- and the chunk long enough for the search to reach step 16)
         if (digest && ((len / 8) % gap_chunk != 0 || gap_chunk < 16384u || digest_stride == 0)) return hipErrorInvalidValue;
