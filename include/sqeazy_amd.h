@@ -51,9 +51,13 @@ SQY_FUNCTION_PREFIX int SQY_Version_Triple(int* version);
  *   dstlength   out only: bytes written (header + payload)
  *   nthreads    <=0 or > hardware threads: all hardware threads (src/sqeazy_algorithms.hpp:14-22).  The value selects
  *               the LZ4 LAYOUT exactly as in the reference (encoders/lz4.hpp:227-239): effective 1 -> ONE frame of
- *               block-linked 256 KiB blocks (lz4_utils.hpp:99-173; bit-identical; its blocks are parsed in parallel from
- *               verified hash-table guesses, about half the rate of the chunked layout); >=2 -> one independent frame per 256 KiB chunk
- *               (lz4_utils.hpp:193-274; byte-identical for every count >= 2; the fast path). */
+ *               block-linked 256 KiB blocks (lz4_utils.hpp:99-173; bit-identical).  Its blocks are parsed in parallel from hash-table
+ *               guesses that are verified and parsed again, in order, where they fail: 2-4 x the chunked layout's time on ordinary
+ *               stacks (3 ms against 1.4 for a 1 GiB stack, 21 ms against 5.4 for a diff3x3x1 slab of 2 GiB) -- but SECONDS where no
+ *               guess holds: a stream of short sequences such as the top plane of quantised data (511 blocks in a row, one wavefront,
+ *               ~10 ms per block: 4.7 s for a 2048x2048x256 slab of quantiser->bitswap1->lz4, slower than one CPU core; the library
+ *               says so once on stderr).  >=2 -> one independent frame per 256 KiB chunk (lz4_utils.hpp:193-274; byte-identical for
+ *               every count >= 2; the fast path: 12 ms for that slab).  Same decoder for both. */
 SQY_FUNCTION_PREFIX int SQY_PipelineEncode_UI8(const char* pipeline, const char* src, long* shape, unsigned shape_size,
                                                char* dst, long* dstlength, int nthreads);
 
@@ -197,6 +201,8 @@ SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
  *   "noise_digest"                    1 [SQY_NO_NOISE_DIGEST=1 -> 0]  frames in place: the bit-plane transpose leaves bucket and tag of every position
  *                                     liblz4's search probes in a chunk of noise; the LZ4 parse proves such chunks incompressible from them
  *                                     instead of reading the plane stream again (0: it reads)
+ *   "transpose_blocks_per_cu"         32 [SQY_TRANSPOSE_BLOCKS_PER_CU=<1..64>]  frames in place: workgroups (two wavefronts) of the transposer's grid
+ *                                     per CU (32: as many as fit; fewer leave room for the small kernels of other calls in flight -- measured: slower)
  * Set: 0 = done, 1 = unknown name or value out of range.  Get: the value, -1 for an unknown name. */
 SQY_FUNCTION_PREFIX int SQYAMD_Set_Option(const char* name, long value);
 SQY_FUNCTION_PREFIX long SQYAMD_Get_Option(const char* name);

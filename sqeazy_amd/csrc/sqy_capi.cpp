@@ -1479,21 +1479,25 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 // config's decode 1.49 -> 1.1 ms)
                 const uint64_t* remap = nullptr;
                 uint64_t remap_bytes = 0;
+                bool remap_zero = false;
                 if (si >= 1 && pipe.stages[si - 1].kind == StageKind::frame_shuffle && nframes == nchunks && nframes > 1 && total % chunk == 0 &&
                     count_before[si - 1] * (uint64_t)elem_before[si - 1] == total && h.shape.size() == 3) {
                     uint64_t Z = 0, fb = 0;
                     bool permutation = true;
                     if (const int rc = frame_shuffle_prepare(si - 1, Z, fb, permutation)) return rc;
-                    // (round-5 advice) only when the map is a permutation: with a frame named twice -- frames of equal metric on the encoder's
-                    // side, or a crafted blob -- several LZ4 frames would decode into the same place at once, and the ring kernels read
-                    // matches that reach behind their ring back from that place.  Then: plain decode, the stage's own inverse behind it.
-                    if (fb && fb % chunk == 0 && Z * fb == total && permutation) {
+                    // (round-5 advice) a map that names a place twice -- frames of equal metric on the encoder's side, or a crafted blob --:
+                    // several LZ4 frames must not decode into one place at once (the ring kernels read matches that reach behind their
+                    // ring back from there).  The device's copy of such a map has every frame but the last one named for a place struck
+                    // (frame_shuffle_prepare): struck frames are not decoded, the places nobody names are zeroed first.
+                    if (fb && fb % chunk == 0 && Z * fb == total) {
                         remap = static_cast<const uint64_t*>(ws->small.p);
                         remap_bytes = fb;
+                        remap_zero = !permutation;
                     }
                 }
                 uint8_t* out = out_buf(remap ? si - 1 : si, total);
                 if (!out) return 1;
+                if (remap_zero) SQY_HIP(hipMemsetAsync(out, 0, total, stream));       // (frames nobody names come out as zeros, as behind the stage's own inverse)
                 uint32_t bad = 0;
                 bool decoded = false;
                 // ONE block-linked frame (nthreads = 1 on the encoder's side): every block at once with the history as an unknown, the

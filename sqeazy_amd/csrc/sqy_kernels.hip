@@ -3574,6 +3574,13 @@ void lz4_frame_index_kernel(const uint8_t* __restrict__ in, uint64_t n, uint4* _
 // Round 5: `remap` != nullptr -- the stage in front of `lz4` on the encoder's side was frame_shuffle, and every LZ4 chunk lies inside ONE of
 // its frames of remap_bytes: the frames are decoded straight to where the shuffle's inverse would move them (frame i of the sorted
 // stream is frame remap[i] of the volume, frame_shuffle_utils.hpp:337-344), one pass over the decoded bytes less.
+// (a map that names a place several times -- frames of equal metric on the encoder's side -- reaches the device with all but the LAST frame
+// named for a place struck (~0, sqy_capi.cpp frame_shuffle_prepare): those frames are not decoded at all, what they would write is
+// overwritten by definition (the reference's loop: the last one stays), and no two frames ever decode into one place at once)
+__device__ __forceinline__ bool lz4_decode_frame_struck(uint64_t o, const uint64_t* __restrict__ remap, uint64_t remap_bytes)
+{
+    return remap && remap[o / remap_bytes] == ~0ull;
+}
 __device__ __forceinline__ uint64_t lz4_decode_frame_out(uint64_t o, const uint64_t* __restrict__ remap, uint64_t remap_bytes)
 {
     if (!remap) return o;
@@ -3604,6 +3611,7 @@ void lz4_frames_decode_kernel(const uint8_t* __restrict__ in, const uint4* __res
     const int lane = threadIdx.x;
     const uint32_t f = blockIdx.x;
     const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
+    if (lz4_decode_frame_struck((uint64_t)f * frame_stride, remap, remap_bytes)) return;
     const uint64_t frame_out = lz4_decode_frame_out((uint64_t)f * frame_stride, remap, remap_bytes);   // frame f decodes to [f*chunk, ...)
     uint32_t pos = 0;                                          // decoded bytes of this frame so far
     uint32_t flushed = 0;                                      // bytes of this frame already written to global memory
@@ -4713,6 +4721,7 @@ void lz4_frames_decode2_kernel(const uint8_t* __restrict__ in, const uint4* __re
     const uint32_t role = sgpr(threadIdx.x >> 6);
     const uint32_t f = blockIdx.x;
     const uint32_t b0 = frame_first[f], b1 = frame_first[f + 1];
+    if (lz4_decode_frame_struck((uint64_t)f * frame_stride, remap, remap_bytes)) return;      // (the whole workgroup: f is its frame)
     if (threadIdx.x < 8) ctrl[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t frame_out = lz4_decode_frame_out((uint64_t)f * frame_stride, remap, remap_bytes);
@@ -4750,6 +4759,7 @@ void lz4_stored_frames_copy_kernel(const uint8_t* __restrict__ in, const uint4* 
     const uint4 e = blk[b0];
     if (!(e.z >> 31)) return;
     const uint32_t sz = e.z & 0x7fffffffu;
+    if (lz4_decode_frame_struck((uint64_t)f * frame_stride, remap, remap_bytes)) return;
     const uint64_t o = lz4_decode_frame_out((uint64_t)f * frame_stride, remap, remap_bytes);
     if (o + sz > out_bytes) return;                              // the decode kernel reports it
     const uint32_t begin = slice * DEC_COPY_SLICE;
@@ -6000,7 +6010,7 @@ hipError_t launch_lz4_frame_scan(const uint32_t* csize, uint64_t nchunks, uint64
 // Stored chunks IN FRONT of j (their bodies lie where gathered frames go) need the stash pass first: status 4, the host runs the
 // separate kernels.  guard[0] != 0 (chunks left to the dense pass): status 2 as before.
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t TAIL_THREADS = 256;
+constexpr uint32_t TAIL_THREADS = 64;         // (one wave: with calls in flight a workgroup of four waited for a CU with room for all four -- 0.23 ms against 0.10)
 __global__ __launch_bounds__(TAIL_THREADS)
 void lz4_inplace_tail_fused_kernel(uint8_t* __restrict__ out, uint64_t t0, uint64_t in_stride, uint64_t total, uint32_t chunk, uint64_t nchunks,
                                    uint32_t cpb, const uint8_t* __restrict__ scratch, uint64_t stride, const uint32_t* __restrict__ csize,
