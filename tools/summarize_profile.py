@@ -55,7 +55,8 @@ def short(name):
         if args[0] == "true":
             return "lz4_linked"
         return "lz4_chunks_dense" if args[1] == "true" else ("lz4_chunks_accel" if len(args) > 2 and args[2] == "true" else "lz4_chunks")
-    for k, v in (("lz4_dedupe_clear_kernel", "lz4_dedupe_clear"), ("lz4_inplace_finish_kernel", "lz4_inplace_finish")):
+    for k, v in (("lz4_dedupe_clear_kernel", "lz4_dedupe_clear"), ("lz4_inplace_finish_kernel", "lz4_inplace_finish"),
+                 ("lz4_inplace_tail_fused_kernel", "lz4_inplace_tail_fused")):
         if base.startswith(k):
             return v
     return SHORT.get(base, base)
