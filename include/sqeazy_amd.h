@@ -203,6 +203,9 @@ SQY_FUNCTION_PREFIX void SQYAMD_Release_Workspace(void);
  *                                     instead of reading the plane stream again (0: it reads)
  *   "transpose_blocks_per_cu"         32 [SQY_TRANSPOSE_BLOCKS_PER_CU=<1..64>]  frames in place: workgroups (two wavefronts) of the transposer's grid
  *                                     per CU (32: as many as fit; fewer leave room for the small kernels of other calls in flight -- measured: slower)
+ *   "stored_tail_index"               1 [SQY_NO_STORED_TAIL_INDEX=1 -> 0]  decode of the chunked layout: the stored frames at the end of the LZ4
+ *                                     stream (bit planes of noise) are looked for where they must start, the scan for frame headers stops in
+ *                                     front of them (0: it reads the whole stream)
  * Set: 0 = done, 1 = unknown name or value out of range.  Get: the value, -1 for an unknown name. */
 SQY_FUNCTION_PREFIX int SQYAMD_Set_Option(const char* name, long value);
 SQY_FUNCTION_PREFIX long SQYAMD_Get_Option(const char* name);

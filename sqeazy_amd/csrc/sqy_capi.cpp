@@ -69,12 +69,13 @@ struct Options {
     std::atomic<long> decode_two_waves;                 // chunked-layout decode: two wavefronts per frame (one parses, one copies)
     std::atomic<long> noise_digest;                     // frames in place: the transpose leaves the noise digest, the parse proves noise chunks empty from it
     std::atomic<long> transpose_blocks_per_cu;          // frames in place: workgroups of the transposer's grid per CU
+    std::atomic<long> stored_tail_index;                // decode, chunked layout: the stored frames at the stream's end are found where they must start, not by the scan
     Options()
         : transpose_chain(env_flag("SQY_NO_TRANSPOSE_CHAIN") ? 0 : 1), transpose_chain_caller_streams(env_flag("SQY_TRANSPOSE_CHAIN_CALLER_STREAMS")),
           block_parallel(env_flag("SQY_NO_BLOCK_PARALLEL") ? 0 : 1), block_parallel_warmup(env_number("SQY_BLOCK_PARALLEL_WARMUP", 65536, 0, kWarmupMax)),
           block_parallel_stats(env_flag("SQY_BLOCK_PARALLEL_STATS")), tail_scan(env_flag("SQY_NO_TAIL_SCAN") ? 0 : 1),
           decode_two_waves(env_flag("SQY_NO_DECODE_TWO_WAVES") ? 0 : 1), noise_digest(env_flag("SQY_NO_NOISE_DIGEST") ? 0 : 1),
-          transpose_blocks_per_cu(env_number("SQY_TRANSPOSE_BLOCKS_PER_CU", 32, 1, 64)) { sqy::set_bitswap1_blocks_per_cu(transpose_blocks_per_cu.load()); }
+          transpose_blocks_per_cu(env_number("SQY_TRANSPOSE_BLOCKS_PER_CU", 32, 1, 64)), stored_tail_index(env_flag("SQY_NO_STORED_TAIL_INDEX") ? 0 : 1) { sqy::set_bitswap1_blocks_per_cu(transpose_blocks_per_cu.load()); }
     std::atomic<long>* find(const char* name)
     {
         if (!name) return nullptr;
@@ -87,6 +88,7 @@ struct Options {
         if (!std::strcmp(name, "decode_two_waves")) return &decode_two_waves;
         if (!std::strcmp(name, "noise_digest")) return &noise_digest;
         if (!std::strcmp(name, "transpose_blocks_per_cu")) return &transpose_blocks_per_cu;
+        if (!std::strcmp(name, "stored_tail_index")) return &stored_tail_index;
         return nullptr;
     }
 };
@@ -1444,16 +1446,23 @@ int decode_on_device(Context& cx, const void* d_src_v, uint64_t srclen, void* d_
                 void* cand = blk + idx_bytes;
                 if (ws->csize.ensure(64)) return 1;
                 uint32_t* counts = static_cast<uint32_t*>(ws->csize.p);          // [0..3] index result, [4] decode error flag
-                SQY_HIP(hipMemsetAsync(counts, 0, 32, stream));
-                uint32_t hc[4] = {0, 0, 100, 0};
+                SQY_HIP(hipMemsetAsync(counts, 0, 64, stream));
+                uint32_t hc[8] = {0, 0, 100, 0, 0, 0, 0, 0};
                 if (nchunks > 1) {
-                    // chunked layout expected: rank the frame list in parallel
-                    {
-                        ProfScope ps("lz4_frame_rank", stream, pend);
-                        SQY_HIP(sqy::launch_lz4_frame_rank(cur, cur_bytes, blk, frame_first, max_blocks, counts, nchunks, cand, stream));
+                    // chunked layout expected: rank the frame list in parallel.  The frames at the stream's end that are stored blocks of
+                    // the chunk size are found where they must start, not by the scan (hc[6] of them); should the ranking give up with
+                    // such a tail, the whole stream is scanned before the walk below is tried.
+                    for (int with_tail = g_opt.stored_tail_index.load() ? 1 : 0; with_tail >= 0; --with_tail) {
+                        {
+                            ProfScope ps("lz4_frame_rank", stream, pend);
+                            SQY_HIP(sqy::launch_lz4_frame_rank(cur, cur_bytes, blk, frame_first, max_blocks, counts, nchunks, cand, stream,
+                                                               with_tail ? chunk : 0, with_tail ? total - (nchunks - 1) * chunk : 0));
+                        }
+                        SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
+                        SQY_HIP(hipStreamSynchronize(stream));
+                        if (hc[2] != 100 || hc[6] == 0) break;
+                        SQY_HIP(hipMemsetAsync(counts, 0, 64, stream));
                     }
-                    SQY_HIP(hipMemcpyAsync(hc, counts, sizeof(hc), hipMemcpyDeviceToHost, stream));
-                    SQY_HIP(hipStreamSynchronize(stream));
                 }
                 if (hc[2] == 100) {
                     // one frame, the serial block-linked layout, or anything the parallel ranking does not cover

@@ -189,7 +189,9 @@ hipError_t launch_lz4_frame_index(const uint8_t* in, uint64_t n, void* blk, uint
 // parallel variant for the chunked layout (single-block frames): counts[2] == 100 means "not covered, run the serial walk"
 uint64_t lz4_frame_rank_scratch_bytes(uint64_t expected_frames);
 hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
-                                 uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream);
+                                 uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream, uint64_t chunk = 0, uint64_t last = 0);
+// (chunk, last: the bytes every frame but the last / the last frame decodes to -- frames at the stream's end that are STORED blocks of
+//  those sizes are found where they must start instead of by the scan; 0 = scan everything.  counts: 16 words, [6] = frames found so)
 // frame f decodes to out + f*frame_stride; every block decodes to at most block_bytes
 // ONE block-linked frame (the serial layout) decoded block-parallel: every block at once with the history as an unknown (16-bit
 // references in `refs`, out_bytes words), the tails resolved in order by one workgroup, the rest at once.  blk: the frame's blocks

@@ -826,7 +826,10 @@ extern "C" __attribute__((visibility("default"))) int SQYAMD_Exp_Set_Buffer(void
 #define SQY_EXP(...)
 #endif
 constexpr uint32_t LZ4_RINGLESS_U = 64u * 15u;   // probes since the last match from which on the batches stride over the ring (step >= 16)
-constexpr uint32_t LZ4_WIN_LEAN = 8192, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
+#ifndef SQY_EXP_WIN_LEAN
+#define SQY_EXP_WIN_LEAN 8192
+#endif
+constexpr uint32_t LZ4_WIN_LEAN = SQY_EXP_WIN_LEAN, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 template <uint32_t LZ4_WIN>
 struct Lz4WindowT {
@@ -3278,11 +3281,82 @@ __device__ __noinline__ void frame_cand_record(uint64_t n, FrameSlot* __restrict
     }
 }
 
+// The stored tail (round 6).  Bit planes of noise end up as stored frames: 99.5 % of the bench stack's blob, all of them the same size,
+// and the scan above reads every byte of them to find nothing.  The decoder knows the chunk size, so it knows where the LAST frames would
+// start if they were stored ones: n - (15 + last), and from there every 15 + chunk bytes towards the front.  One workgroup looks at those
+// places -- magic, a FLG the encoder writes (no block checksum), the size field of a stored block of exactly that size, the end mark
+// behind it, the four zero bytes in front -- and takes the longest run of them that reaches the end of the stream: those m places go into
+// the candidate list as the scan would have put them, *scan_end = the first of them, and the scan stops there.  Nothing is taken on
+// trust: the ranking still has to reach the first of these from position 0 and the last one's end mark has to sit on the stream's end; a
+// stream built to fool this (stored payloads that hold such headers at those very places) makes the ranking give up, and the host scans
+// again with last = 0 (no tail), then walks.
+__global__ __launch_bounds__(1024)
+void lz4_frame_tail_kernel(const uint8_t* __restrict__ in, uint64_t n, uint64_t chunk, uint64_t last, uint32_t kmax, FrameSlot* __restrict__ table,
+                           uint32_t mask, FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand,
+                           const uint32_t* __restrict__ hint, uint32_t* __restrict__ tail_frames, unsigned long long* __restrict__ scan_end)
+{
+    __shared__ uint32_t first_bad;
+    const uint32_t tid = threadIdx.x;
+    if (tid == 0) { first_bad = kmax + 1u; *scan_end = n; *tail_frames = 0u; }
+    __syncthreads();
+    if (*hint || last == 0 || last > chunk || chunk >= 0x7fffffffull || n < last + 15) return;
+    // place k = 1 .. kmax from the end: start(k) = n - (15 + last) - (k - 1) * (15 + chunk)
+    auto start_of = [&](uint32_t k) -> int64_t { return (int64_t)n - (int64_t)(15 + last) - (int64_t)(k - 1u) * (int64_t)(15 + chunk); };
+    // (every load of a thread's four places in flight at once, at clamped addresses: a place costs one trip to memory, not five)
+    for (uint32_t k0 = 1u; k0 <= kmax && k0 < first_bad; k0 += 4096u) {
+        uint32_t pz[4], mg[4], w1[4], w2[4], em[4];
+        bool in_range[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = k0 + tid + 1024u * (uint32_t)j;
+            const int64_t p = start_of(k);
+            in_range[j] = k <= kmax && p >= 0 && p != 1 && p != 2 && p != 3;
+            const uint64_t q = in_range[j] ? (uint64_t)p : (uint64_t)start_of(1u);
+            const uint64_t raw = (in_range[j] && k != 1u) ? chunk : last;
+            const uint8_t* f = in + q;
+            pz[j] = q >= 4 ? ld_u32(f - 4) : 0u;
+            mg[j] = ld_u32(f); w1[j] = ld_u32(f + 4); w2[j] = ld_u32(f + 8);
+            em[j] = ld_u32(f + 11 + raw);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t k = k0 + tid + 1024u * (uint32_t)j;
+            if (k > kmax) continue;
+            const uint32_t raw = (uint32_t)(k == 1u ? last : chunk);
+            const uint32_t flg = w1[j] & 0xffu, field = (w1[j] >> 24) | (w2[j] << 8);
+            // magic, a FLG the encoder writes without block checksum (as frame_cand_record), a stored block of that size, the end mark
+            // behind it (the last one's ends the stream), what the frame in front ends with
+            const bool ok = in_range[j] && mg[j] == 0x184D2204u && (flg >> 6) == 1u && !(flg & 0x1Du) && field == (0x80000000u | raw) && em[j] == 0u && pz[j] == 0u;
+            if (!ok) atomicMin(&first_bad, k);
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    const uint32_t m = first_bad - 1u;
+    if (m == 0u) return;
+    for (uint32_t k = 1u + tid; k <= m; k += 1024u) {
+        const uint64_t pos = (uint64_t)start_of(k);
+        const uint32_t idx = atomicAdd(ncand, 1u);
+        if (idx >= cap) continue;                                                     // (the rank kernel sees ncand > cap and gives up)
+        FrameCand c;
+        c.pos = pos; c.field = 0x80000000u | (uint32_t)(k == 1u ? last : chunk); c.flags = (pos >= 4 ? 1u : 0u) | ((uint32_t)in[pos + 4] << 8);
+        list[idx] = c;
+        uint32_t s_ = cand_slot(pos, mask);
+        for (uint32_t probe = 0; probe <= mask; ++probe, s_ = (s_ + 1) & mask) {
+            if (atomicCAS(&table[s_].key, 0ull, (unsigned long long)(pos + 1)) == 0ull) { table[s_].idx = idx; break; }
+        }
+    }
+    if (tid == 0) { *scan_end = (unsigned long long)start_of(m); *tail_frames = m; }
+}
+
 __global__ __launch_bounds__(256)
-void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n, FrameSlot* __restrict__ table, uint32_t mask,
-                                 FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand, const uint32_t* __restrict__ hint)
+void lz4_frame_candidates_kernel(const uint8_t* __restrict__ in, uint64_t n_stream, FrameSlot* __restrict__ table, uint32_t mask,
+                                 FrameCand* __restrict__ list, uint32_t cap, uint32_t* __restrict__ ncand, const uint32_t* __restrict__ hint,
+                                 const unsigned long long* __restrict__ scan_end)
 {
     if (*hint) return;
+    // (the stored tail, above: its frames are on the list already; a frame that starts in front of it ends in front of it)
+    const uint64_t n = *scan_end < n_stream ? (uint64_t)*scan_end : n_stream;
     // a thread inspects 16 start positions [base, base + 16); it needs the bytes [base - 4, base + 28).  Four such windows per thread and
     // step, all their loads issued before the first is looked at
     const uint64_t stride = (uint64_t)gridDim.x * 256;
@@ -6410,7 +6484,7 @@ uint64_t lz4_frame_rank_scratch_bytes(uint64_t expected_frames)
 }
 
 hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint32_t* frame_first, uint64_t max_blocks,
-                                 uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream)
+                                 uint32_t* counts, uint64_t expected_frames, void* scratch, hipStream_t stream, uint64_t chunk, uint64_t last)
 {
     const uint64_t cap = expected_frames * 4 + 1024;
     uint64_t slots = 1024;
@@ -6430,9 +6504,13 @@ hipError_t launch_lz4_frame_rank(const uint8_t* in, uint64_t n, void* blk, uint3
     if (blocks > gcap) blocks = gcap;
     if (blocks == 0) blocks = 1;
     uint32_t* hint = counts + 5;                                          // (counts: [0..3] the index, [4] the decoders' flag, [5] this)
+    uint32_t* tail_frames = counts + 6;                                   // [6] frames of the stored tail the scan skipped, [8..9] where the scan ends
+    unsigned long long* scan_end = reinterpret_cast<unsigned long long*>(counts + 8);
     hipLaunchKernelGGL(lz4_frame_probe_kernel, dim3(1), dim3(1), 0, stream, in, n, hint);
+    hipLaunchKernelGGL(lz4_frame_tail_kernel, dim3(1), dim3(1024), 0, stream, in, n, chunk, last, (uint32_t)std::min<uint64_t>(expected_frames, 1u << 20), table,
+                       (uint32_t)(slots - 1), list, (uint32_t)cap, ncand, (const uint32_t*)hint, tail_frames, scan_end);
     hipLaunchKernelGGL(lz4_frame_candidates_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, in, n, table, (uint32_t)(slots - 1), list,
-                       (uint32_t)cap, ncand, (const uint32_t*)hint);
+                       (uint32_t)cap, ncand, (const uint32_t*)hint, (const unsigned long long*)scan_end);
     // LDS for the rank kernel's work arrays: 9 bytes per candidate (the frames expected + room for false magics), when that fits
     uint64_t lds_entries = (expected_frames + 1024 + 2 + 7) & ~(uint64_t)7;
     if (lds_entries > 16000) lds_entries = 0;                            // (144 KiB of the CU's 160)

@@ -816,3 +816,70 @@ def test_damaged_blocks_never_write_outside_the_volume(sqy, oracle, options, pip
             assert bool((d_out[:PAD] == 0xC3).all()) and bool((d_out[PAD + vol.size:] == 0xC3).all()), (what, two, "bytes outside the volume were written")
             if rc == 0:
                 assert d_out[PAD:PAD + vol.size].numel() == vol.size
+
+
+def _rank_launches(sqy):
+    return sum(v[1] for k, v in sqy.profile_get().items() if k == "lz4_frame_rank")
+
+
+@pytest.mark.parametrize("cfg", ["", "(blocksize_kb=64,framestep_kb=64)"])
+def test_stored_tail_is_found_where_it_must_start(sqy, oracle, options, cfg):
+    """round 6: the stored frames at the end of an LZ4 stream are looked for at n - (15 + last) - k * (15 + chunk) instead of by the scan
+    for frame headers; the ranking still has to reach them from position 0.  Streams with a long tail, none, a compressed frame inside
+    the noise, a short last frame, the first frame as part of the tail -- and one built to fool the look: a stored payload that holds a
+    header, zeros in front and the end mark of ANOTHER frame behind, exactly where a tail frame would start (the ranking gives up, the
+    whole stream is scanned: two launches)."""
+    chunk = (64 << 10) if cfg else (256 << 10)
+    rng = np.random.default_rng(61)
+    noise = lambda n: rng.integers(0, 256, n, dtype=np.uint8)
+    zeros = lambda n: np.zeros(n, np.uint8)
+    runs = lambda n: np.repeat(rng.integers(0, 256, n // 100 + 1, dtype=np.uint8), 100)[:n]
+    streams = {
+        "long tail, short last": [zeros(chunk), runs(chunk)] + [noise(chunk) for _ in range(5)] + [noise(12345)],
+        "all stored, whole chunks": [noise(chunk) for _ in range(6)],
+        "no tail": [noise(chunk), noise(chunk), zeros(chunk)],
+        "compressed inside the noise": [noise(chunk), noise(chunk), zeros(chunk), noise(chunk), noise(chunk), noise(chunk)],
+        "short compressed last": [noise(chunk), noise(chunk), zeros(777)],
+        "tail of one": [runs(chunk), zeros(chunk), noise(chunk)],
+        "tiny last": [noise(chunk), noise(chunk), noise(1)],
+    }
+    for name, parts in streams.items():
+        data = np.concatenate(parts)
+        blob = oracle.pipeline_encode("lz4" + cfg, data.reshape(1, 1, -1), nthreads=2)
+        for on in (1, 0):
+            options("stored_tail_index", on)
+            sqy.profile_reset(); sqy.profile_enable(True)
+            rc, back = sqy.decode(blob)
+            sqy.profile_enable(False)
+            assert rc == 0 and np.array_equal(back.reshape(-1), data), (name, on)
+            assert _rank_launches(sqy) == 1, (name, on)
+    # the stream that fools the look: Z, A (noise), B (zeros: c bytes as a frame), C (noise, the last)
+    parts = [noise(chunk), noise(chunk), zeros(chunk), noise(chunk - 4321)]
+    data = np.concatenate(parts)
+    blob = oracle.pipeline_encode("lz4" + cfg, data.reshape(1, 1, -1), nthreads=2)
+    h = oracle.header_unpack(blob)
+    payload = blob[h["size"]:]
+    c = len(payload) - 2 * (15 + chunk) - (15 + chunk - 4321)
+    assert 64 < c < chunk // 2
+    fake = bytes(4) + payload[:7] + int(0x80000000 | chunk).to_bytes(4, "little")
+    at = chunk + (c - 11 - 4)                                   # in A's bytes: a frame start c bytes behind A's own
+    data[at:at + len(fake)] = np.frombuffer(fake, np.uint8)
+    blob = oracle.pipeline_encode("lz4" + cfg, data.reshape(1, 1, -1), nthreads=2)
+    payload = blob[h["size"]:]
+    t2 = len(payload) - (15 + chunk - 4321) - (15 + chunk)
+    assert payload[t2:t2 + 4] == bytes([0x04, 0x22, 0x4D, 0x18]) and t2 == 15 + chunk + c
+    for on, launches in ((1, 2), (0, 1)):
+        options("stored_tail_index", on)
+        sqy.profile_reset(); sqy.profile_enable(True)
+        rc, back = sqy.decode(blob)
+        sqy.profile_enable(False)
+        assert rc == 0 and np.array_equal(back.reshape(-1), data), on
+        assert _rank_launches(sqy) == launches, on
+    # bit planes: the bench stack's shape of blob (compressed head, stored tail), both ways
+    vol = synth.stack((16, 256, 256))
+    rc, blob = sqy.encode("bitswap1->lz4", vol, nthreads=2)
+    assert rc == 0
+    for on in (1, 0):
+        options("stored_tail_index", on)
+        rc, back = sqy.decode(blob)
+        assert rc == 0 and np.array_equal(back, vol)
