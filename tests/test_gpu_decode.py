@@ -883,3 +883,26 @@ def test_stored_tail_is_found_where_it_must_start(sqy, oracle, options, cfg):
         options("stored_tail_index", on)
         rc, back = sqy.decode(blob)
         assert rc == 0 and np.array_equal(back, vol)
+
+
+def test_stored_tail_random_streams(sqy, oracle, options):
+    """random orders of stored and compressible chunks, random last lengths: the decode with and without the look at the stored tail"""
+    chunk = 64 << 10
+    cfg = "(blocksize_kb=64,framestep_kb=64)"
+    rng = np.random.default_rng(62)
+    for case in range(40):
+        nch = int(rng.integers(2, 24))
+        parts = []
+        for i in range(nch):
+            n = chunk if i + 1 < nch else int(rng.choice([1, 5, 15, 16, 17, 4095, chunk - 1, chunk, int(rng.integers(1, chunk + 1))]))
+            kind = rng.integers(0, 4) if case % 3 else 0              # every third stream: noise only
+            if kind == 0: parts.append(rng.integers(0, 256, n, dtype=np.uint8))
+            elif kind == 1: parts.append(np.zeros(n, np.uint8))
+            elif kind == 2: parts.append(np.repeat(rng.integers(0, 256, n // 50 + 1, dtype=np.uint8), 50)[:n])
+            else: parts.append(np.tile(rng.integers(0, 256, 300, dtype=np.uint8), n // 300 + 1)[:n])
+        data = np.concatenate(parts)
+        blob = oracle.pipeline_encode("lz4" + cfg, data.reshape(1, 1, -1), nthreads=2)
+        for on in (1, 0):
+            options("stored_tail_index", on)
+            rc, back = sqy.decode(blob)
+            assert rc == 0 and np.array_equal(back.reshape(-1), data), (case, on, nch, len(parts[-1]))
