@@ -100,7 +100,7 @@ SQY_FUNCTION_PREFIX int SQY_Decode_UI8(const char* src, long srclength, char* ds
 
 /* d_src / d_dst are device pointers on the current HIP device; dst_capacity is checked (1 when the
  * blob does not fit).  hip_stream is a hipStream_t (NULL = default stream).  The call returns after the
- * blob is complete in d_dst. */
+ * blob is complete in d_dst.  All work is queued on hip_stream: whatever made d_src has to be in front of it there (or complete). */
 SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI16_Device(const char* pipeline, const void* d_src, const long* shape,
                                                           unsigned shape_size, void* d_dst, long dst_capacity,
                                                           long* dstlength, int nthreads, void* hip_stream);
@@ -138,7 +138,9 @@ SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_UI8_DeviceAt_Frames(const char* pi
  * SQYAMD_PipelineEncode_*_DeviceAt would encode it (every blob is a complete sqeazy blob, bytes identical to the single calls).
  * Blob i lies inside d_dst[i*slab_capacity, (i+1)*slab_capacity) (slab_capacity >= SQY_Pipeline_Max_Compressed_Length_3D_* of the
  * largest slab): offsets[i] = its start relative to d_dst, lengths[i] = its bytes.  `inflight` slab calls (<= 0: three) run at a
- * time on library-owned streams: the transposes, LZ4 parses and gathers of different slabs overlap.  Returns when all are done. */
+ * time on library-owned streams: the transposes, LZ4 parses and gathers of different slabs overlap.  Returns when all are done.
+ * Ordering: the slab calls start behind everything queued on the DEFAULT stream when the call is made (the kernels that made d_src, a
+ * fill of d_dst); work on other streams that touches d_src or d_dst has to be complete (synchronised) before the call. */
 SQY_FUNCTION_PREFIX int SQYAMD_PipelineEncode_Slabs_UI16_Device(const char* pipeline, const void* d_src, const long* shape,
                                                                 unsigned shape_size, int nslabs, void* d_dst, long slab_capacity,
                                                                 long* offsets, long* lengths, int nthreads, int inflight);

@@ -2045,8 +2045,22 @@ static int encode_slabs(const char* pipeline, const void* d_src, const long* sha
     if (inflight > (int)kMaxCtxPerDev) inflight = (int)kMaxCtxPerDev;
     std::atomic<int> first_error(0);
     for (int i = 0; i < nslabs; ++i) { offsets[i] = 0; lengths[i] = 0; }      // (defined whatever happens below)
+    // The slab calls run on streams of the library's own (non-blocking ones: nothing orders them behind the default stream by itself), the
+    // caller passes none -- so what the caller has queued on the DEFAULT stream up to now (the kernel that makes d_src, a fill of d_dst: a
+    // framework's allocations and copies usually live there) is put in front of them here: an event on the default stream, waited for by
+    // every worker's stream.  Found by the full-size slab test of round 6, whose fill of d_dst overtook the first slabs' transposes and
+    // was parsed in their place.  Work on OTHER streams of the caller has to be complete when the call is made (include/sqeazy_amd.h).
+    hipEvent_t front = nullptr;
+    if (hipEventCreateWithFlags(&front, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); front = nullptr; }
+    struct EventGuard { hipEvent_t& e; ~EventGuard() { if (e) (void)hipEventDestroy(e); } } front_guard{front};
+    if (!front || hipEventRecord(front, nullptr) != hipSuccess) {            // (no event to be had: wait here for everything instead)
+        (void)hipGetLastError();
+        if (front) { (void)hipEventDestroy(front); front = nullptr; }
+        if (hipDeviceSynchronize() != hipSuccess) return 1;
+    }
     auto work = [&](int t) {
         if (hipSetDevice(dev) != hipSuccess) { int z = 0; first_error.compare_exchange_strong(z, 1); return; }
+        bool ordered = front == nullptr;
         for (int i = t; i < nslabs && first_error.load() == 0; i += inflight) {
             const long z0 = (long)i * base + std::min<long>(i, rem), nz = base + (i < rem ? 1 : 0);
             std::vector<long> shp(shape, shape + rank);
@@ -2058,6 +2072,8 @@ static int encode_slabs(const char* pipeline, const void* d_src, const long* sha
                 if (!lease.ctx) rc = 1;
                 else {
                     hipStream_t stream = lease.ctx->own_stream();
+                    // (every lease may be another context with another stream: each call waits; an event that has completed costs nothing)
+                    if (stream && !ordered && hipStreamWaitEvent(stream, front, 0) != hipSuccess) { (void)hipGetLastError(); stream = nullptr; }
                     rc = stream ? encode_on_device(*lease.ctx, pipeline, static_cast<const char*>(d_src) + (uint64_t)z0 * per_frame, shp.data(), rank,
                                                    elem_size, static_cast<char*>(d_dst) + (uint64_t)i * (uint64_t)slab_capacity,
                                                    (uint64_t)slab_capacity, &len, nthreads, stream, &at)

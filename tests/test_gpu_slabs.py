@@ -38,6 +38,32 @@ def test_slabs_call_equals_single_calls(sqy, oracle, pipeline, shape, dtype, nsl
         assert got == oracle.pipeline_encode(pipeline, vol[z0:z0 + nz]), (pipeline, i)
 
 
+def test_slabs_call_starts_behind_the_default_stream(sqy, oracle):
+    """The slab calls run on streams of the library's own; what the caller has queued on the DEFAULT stream -- here: the kernels that make
+    the volume and a fill of the output buffer, behind a pile of other work -- has to be in front of them (round 6: the full-size slab
+    test's fill of d_dst overtook the first slabs' transposes and was parsed in their place: 8.6 MB blobs of 0x5A instead of 1.2 GB)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    pipeline, shape, nslabs = "bitswap1->lz4", (64, 256, 256), 4
+    vol = synth.stack(shape, np.uint16)
+    want = [oracle.pipeline_encode(pipeline, vol[multi.slab_range(shape[0], i, nslabs)[0]:sum(multi.slab_range(shape[0], i, nslabs))]) for i in range(nslabs)]
+    cap = (sqy.max_compressed_length(pipeline, (shape[0] // nslabs,) + shape[1:], np.uint16) + 255) & ~255
+    h_vol = torch.from_numpy(vol.copy()).pin_memory()
+    ballast = torch.empty(1 << 30, dtype=torch.uint8, device=dev)
+    for fill in (0x5A, 0):
+        d_vol = torch.zeros(shape, dtype=torch.uint16, device=dev)
+        out = torch.empty(cap * nslabs, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        for k in range(8):
+            ballast.fill_(k)                                   # a few milliseconds of work in front
+        d_vol.copy_(h_vol, non_blocking=True)                  # the volume arrives behind it ...
+        out.fill_(fill)                                        # ... and so does the fill of the output
+        rc, offs, lens = sqy.encode_slabs_device(pipeline, d_vol.data_ptr(), shape, np.uint16, nslabs, out.data_ptr(), cap, inflight=3)
+        assert rc == 0
+        for i in range(nslabs):
+            assert bytes(out[offs[i]:offs[i] + lens[i]].cpu().numpy().tobytes()) == want[i], (fill, i)
+
+
 def test_slabs_call_errors(sqy):
     import torch
     dev = torch.device("cuda", 0)
