@@ -829,6 +829,9 @@ constexpr uint32_t LZ4_RINGLESS_U = 64u * 15u;   // probes since the last match 
 #ifndef SQY_EXP_WIN_LEAN
 #define SQY_EXP_WIN_LEAN 8192
 #endif
+#ifndef SQY_EXP_DG_AHEAD
+#define SQY_EXP_DG_AHEAD 8
+#endif
 constexpr uint32_t LZ4_WIN_LEAN = SQY_EXP_WIN_LEAN, LZ4_WIN_DENSE = 32768, LZ4_FB = 1024, LZ4_AHEAD = 2048, LZ4_MIRROR = 16;
 
 template <uint32_t LZ4_WIN>
@@ -1293,6 +1296,14 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
     // pieces is all zero (those write no entries: what lies there is a former call's)
     const uint32_t* __restrict__ dgp = nullptr;
     uint32_t dg_words = 0;
+    // the digest's batches are fetched DG_AHEAD batches ahead of their use (round 6: a batch's entries are 256 bytes in a row, where they
+    // lie is known as long as nothing is found, and with calls in flight a load takes a microsecond -- a chunk of noise spent three
+    // quarters of its 120 us waiting for its 76 loads one after the other): dgq[0] holds the batch that starts at probe dgq_U
+    constexpr int DG_AHEAD = SQY_EXP_DG_AHEAD;
+    uint32_t dgq[DG_AHEAD];
+    uint32_t dgq_U = 0xffffffffu;
+#pragma unroll
+    for (int k = 0; k < DG_AHEAD; ++k) dgq[k] = 0u;
     if constexpr (!LINKED && !DENSE && !ACCEL) {
         if (dd.digest && n == chunk && dd.holes_map &&
             (uint32_t)dd.holes_map[blk * (1u + ((chunk >> 10) + 63u) / 64u)] == 0u) {
@@ -1850,45 +1861,80 @@ void lz4_chunks_kernel(const uint8_t* __restrict__ in, uint64_t total, uint32_t 
             // bandwidth from the other calls' transposes, which set the pace), and the sparse planes of a diff3x3x1 residual lost up to 12 %
             // when the proof was tried right behind the lean loop: profiles/r06_experiments.txt.)
             while (!DENSE && !ACCEL && !batch_done && U >= LZ4_RINGLESS_U && put2 == 0xffffffffu) {
-                const uint32_t s_first = (62 + U) >> 6;
-                const uint32_t ustar = 64 * (s_first + 1) - 62;
-                const uint32_t u = U + lane;
-                const uint32_t pos = P + s_first * lane + (u > ustar ? u - ustar : 0u);
-                const uint32_t nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
-                if (ballot(nxt <= mflimitPlusOne) != ~0ull) break;
-                uint32_t h, mytag;
-                // Nothing has matched since the chunk began (anchor == p0: the search started at probe 1 and these are the positions the
-                // transpose foresaw): bucket and tag of this batch's probes come from the digest, 256 bytes instead of 64 scattered reads
-                // of the plane stream.  An entry of all ones: the probe's five bytes end in another wave's piece -- that lane looks itself.
-                if (dgp && anchor == p0 && U >= 961u && U - 961u + 64u <= dg_words) {
-                    const uint32_t e = dgp[U - 961u + (uint32_t)lane];
-                    h = e >> 16; mytag = e & 0xffffu;
-                    if (ballot(e == 0xffffffffu)) {
-                        if (e == 0xffffffffu) {
-                            const uint64_t seq = glb_ld_u64(w.src + pos);
-                            h = lz4_hash5(seq); mytag = tag_of((uint32_t)seq);
-                        }
-                    }
-                } else {
-                    const uint64_t seq = glb_ld_u64(w.src + pos);          // (the ring was left behind at these strides)
-                    h = lz4_hash5(seq);
-                    mytag = tag_of((uint32_t)seq);
-                }
-                const uint32_t mine = (pos << tsh) | mytag;
-                const uint32_t oe = table[h];
-                const uint32_t seen = atomicMax(&table[h], mine);
-                wave_lds_sync();
-                const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
-                const uint32_t sp = seen >> tsh;
-                const bool in_batch = sp >= P && seen != oe;
-                const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
-                if (ballot(trouble)) {
-                    table[h] = oe;                                          // (same value from every probe of a bucket)
+                // where this batch's probes are; false = the batch reaches the end of the search (the generic path takes it)
+                auto geometry = [&](uint32_t& pos, uint32_t& nxt) -> bool {
+                    const uint32_t s_first = (62 + U) >> 6;
+                    const uint32_t ustar = 64 * (s_first + 1) - 62;
+                    const uint32_t u = U + lane;
+                    pos = P + s_first * lane + (u > ustar ? u - ustar : 0u);
+                    nxt = pos + ((u >= ustar) ? s_first + 1 : s_first);
+                    return ballot(nxt <= mflimitPlusOne) == ~0ull;
+                };
+                // the batch's probes against the table; false = one of them may match (the table is as before: the generic path decides)
+                auto enter = [&](uint32_t h, uint32_t mytag, uint32_t pos, uint32_t nxt) -> bool {
+                    const uint32_t mine = (pos << tsh) | mytag;
+                    const uint32_t oe = table[h];
+                    const uint32_t seen = atomicMax(&table[h], mine);
                     wave_lds_sync();
-                    break;
+                    const bool hit_before = (oe & tmask) == mytag && (pos - (oe >> tsh)) <= LZ4_MAXD;
+                    const uint32_t sp = seen >> tsh;
+                    const bool in_batch = sp >= P && seen != oe;
+                    const bool trouble = hit_before || (in_batch && (sp >= pos || (seen & tmask) == mytag));
+                    if (ballot(trouble)) {
+                        table[h] = oe;                                      // (same value from every probe of a bucket)
+                        wave_lds_sync();
+                        return false;
+                    }
+                    P = lane_read(nxt, 63);
+                    U += 64;
+                    return true;
+                };
+                // Nothing has matched since the chunk began (anchor == p0: the search started at probe 1 and these are the positions the
+                // transpose foresaw): bucket and tag of a batch's probes come from the digest, 256 bytes instead of 64 scattered reads
+                // of the plane stream.  An entry of all ones: the probe's five bytes end in another wave's piece -- that lane looks itself.
+                // The entries are fetched DG_AHEAD batches ahead: a pass of DG_AHEAD batches, batch k out of slot k of the queue, the slot
+                // filled again at once for the pass behind (fixed registers: a queue that shifts would have to wait for what it moves).
+                auto digest_ok = [&]() -> bool { return sgpr((uint32_t)(dgp && anchor == p0 && U >= 961u && U - 961u + 64u <= dg_words)) != 0u; };   // (uniform: it decides about P and U)
+                if (digest_ok()) {
+                    SQY_GLB const uint32_t* const dg = (SQY_GLB const uint32_t*)dgp;
+                    // (loads behind the row's end are clamped to its last word: never used -- digest_ok() guards every batch)
+                    auto dg_fetch = [&](uint32_t ahead) -> uint32_t {
+                        const uint32_t ix = U - 961u + 64u * ahead + (uint32_t)lane;
+                        return dg[ix < dg_words ? ix : dg_words - 1u];
+                    };
+                    if (dgq_U != U) {                                       // the first pass, or back from the generic path: fill the queue
+#pragma unroll
+                        for (int k = 0; k < DG_AHEAD; ++k) dgq[k] = dg_fetch((uint32_t)k);
+                    }
+                    dgq_U = 0xffffffffu;
+                    bool on = true;
+#pragma unroll
+                    for (int k = 0; k < DG_AHEAD; ++k) {
+                        if (!on) continue;
+                        uint32_t pos, nxt;
+                        if (!digest_ok() || !geometry(pos, nxt)) { on = false; continue; }
+                        const uint32_t e = dgq[k];
+                        uint32_t h = e >> 16, mytag = e & 0xffffu;
+                        if (ballot(e == 0xffffffffu)) {
+                            if (e == 0xffffffffu) {
+                                const uint64_t seq = glb_ld_u64(w.src + pos);
+                                h = lz4_hash5(seq); mytag = tag_of((uint32_t)seq);
+                            }
+                        }
+                        if (!enter(h, mytag, pos, nxt)) { on = false; continue; }
+                        // the batch DG_AHEAD behind the one just taken, into its slot (U has moved on; fetched only now, when nothing
+                        // reads the slot's old value any more: fetched in front, it went to another register and was MOVED here at the
+                        // end of the step -- behind a wait for the load)
+                        dgq[k] = dg_fetch((uint32_t)DG_AHEAD - 1u);
+                    }
+                    if (!on) break;                                         // (whatever ended the pass: the generic path looks at the batch)
+                    dgq_U = U;                                              // a whole pass: slot k holds the batch k behind U again
+                    continue;
                 }
-                P = lane_read(nxt, 63);
-                U += 64;
+                uint32_t pos, nxt;
+                if (!geometry(pos, nxt)) break;
+                const uint64_t seq = glb_ld_u64(w.src + pos);              // (the ring was left behind at these strides)
+                if (!enter(lz4_hash5(seq), tag_of((uint32_t)seq), pos, nxt)) break;
             }
             SQY_EXP(x_lap(2);)                                  // 2: batches proved empty
             SQY_EXP(x_ngen += 1;)
